@@ -1,0 +1,182 @@
+/*
+ * rmcv_abi.h -- C-ABI of the MI355X-native rmcv detection path (librmcv_hip.so).
+ *
+ * The reference has no plugin/FFI layer: its boundary is the C++ linkage of the
+ * static library `rmcv` (/root/reference/CMakeLists.txt:13-16) consumed through
+ * include/rmcv.h by executable/main.cpp:172-176.  This header is the thin C-ABI
+ * that boundary is re-hosted on: plain pointers and sizes, PODs only, error
+ * codes instead of exceptions.  include/rmcv_shim.hpp layers the reference's own
+ * rm:: signatures on top of it where OpenCV headers exist.
+ *
+ * Every entry point runs on the GPU (hand-written HIP, gfx950).  There is no CPU
+ * fallback: without a usable device rmcv_ctx_create() fails with
+ * RMCV_ERR_NO_DEVICE.
+ *
+ * Threading (reference: one caller thread, executable/main.cpp:55): a context is
+ * single-owner; calls on one context must not overlap.  Input memory is borrowed
+ * read-only and must stay valid until the call (or, for the batch API, the
+ * matching rmcv_batch_sync) returns.  The library never frees caller memory.
+ */
+#ifndef RMCV_ABI_H
+#define RMCV_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMCV_ABI_VERSION 1
+
+/* error codes (0 = ok) */
+#define RMCV_OK 0
+#define RMCV_ERR_BAD_ARG (-1)   /* null pointer, bad size, unsupported value            */
+#define RMCV_ERR_CAPACITY (-2)  /* an output did not fit; the counts report what is needed */
+#define RMCV_ERR_NOMEM (-3)
+#define RMCV_ERR_HIP (-4)       /* a HIP runtime call failed: see rmcv_last_error        */
+#define RMCV_ERR_NO_DEVICE (-5) /* no gfx950 device: this library has no CPU path        */
+
+/* rm::camp -- include/core.h:20-23 */
+#define RMCV_CAMP_RED 0
+#define RMCV_CAMP_BLUE 1
+#define RMCV_CAMP_GUIDELIGHT 2
+#define RMCV_CAMP_NEUTRAL (-1)
+
+/* morphology after the threshold.  The snapshot does MORPH_CLOSE (src/imgproc.cpp:68-69);
+ * the older ExtractColor API (docs/namespacerm.html:854) did a dilate only, which is what
+ * BASELINE.json config 2 names. */
+#define RMCV_MORPH_NONE 0
+#define RMCV_MORPH_DILATE 1
+#define RMCV_MORPH_CLOSE 2
+
+typedef struct { int32_t x, y; } rmcv_point;               /* cv::Point, rm::contour element (core.h:87) */
+typedef struct { float cx, cy, w, h, angle; } rmcv_rrect;  /* cv::RotatedRect */
+
+typedef struct {            /* rm::lightblob, include/core.h:89-99 */
+    float   angle;          /* vertical = 90 */
+    int32_t target;         /* rm::camp */
+    float   center[2];
+    float   vertices[4][2]; /* left-down, left-up, right-up, right-down (core.cpp:265-283) */
+    float   size[2];        /* width = min side, height = max side */
+} rmcv_lightblob;           /* 56 bytes */
+
+typedef struct {            /* the per-frame data members of rm::armour, include/core.h:110-112 */
+    float   icon[4][2];
+    float   vertices[4][2]; /* the bit-exact deliverable */
+    float   bbox[4];        /* cv::Rect2f bounding_box: x, y, width, height */
+    int32_t blob_i, blob_j; /* indices of the two light blobs in the positive list */
+} rmcv_armour;              /* 88 bytes */
+
+typedef struct {            /* the literals of executable/main.cpp:172-176 are the defaults */
+    int32_t camp;           /* enemy colour, CAMP_BLUE     */
+    int32_t lower_bound;    /* 80                          */
+    int32_t morph;          /* RMCV_MORPH_CLOSE            */
+    float   tilt_max;       /* 70                          */
+    float   ratio_lo, ratio_hi; /* 1.5, 80                 */
+    double  area_lo, area_hi;   /* 10, 99999               */
+    float   angle_diff_max; /* 12                          */
+    float   shear_max;      /* 22                          */
+    float   length_ratio_max; /* 0.4                       */
+    int32_t _pad;
+} rmcv_params;
+
+typedef struct {            /* capacities of one context; 0 = default */
+    int32_t max_frames;     /* frames per batch                  (256)   */
+    int32_t max_width;      /*                                   (1920)  */
+    int32_t max_height;     /*                                   (1200)  */
+    int32_t max_contours;   /* contours per frame                (2048)  */
+    int32_t max_points;     /* contour points per frame          (65536) */
+    int32_t max_blobs;      /* positive light blobs per frame    (256)   */
+    int32_t max_armours;    /* armours per frame                 (256)   */
+    int32_t _pad;
+} rmcv_limits;
+
+/* stages of rmcv_batch_run (bit mask); each stage needs the ones below it */
+#define RMCV_STAGE_BINARY 1   /* extract_color up to morphologyEx    src/imgproc.cpp:52-69    */
+#define RMCV_STAGE_CONTOURS 2 /* findContours                        src/imgproc.cpp:71-72    */
+#define RMCV_STAGE_BLOBS 4    /* filter_lightblobs                   src/objdetect.cpp:55-87  */
+#define RMCV_STAGE_ARMOURS 8  /* filter_armours                      src/objdetect.cpp:114-166 */
+#define RMCV_STAGE_ALL 15
+
+/* per-frame status bits reported by rmcv_batch_counts */
+#define RMCV_FRAME_OVF_CONTOURS 1
+#define RMCV_FRAME_OVF_POINTS 2
+#define RMCV_FRAME_OVF_BLOBS 4
+#define RMCV_FRAME_OVF_ARMOURS 8
+#define RMCV_FRAME_SLOW_PATH 16 /* informational: nested components, literal scan was used */
+
+typedef struct rmcv_ctx rmcv_ctx;
+
+int  rmcv_abi_version(void);
+void rmcv_default_params(rmcv_params* p);
+void rmcv_default_limits(rmcv_limits* l);
+
+int  rmcv_ctx_create(int device, const rmcv_limits* limits /* nullable */, rmcv_ctx** out);
+void rmcv_ctx_destroy(rmcv_ctx* ctx);
+const char* rmcv_last_error(const rmcv_ctx* ctx);
+
+/* ---- single frame, host buffers: one call per reference function ---------------------- */
+
+/* rm::extract_color (include/imgproc.h:29, src/imgproc.cpp:50-75).  bgr: CV_8UC3, row pitch
+ * `stride` bytes.  binary_out (h*w bytes, 0/255) may be NULL.  Contours come back as CSR in
+ * cv::findContours(RETR_EXTERNAL, CHAIN_APPROX_NONE) order: offs_out has n_contours+1 entries. */
+int rmcv_extract_color(rmcv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int camp, int lower_bound,
+                       int morph, uint8_t* binary_out, rmcv_point* pts_out, int pts_cap, int32_t* offs_out,
+                       int contours_cap, int32_t* n_contours, int32_t* n_points);
+
+/* rm::filter_lightblobs (include/objdetect.h:47-49, src/objdetect.cpp:55-87).  The negative
+ * list is returned as contour indices.  blob_src (nullable) = contour index of each positive. */
+int rmcv_filter_lightblobs(rmcv_ctx* ctx, const rmcv_point* pts, const int32_t* offs, int n_contours,
+                           float tilt_max, float ratio_lo, float ratio_hi, double area_lo, double area_hi,
+                           int enemy, rmcv_lightblob* blobs_out, int blobs_cap, int32_t* n_blobs,
+                           int32_t* blob_src, int32_t* neg_idx_out, int32_t* n_neg);
+
+/* rm::filter_armours (include/objdetect.h:70-71, src/objdetect.cpp:114-166) */
+int rmcv_filter_armours(rmcv_ctx* ctx, const rmcv_lightblob* blobs, int n_blobs, float angle_diff_max,
+                        float shear_max, float length_ratio_max, int enemy, rmcv_armour* armours_out,
+                        int armours_cap, int32_t* n_armours);
+
+/* cv::fitEllipseDirect on one contour (the step of src/objdetect.cpp:68), for stage-wise parity */
+int rmcv_fit_ellipse(rmcv_ctx* ctx, const rmcv_point* pts, int n, rmcv_rrect* out);
+
+/* ---- batch of independent frames, resident on the device ------------------------------ */
+
+/* copy n_frames host frames (each h rows of `stride` bytes, frames `frame_pitch` bytes apart)
+ * into the context's own HBM buffer */
+int rmcv_batch_upload(rmcv_ctx* ctx, const uint8_t* frames, int n_frames, int w, int h, int stride,
+                      int64_t frame_pitch);
+/* or borrow frames that are already in HBM (e.g. a torch tensor's data_ptr) */
+int rmcv_batch_set_device_frames(rmcv_ctx* ctx, const void* d_frames, int n_frames, int w, int h, int stride,
+                                 int64_t frame_pitch);
+/* enqueue the selected stages on `hip_stream` (a hipStream_t, NULL = the context's stream);
+ * asynchronous: results are valid after rmcv_batch_sync */
+int rmcv_batch_run(rmcv_ctx* ctx, const rmcv_params* p, int stages, void* hip_stream);
+int rmcv_batch_sync(rmcv_ctx* ctx);
+/* same, but brackets every kernel with HIP events on that stream and, after syncing, reports the
+ * milliseconds of each: stage_ms[0]=binary, [1]=contours, [2]=blobs, [3]=armours, [4]=total */
+int rmcv_batch_run_timed(rmcv_ctx* ctx, const rmcv_params* p, int stages, void* hip_stream, float stage_ms[5]);
+
+/* per-frame result sizes (arrays of n_frames entries, any may be NULL) */
+int rmcv_batch_counts(rmcv_ctx* ctx, int32_t* n_contours, int32_t* n_points, int32_t* n_blobs,
+                      int32_t* n_armours, int32_t* status);
+int rmcv_batch_get_binary(rmcv_ctx* ctx, int frame, uint8_t* binary_out);
+int rmcv_batch_get_contours(rmcv_ctx* ctx, int frame, rmcv_point* pts_out, int pts_cap, int32_t* offs_out,
+                            int contours_cap, int32_t* n_contours, int32_t* n_points);
+int rmcv_batch_get_blobs(rmcv_ctx* ctx, int frame, rmcv_lightblob* blobs_out, int cap, int32_t* n_blobs,
+                         int32_t* blob_src);
+/* all armours of the batch, frame-major: frame_offs has n_frames+1 entries */
+int rmcv_batch_get_armours(rmcv_ctx* ctx, rmcv_armour* armours_out, int cap, int32_t* frame_offs,
+                           int32_t* n_total);
+/* device views for a zero-copy hand-over to a collective (RCCL gather of the detections):
+ * d_armours[frame][per_frame_cap], d_counts[frame] */
+int rmcv_batch_device_views(rmcv_ctx* ctx, void** d_armours, void** d_counts, int32_t* per_frame_cap,
+                            int32_t* n_frames);
+
+/* ---- synthetic stream: host generator, integer-only, bit-reproducible --- */
+int      rmcv_synth_frame(uint8_t* bgr, int w, int h, int stride, uint64_t frame_index, int camp, int variant);
+uint64_t rmcv_synth_checksum(const uint8_t* bgr, int w, int h, int stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMCV_ABI_H */

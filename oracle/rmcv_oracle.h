@@ -1,0 +1,111 @@
+/*
+ * rmcv_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C restatement of the reference's per-frame armour-detection path
+ *   rm::extract_color      /root/reference/src/imgproc.cpp:50-75
+ *   rm::filter_lightblobs  /root/reference/src/objdetect.cpp:55-87
+ *   rm::filter_armours     /root/reference/src/objdetect.cpp:114-166
+ *   rm::lightblob ctor     /root/reference/src/core.cpp:9-19, 265-283
+ *   rm::armour ctor        /root/reference/src/core.cpp:21-49, 285-404
+ * including the OpenCV (>= 4.8.0, vcpkg.json:28-35) primitives those call.
+ *
+ * PARITY STATUS: **parity unpinned** against real OpenCV.  OpenCV is an
+ * un-vendored third-party dependency (not under /root/reference, not installed
+ * here) and the reference ships no tests, fixtures or golden vectors
+ * (SURVEY.md section 4, 8c).  Integer stages (threshold, morphology, contours,
+ * contourArea) restate fully specified published behaviour; fitEllipseDirect
+ * restates the published algorithm with an operation order documented in
+ * rmcv_oracle.c.  What pins this file is tests/golden/ (hand-derived KATs).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library -- never the product path (rmcv_amd/).
+ */
+#ifndef RMCV_ORACLE_H
+#define RMCV_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* rm::camp, include/core.h:20-23 */
+enum { ORC_CAMP_RED = 0, ORC_CAMP_BLUE = 1, ORC_CAMP_GUIDELIGHT = 2, ORC_CAMP_NEUTRAL = -1 };
+/* morphology selector: the snapshot does CLOSE; the older API did a dilate only */
+enum { ORC_MORPH_NONE = 0, ORC_MORPH_DILATE = 1, ORC_MORPH_CLOSE = 2 };
+
+typedef struct { int32_t x, y; } orc_point;                      /* cv::Point        */
+typedef struct { float cx, cy, w, h, angle; } orc_rrect;          /* cv::RotatedRect  */
+typedef struct {                                                  /* rm::lightblob, include/core.h:89-99 */
+    float   angle;
+    int32_t target;
+    float   center[2];
+    float   vertices[4][2];
+    float   size[2];            /* (width=min, height=max) */
+} orc_lightblob;                                                  /* 56 bytes */
+typedef struct {                                                  /* rm::armour PODs, include/core.h:110-112 */
+    float   icon[4][2];
+    float   vertices[4][2];
+    float   bbox[4];            /* x, y, width, height */
+    int32_t blob_i, blob_j;     /* indices into the positive light-blob list */
+} orc_armour;                                                     /* 88 bytes */
+
+typedef struct {                /* literals of executable/main.cpp:172-176 are the defaults */
+    int32_t camp;               /* enemy colour                          (CAMP_BLUE) */
+    int32_t lower_bound;        /* inRange lower bound                   (80)        */
+    int32_t morph;              /* ORC_MORPH_*                           (CLOSE)     */
+    float   tilt_max;           /*                                       (70)        */
+    float   ratio_lo, ratio_hi; /* range<float>                          (1.5, 80)   */
+    double  area_lo, area_hi;   /* range<double>                         (10, 99999) */
+    float   angle_diff_max;     /*                                       (12)        */
+    float   shear_max;          /*                                       (22)        */
+    float   length_ratio_max;   /*                                       (0.4)       */
+    int32_t _pad;
+} orc_params;
+
+/* 0 = pinned_math.h (the parity contract with the GPU), 1 = host libm (what the
+ * reference itself would link).  tests compare the two. */
+void orc_set_math_mode(int mode);
+int  orc_get_math_mode(void);
+
+void orc_default_params(orc_params* p);
+
+/* imgproc.cpp:52-69 : binary = close3x3(inRange(sat(chA - chB), lb, 255)) */
+int orc_extract_binary(const uint8_t* bgr, int w, int h, int stride, int camp, int lower_bound, int morph,
+                       uint8_t* binary /* h*w, 0/255 */);
+void orc_dilate3x3(const uint8_t* in, uint8_t* out, int w, int h);
+void orc_erode3x3(const uint8_t* in, uint8_t* out, int w, int h);
+
+/* imgproc.cpp:71-72 : cv::findContours(RETR_EXTERNAL, CHAIN_APPROX_NONE).
+ * offs has n+1 entries; returns 0, or -2 if a capacity was exceeded (counts
+ * are still the required sizes). */
+int orc_find_contours(const uint8_t* binary, int w, int h, orc_point* pts, int cap_pts, int32_t* offs,
+                      int cap_contours, int32_t* n_contours, int32_t* n_points);
+
+double orc_contour_area(const orc_point* pts, int n);                   /* cv::contourArea */
+int    orc_fit_ellipse_direct(const orc_point* pts, int n, orc_rrect* out); /* cv::fitEllipseDirect; returns
+                                 0 direct solution, 1 fell back to the general (LIN) fit */
+void   orc_rrect_points(const orc_rrect* r, float pt[4][2]);            /* cv::RotatedRect::points */
+void   orc_make_lightblob(const orc_rrect* box, int camp, orc_lightblob* out); /* core.cpp:9-19 */
+void   orc_make_armour(const orc_lightblob* a, const orc_lightblob* b, orc_armour* out); /* core.cpp:21-49 */
+
+/* objdetect.cpp:55-87.  neg_idx receives the contour indices of the "negative" list. */
+int orc_filter_lightblobs(const orc_point* pts, const int32_t* offs, int n_contours, float tilt_max,
+                          float ratio_lo, float ratio_hi, double area_lo, double area_hi, int enemy,
+                          orc_lightblob* blobs, int cap_blobs, int32_t* n_blobs, int32_t* blob_src,
+                          int32_t* neg_idx, int32_t* n_neg, orc_rrect* ellipses /* optional, per positive */);
+
+/* objdetect.cpp:114-166 */
+int orc_filter_armours(const orc_lightblob* blobs, int n, float angle_diff_max, float shear_max,
+                       float length_ratio_max, int enemy, orc_armour* out, int cap, int32_t* n_out);
+
+/* the whole per-frame path, main.cpp:172-176; any output pointer may be NULL */
+int orc_detect_frame(const uint8_t* bgr, int w, int h, int stride, const orc_params* p, uint8_t* binary,
+                     orc_point* pts, int cap_pts, int32_t* offs, int cap_contours, int32_t* n_contours,
+                     orc_lightblob* blobs, int cap_blobs, int32_t* n_blobs, orc_armour* armours, int cap_armours,
+                     int32_t* n_armours);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

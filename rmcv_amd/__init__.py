@@ -1,0 +1,13 @@
+"""rmcv_amd -- MI355X-native (gfx950, hand-written HIP) implementation of rmcv's per-frame
+armour-detection hot path, behind the reference's own function names.
+
+    from rmcv_amd import Context
+    ctx = Context(device=0)
+    contours, binary = ctx.extract_color(image, CAMP_BLUE, 80)
+"""
+from .abi import (ARMOUR, CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL, CAMP_RED, LIGHTBLOB, MORPH_CLOSE, MORPH_DILATE,
+                  MORPH_NONE, POINT, RRECT, STAGE_ALL, STAGE_ARMOURS, STAGE_BINARY, STAGE_BLOBS, STAGE_CONTOURS, Limits,
+                  Params, RmcvError, default_params)
+from .api import Context
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,85 @@
+"""ctypes binding of librmcv_hip.so (the C-ABI declared in include/rmcv_abi.h).
+
+There is no fallback: if the HIP library is missing or no GPU is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librmcv_hip.so")
+
+# PODs of include/rmcv_abi.h as numpy dtypes
+POINT = np.dtype([("x", "<i4"), ("y", "<i4")])
+RRECT = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("w", "<f4"), ("h", "<f4"), ("angle", "<f4")])
+LIGHTBLOB = np.dtype([("angle", "<f4"), ("target", "<i4"), ("center", "<f4", (2,)),
+                      ("vertices", "<f4", (4, 2)), ("size", "<f4", (2,))])
+ARMOUR = np.dtype([("icon", "<f4", (4, 2)), ("vertices", "<f4", (4, 2)), ("bbox", "<f4", (4,)),
+                   ("blob_i", "<i4"), ("blob_j", "<i4")])
+assert POINT.itemsize == 8 and LIGHTBLOB.itemsize == 56 and ARMOUR.itemsize == 88
+
+OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+CAMP_RED, CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL = 0, 1, 2, -1
+MORPH_NONE, MORPH_DILATE, MORPH_CLOSE = 0, 1, 2
+STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL = 1, 2, 4, 8, 15
+FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_SLOW_PATH = 1, 2, 4, 8, 16
+
+EXPORTS = [
+    "rmcv_abi_version", "rmcv_default_params", "rmcv_default_limits", "rmcv_ctx_create", "rmcv_ctx_destroy",
+    "rmcv_last_error", "rmcv_extract_color", "rmcv_filter_lightblobs", "rmcv_filter_armours", "rmcv_fit_ellipse",
+    "rmcv_batch_upload", "rmcv_batch_set_device_frames", "rmcv_batch_run", "rmcv_batch_sync", "rmcv_batch_run_timed",
+    "rmcv_batch_counts", "rmcv_batch_get_binary", "rmcv_batch_get_contours", "rmcv_batch_get_blobs",
+    "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_synth_frame", "rmcv_synth_checksum",
+]
+
+
+class Params(C.Structure):
+    """rmcv_params; defaults are the literals of the reference's executable/main.cpp:172-176"""
+    _fields_ = [("camp", C.c_int32), ("lower_bound", C.c_int32), ("morph", C.c_int32), ("tilt_max", C.c_float),
+                ("ratio_lo", C.c_float), ("ratio_hi", C.c_float), ("area_lo", C.c_double), ("area_hi", C.c_double),
+                ("angle_diff_max", C.c_float), ("shear_max", C.c_float), ("length_ratio_max", C.c_float),
+                ("_pad", C.c_int32)]
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_frames", C.c_int32), ("max_width", C.c_int32), ("max_height", C.c_int32),
+                ("max_contours", C.c_int32), ("max_points", C.c_int32), ("max_blobs", C.c_int32),
+                ("max_armours", C.c_int32), ("_pad", C.c_int32)]
+
+
+class RmcvError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("rmcv error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """load librmcv_hip.so; raises (never falls back) when it has not been built"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `make -C rmcv_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.rmcv_last_error.restype = C.c_char_p
+        L.rmcv_last_error.argtypes = [C.c_void_p]
+        L.rmcv_synth_checksum.restype = C.c_uint64
+        L.rmcv_ctx_destroy.restype = None
+        L.rmcv_ctx_destroy.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw):
+    p = Params()
+    lib().rmcv_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p

@@ -1,0 +1,190 @@
+"""Host-side mirror of the reference's detection interface over the C-ABI.
+
+Same names, argument meaning and result order as the reference's
+  rm::extract_color      include/imgproc.h:29      (src/imgproc.cpp:50-75)
+  rm::filter_lightblobs  include/objdetect.h:47-49 (src/objdetect.cpp:55-87)
+  rm::filter_armours     include/objdetect.h:70-71 (src/objdetect.cpp:114-166)
+plus the batch entry point the north star adds (independent frames resident in HBM).
+Every call runs on the GPU through librmcv_hip.so; nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .abi import (ARMOUR, CAMP_BLUE, LIGHTBLOB, MORPH_CLOSE, POINT, RRECT, STAGE_ALL, Limits, Params, RmcvError,
+                  default_params, lib, ptr)
+
+
+class Context:
+    """One rmcv_ctx: a GPU, its HBM work buffers and a stream.  Single-owner, like the reference's
+    process_thread (executable/main.cpp:55)."""
+
+    def __init__(self, device=0, **limits):
+        lim = Limits()
+        lib().rmcv_default_limits(C.byref(lim))
+        for k, v in limits.items():
+            setattr(lim, k, v)
+        self.limits = lim
+        h = C.c_void_p()
+        rc = lib().rmcv_ctx_create(int(device), C.byref(lim), C.byref(h))
+        if rc != 0:
+            raise RmcvError(rc, "rmcv_ctx_create failed (no GPU? this library has no CPU path)")
+        self._h = h
+        self.device = device
+        self._frames_ref = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rmcv_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RmcvError(rc, lib().rmcv_last_error(self._h).decode())
+
+    # ---------------------------------------------------------------- single frame
+    def extract_color(self, image, target=CAMP_BLUE, lower_bound=80, morph=MORPH_CLOSE):
+        """rm::extract_color -> (contours, binary); contours = list of (n,2) int32 arrays in
+        cv::findContours(RETR_EXTERNAL, CHAIN_APPROX_NONE) order"""
+        pts, offs, binary = self.extract_color_csr(image, target, lower_bound, morph)
+        xy = np.stack([pts["x"], pts["y"]], axis=1) if len(pts) else np.zeros((0, 2), np.int32)
+        return [xy[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], binary
+
+    def extract_color_csr(self, image, target=CAMP_BLUE, lower_bound=80, morph=MORPH_CLOSE):
+        image = np.ascontiguousarray(image, np.uint8)
+        h, w, ch = image.shape
+        assert ch == 3
+        binary = np.empty((h, w), np.uint8)
+        cap_p, cap_c = self.limits.max_points, self.limits.max_contours
+        pts = np.empty(cap_p, POINT)
+        offs = np.empty(cap_c + 1, np.int32)
+        nc, npnt = C.c_int32(0), C.c_int32(0)
+        self._chk(lib().rmcv_extract_color(self._h, ptr(image), w, h, 3 * w, int(target), int(lower_bound), int(morph),
+                                           ptr(binary), ptr(pts), cap_p, ptr(offs), cap_c, C.byref(nc), C.byref(npnt)))
+        return pts[:npnt.value].copy(), offs[:nc.value + 1].copy(), binary
+
+    def filter_lightblobs(self, pts, offs, tilt_max=70.0, ratio_range=(1.5, 80.0), area_range=(10.0, 99999.0),
+                          enemy=CAMP_BLUE):
+        """rm::filter_lightblobs on CSR contours -> (positive LIGHTBLOB[], source contour index[], negative contour index[])"""
+        pts = np.ascontiguousarray(pts, POINT)
+        offs = np.ascontiguousarray(offs, np.int32)
+        n = len(offs) - 1
+        cap = self.limits.max_blobs
+        blobs = np.empty(cap, LIGHTBLOB)
+        src = np.empty(cap, np.int32)
+        neg = np.empty(max(n, 1), np.int32)
+        nb, nn = C.c_int32(0), C.c_int32(0)
+        self._chk(lib().rmcv_filter_lightblobs(self._h, ptr(pts), ptr(offs), n, C.c_float(tilt_max),
+                                               C.c_float(ratio_range[0]), C.c_float(ratio_range[1]),
+                                               C.c_double(area_range[0]), C.c_double(area_range[1]), int(enemy),
+                                               ptr(blobs), cap, C.byref(nb), ptr(src), ptr(neg), C.byref(nn)))
+        return blobs[:nb.value].copy(), src[:nb.value].copy(), neg[:nn.value].copy()
+
+    def filter_armours(self, lightblobs, angle_difference_max=12.0, shear_max=22.0, lenght_ratio_max=0.4, enemy=CAMP_BLUE):
+        """rm::filter_armours -> ARMOUR[] in (i,j) lexicographic order"""
+        lightblobs = np.ascontiguousarray(lightblobs, LIGHTBLOB)
+        cap = self.limits.max_armours
+        out = np.empty(cap, ARMOUR)
+        na = C.c_int32(0)
+        self._chk(lib().rmcv_filter_armours(self._h, ptr(lightblobs), len(lightblobs), C.c_float(angle_difference_max),
+                                            C.c_float(shear_max), C.c_float(lenght_ratio_max), int(enemy), ptr(out), cap,
+                                            C.byref(na)))
+        return out[:na.value].copy()
+
+    def fit_ellipse(self, pts):
+        """cv::fitEllipseDirect of one contour (stage-wise parity hook)"""
+        pts = np.ascontiguousarray(pts, POINT)
+        out = np.zeros(1, RRECT)
+        self._chk(lib().rmcv_fit_ellipse(self._h, ptr(pts), len(pts), ptr(out)))
+        return out[0]
+
+    # ---------------------------------------------------------------- batch
+    def upload(self, frames):
+        """frames: uint8 [n, h, w, 3] on the host -> the context's HBM buffer"""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w, ch = frames.shape
+        assert ch == 3
+        self._chk(lib().rmcv_batch_upload(self._h, ptr(frames), n, w, h, 3 * w, C.c_int64(3 * w * h)))
+        self.shape = (n, h, w)
+
+    def bind_device_frames(self, data_ptr, n, h, w, stride=None, frame_pitch=None, keepalive=None):
+        """borrow frames already in HBM (e.g. torch_tensor.data_ptr())"""
+        stride = stride or 3 * w
+        frame_pitch = frame_pitch or stride * h
+        self._frames_ref = keepalive
+        self._chk(lib().rmcv_batch_set_device_frames(self._h, C.c_void_p(data_ptr), n, w, h, stride, C.c_int64(frame_pitch)))
+        self.shape = (n, h, w)
+
+    def run(self, params=None, stages=STAGE_ALL, stream=None):
+        self._params = params or default_params()
+        self._chk(lib().rmcv_batch_run(self._h, C.byref(self._params), int(stages), C.c_void_p(stream or 0)))
+
+    def run_timed(self, params=None, stages=STAGE_ALL, stream=None):
+        """returns ms of [binary, contours, blobs, armours, total] measured with HIP events on the launch stream"""
+        self._params = params or default_params()
+        ms = (C.c_float * 5)()
+        self._chk(lib().rmcv_batch_run_timed(self._h, C.byref(self._params), int(stages), C.c_void_p(stream or 0), ms))
+        return [float(x) for x in ms]
+
+    def sync(self):
+        self._chk(lib().rmcv_batch_sync(self._h))
+
+    def counts(self):
+        n = self.shape[0]
+        a = [np.empty(n, np.int32) for _ in range(5)]
+        self._chk(lib().rmcv_batch_counts(self._h, *[ptr(x) for x in a]))
+        return dict(n_contours=a[0], n_points=a[1], n_blobs=a[2], n_armours=a[3], status=a[4])
+
+    def binary(self, frame):
+        n, h, w = self.shape
+        out = np.empty((h, w), np.uint8)
+        self._chk(lib().rmcv_batch_get_binary(self._h, int(frame), ptr(out)))
+        return out
+
+    def contours(self, frame):
+        cap_p, cap_c = self.limits.max_points, self.limits.max_contours
+        pts = np.empty(cap_p, POINT)
+        offs = np.empty(cap_c + 1, np.int32)
+        nc, npnt = C.c_int32(0), C.c_int32(0)
+        self._chk(lib().rmcv_batch_get_contours(self._h, int(frame), ptr(pts), cap_p, ptr(offs), cap_c, C.byref(nc),
+                                                C.byref(npnt)))
+        return pts[:npnt.value].copy(), offs[:nc.value + 1].copy()
+
+    def blobs(self, frame):
+        cap = self.limits.max_blobs
+        blobs = np.empty(cap, LIGHTBLOB)
+        src = np.empty(cap, np.int32)
+        nb = C.c_int32(0)
+        self._chk(lib().rmcv_batch_get_blobs(self._h, int(frame), ptr(blobs), cap, C.byref(nb), ptr(src)))
+        return blobs[:nb.value].copy(), src[:nb.value].copy()
+
+    def armours(self):
+        """all armours of the batch, frame-major -> (ARMOUR[total], frame_offs[n+1])"""
+        n = self.shape[0]
+        cap = n * self.limits.max_armours
+        out = np.empty(cap, ARMOUR)
+        offs = np.empty(n + 1, np.int32)
+        tot = C.c_int32(0)
+        self._chk(lib().rmcv_batch_get_armours(self._h, ptr(out), cap, ptr(offs), C.byref(tot)))
+        return out[:tot.value].copy(), offs
+
+    def device_views(self):
+        """(armours device pointer, counts device pointer, per-frame capacity, n_frames) for a collective"""
+        a, c = C.c_void_p(), C.c_void_p()
+        cap, n = C.c_int32(0), C.c_int32(0)
+        self._chk(lib().rmcv_batch_device_views(self._h, C.byref(a), C.byref(c), C.byref(cap), C.byref(n)))
+        return a.value, c.value, cap.value, n.value
+
+    def detect_batch(self, frames, params=None):
+        """the whole path of executable/main.cpp:172-176 on a batch of host frames"""
+        self.upload(frames)
+        self.run(params)
+        self.sync()
+        return self.armours()

@@ -1,0 +1,242 @@
+// k_binary.hip -- K1: the pixel-streaming part of rm::extract_color
+// (/root/reference/src/imgproc.cpp:52-69): split + saturating channel subtract + inRange + 3x3
+// MORPH_CLOSE, fused into ONE pass over the BGR frame.
+//
+// HBM-bound (no MFMA: there is no contraction here).  Algorithmic traffic: 3 B/px read +
+// 1 B/px written (the reference returns `binary`, imgproc.cpp:74) = 4 B/px; the bit plane the
+// contour stage consumes adds 1/8 B/px.  The reference's CPU path makes ~8 full-frame passes
+// (split x3, subtract, inRange, dilate, erode, findContours' copy); here every intermediate lives
+// in registers or LDS:
+//
+//   phase 1  each lane loads 16 px = 48 contiguous bytes (3 x dwordx4), thresholds them to a 16-bit
+//            mask, 4 lanes merge to one u64 word of the strip's bit plane T in LDS
+//   phase 2  dilate on the bit plane  D = hdil(T[y-1] | T[y] | T[y+1])          (64 px / lane-op)
+//   phase 3  erode                    E = hero(D[y-1] & D[y] & D[y+1])
+//   phase 4  E -> 0/255 bytes, 16 px per lane, one coalesced dwordx4 store; E word -> bit plane
+//
+// A workgroup owns a strip of SR rows of one frame (+2 halo rows per side for CLOSE); strips are
+// mapped so that consecutive strips of a frame land on the same XCD (blockIdx % 8 groups), where the
+// halo rows they share are L2 hits.  Border semantics (OpenCV morphologyDefaultBorderValue): samples
+// outside the image never win, i.e. they read 0 for the dilate and 1 for the erode.
+#include "rmcv_internal.h"
+
+namespace rmcv {
+
+static constexpr int SR = 64; // strip rows per workgroup
+
+__device__ __forceinline__ uint32_t expand4(uint32_t nib)
+{ // 4 mask bits -> 4 bytes of 0x00/0xFF
+    return (((nib & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+}
+
+template <int CA, int CB>
+__device__ __forceinline__ uint32_t thresh16(const uint32_t d[12], int lb)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        const int ia = 3 * p + CA, ib = 3 * p + CB;
+        int a = (int)((d[ia >> 2] >> ((ia & 3) * 8)) & 0xFFu);
+        int b = (int)((d[ib >> 2] >> ((ib & 3) * 8)) & 0xFFu);
+        m |= (uint32_t)(a - b >= lb) << p;
+    }
+    return m;
+}
+
+// lb is pre-clamped on the host to [1, 256]: lb <= 0 means "everything passes" (lb = -1 flag).
+template <int CA, int CB, bool FAST>
+__global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride,
+                                                 int w, int h, int ww, int lb, int all_pass, int morph,
+                                                 uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
+                                                 int64_t plane_pitch, int strips, int n_blocks)
+{
+    extern __shared__ uint64_t smem[];
+    const int halo = morph; // NONE 0, DILATE 1, CLOSE 2
+    const int srh = SR + 2 * halo;
+    uint64_t* T = smem;
+    uint64_t* D = smem + (size_t)(SR + 4) * ww;
+
+    // XCD-aware mapping: blocks b, b+8, b+16.. share an XCD -> give them consecutive strips
+    int b = blockIdx.x;
+    const int nb8 = n_blocks & ~7;
+    int L = (b < nb8) ? (b & 7) * (nb8 >> 3) + (b >> 3) : b;
+    const int f = L / strips, strip = L - f * strips;
+    const int y0 = strip * SR;
+    const uint8_t* frame = frames + (int64_t)f * frame_pitch;
+    const int tid = threadIdx.x;
+    const int wq = ww * 4; // 16-pixel groups per row
+
+    // ---------------- phase 1: load + threshold -> T
+    {
+        const int items = srh * wq;
+        int rr = tid / wq, q = tid - rr * wq;
+        const int dr = 256 / wq, dq = 256 - dr * wq;
+        for (int it = tid; it < items; it += 256) {
+            const int y = y0 - halo + rr;
+            uint32_t m = 0;
+            if (y >= 0 && y < h) {
+                if (FAST) {
+                    const uint4* src = reinterpret_cast<const uint4*>(frame + (int64_t)y * stride + q * 48);
+                    uint4 v0 = src[0], v1 = src[1], v2 = src[2];
+                    uint32_t d[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+                    m = all_pass ? 0xFFFFu : thresh16<CA, CB>(d, lb);
+                } else {
+                    const uint8_t* row = frame + (int64_t)y * stride;
+                    for (int p = 0; p < 16; p++) {
+                        int x = q * 16 + p;
+                        if (x < w) {
+                            int a = row[3 * x + CA], bb = row[3 * x + CB];
+                            m |= (uint32_t)(all_pass || (a - bb >= lb)) << p;
+                        }
+                    }
+                }
+            }
+            // merge the 4 lanes of a word (lanes are word-aligned: wq % 4 == 0, 256 % 4 == 0)
+            uint32_t v = m << (16 * (q & 1));
+            v |= __shfl_xor(v, 1);
+            uint32_t o = __shfl_xor(v, 2);
+            if ((q & 3) == 0) T[rr * ww + (q >> 2)] = ((uint64_t)o << 32) | v;
+            rr += dr;
+            q += dq;
+            if (q >= wq) { q -= wq; rr++; }
+        }
+    }
+    __syncthreads();
+
+    const uint64_t last_valid = (w & 63) ? ((1ull << (w & 63)) - 1) : ~0ull; // valid bits of the last word
+    uint64_t* R = T; // plane holding the result rows, result row s at R[(s + halo) * ww + k]
+
+    if (morph != RMCV_MORPH_NONE) {
+        // ---------------- phase 2: dilate -> D (rows 1 .. srh-2)
+        const int items = (srh - 2) * ww;
+        for (int it = tid; it < items; it += 256) {
+            const int rr = 1 + it / ww, k = it % ww;
+            const int y = y0 - halo + rr;
+            uint64_t d;
+            if (y < 0 || y >= h) {
+                d = ~0ull; // outside the image: never wins the erode
+            } else {
+                const uint64_t* t0 = T + (rr - 1) * ww;
+                const uint64_t* t1 = T + rr * ww;
+                const uint64_t* t2 = T + (rr + 1) * ww;
+                uint64_t c = t0[k] | t1[k] | t2[k];
+                uint64_t l = (k > 0) ? (t0[k - 1] | t1[k - 1] | t2[k - 1]) >> 63 : 0;
+                uint64_t r = (k < ww - 1) ? (t0[k + 1] | t1[k + 1] | t2[k + 1]) & 1 : 0;
+                d = c | (c << 1) | l | (c >> 1) | (r << 63);
+                if (k == ww - 1) {
+                    d &= last_valid;
+                    if (morph == RMCV_MORPH_CLOSE) d |= ~last_valid; // columns >= w never win the erode
+                }
+            }
+            D[rr * ww + k] = d;
+        }
+        __syncthreads();
+        R = D;
+        if (morph == RMCV_MORPH_CLOSE) {
+            // ---------------- phase 3: erode -> T (rows 2 .. srh-3 = the strip)
+            const int items3 = SR * ww;
+            for (int it = tid; it < items3; it += 256) {
+                const int rr = 2 + it / ww, k = it % ww;
+                const uint64_t* d0 = D + (rr - 1) * ww;
+                const uint64_t* d1 = D + rr * ww;
+                const uint64_t* d2 = D + (rr + 1) * ww;
+                uint64_t c = d0[k] & d1[k] & d2[k];
+                uint64_t l = (k > 0) ? (d0[k - 1] & d1[k - 1] & d2[k - 1]) >> 63 : 1;
+                uint64_t r = (k < ww - 1) ? (d0[k + 1] & d1[k + 1] & d2[k + 1]) & 1 : 1;
+                uint64_t e = c & ((c << 1) | l) & ((c >> 1) | (r << 63));
+                if (k == ww - 1) e &= last_valid;
+                T[rr * ww + k] = e;
+            }
+            __syncthreads();
+            R = T;
+        }
+    }
+
+    // ---------------- phase 4: expand to bytes + bit plane
+    {
+        const int items = SR * wq;
+        int s = tid / wq, q = tid - s * wq;
+        const int dr = 256 / wq, dq = 256 - dr * wq;
+        uint8_t* bin = binary + (int64_t)f * w * h;
+        uint64_t* plane = bits + (int64_t)f * plane_pitch;
+        for (int it = tid; it < items; it += 256) {
+            const int y = y0 + s;
+            if (y < h) {
+                const uint64_t word = R[(s + halo) * ww + (q >> 2)];
+                const uint32_t m = (uint32_t)(word >> (16 * (q & 3))) & 0xFFFFu;
+                if (FAST) {
+                    uint4 o;
+                    o.x = expand4(m);
+                    o.y = expand4(m >> 4);
+                    o.z = expand4(m >> 8);
+                    o.w = expand4(m >> 12);
+                    *reinterpret_cast<uint4*>(bin + (int64_t)y * w + q * 16) = o;
+                } else {
+                    for (int p = 0; p < 16; p++) {
+                        int x = q * 16 + p;
+                        if (x < w) bin[(int64_t)y * w + x] = ((m >> p) & 1) ? 255 : 0;
+                    }
+                }
+                if ((q & 3) == 0) plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)] = word;
+            }
+            s += dr;
+            q += dq;
+            if (q >= wq) { q -= wq; s++; }
+        }
+    }
+}
+
+template <int CA, int CB>
+static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, hipStream_t s)
+{
+    const int strips = (g.h + SR - 1) / SR;
+    const int n_blocks = g.n_frames * strips;
+    int lb = lower_bound, all_pass = 0;
+    if (lb <= 0) { all_pass = 1; lb = 1; }
+    if (lb > 256) lb = 256;
+    const size_t lds = (size_t)2 * (SR + 4) * g.ww * sizeof(uint64_t);
+    const bool fast = (g.w % 64 == 0) && (g.stride % 16 == 0) && (g.frame_pitch % 16 == 0) &&
+                      ((uintptr_t)b.frames % 16 == 0);
+    if (fast)
+        hipLaunchKernelGGL((k_binary<CA, CB, true>), dim3(n_blocks), dim3(256), lds, s, b.frames, g.frame_pitch, g.stride,
+                           g.w, g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks);
+    else
+        hipLaunchKernelGGL((k_binary<CA, CB, false>), dim3(n_blocks), dim3(256), lds, s, b.frames, g.frame_pitch, g.stride,
+                           g.w, g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, hipStream_t s)
+{
+    // imgproc.cpp:56-65: GUIDELIGHT G-R; BLUE B-R; everything else (RED, NEUTRAL) R-B.  BGR byte order.
+    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, s);
+    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, s);
+    return launch_binary_t<2, 0>(g, b, lower_bound, morph, s);
+}
+
+// binary (0 / non-zero bytes) -> padded bit plane; used when a caller hands in its own binary image
+__global__ void k_pack_bits(const uint8_t* __restrict__ binary, int w, int h, int ww, uint64_t* __restrict__ bits, int prow,
+                            int64_t plane_pitch)
+{
+    const int f = blockIdx.y;
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= h * ww) return;
+    const int y = item / ww, k = item % ww;
+    const uint8_t* row = binary + (int64_t)f * w * h + (int64_t)y * w;
+    uint64_t word = 0;
+    for (int bqt = 0; bqt < 64; bqt++) {
+        int x = k * 64 + bqt;
+        if (x < w && row[x]) word |= 1ull << bqt;
+    }
+    bits[(int64_t)f * plane_pitch + (int64_t)(y + 1) * prow + 1 + k] = word;
+}
+
+hipError_t launch_pack_bits(const Geom& g, const Bufs& b, hipStream_t s)
+{
+    const int items = g.h * g.ww;
+    hipLaunchKernelGGL(k_pack_bits, dim3((items + 255) / 256, g.n_frames), dim3(256), 0, s, b.binary, g.w, g.h, g.ww, b.bits,
+                       g.prow, g.plane_pitch);
+    return hipGetLastError();
+}
+
+} // namespace rmcv

@@ -1,0 +1,565 @@
+// rmcv_host.hip -- the C-ABI of include/rmcv_abi.h: context, HBM buffers, stage sequencing.
+//
+// Host side of the drop-in boundary.  The reference's boundary is the C++ linkage of `librmcv`
+// (/root/reference/CMakeLists.txt:13-16); the calls a maintainer re-hosts on this ABI are exactly
+// rm::extract_color / rm::filter_lightblobs / rm::filter_armours (executable/main.cpp:172-176).
+// No CPU path exists here: every entry point enqueues hand-written HIP kernels.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "rmcv_internal.h"
+
+using namespace rmcv;
+
+struct rmcv_ctx {
+    int device = 0;
+    Limits lim{};
+    Geom geom{};
+    Bufs bufs{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    uint8_t* own_frames = nullptr; // upload buffer (lazy)
+    size_t own_frames_bytes = 0;
+    rmcv_point* pack_pts = nullptr; // CSR download staging
+    int32_t* pack_offs = nullptr;
+    hipStream_t last_stream = nullptr;
+    int geom_w = -1, geom_h = -1; // geometry the planes were zeroed for
+    char err[256] = {0};
+    std::vector<void*> allocs;
+};
+
+static int fail(rmcv_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        if (e != hipSuccess) snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(e));
+        else snprintf(c->err, sizeof(c->err), "%s", what);
+    }
+    return code;
+}
+
+#define HIPCHK(c, call, what)                                           \
+    do {                                                                \
+        hipError_t e__ = (call);                                        \
+        if (e__ != hipSuccess) return fail((c), RMCV_ERR_HIP, what, e__); \
+    } while (0)
+
+template <typename T>
+static hipError_t dalloc(rmcv_ctx* c, T** p, size_t count)
+{
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+    if (e == hipSuccess) {
+        c->allocs.push_back(q);
+        *p = (T*)q;
+    }
+    return e;
+}
+
+extern "C" {
+
+int rmcv_abi_version(void) { return RMCV_ABI_VERSION; }
+
+void rmcv_default_params(rmcv_params* p)
+{ // the literals of executable/main.cpp:172-176
+    memset(p, 0, sizeof(*p));
+    p->camp = RMCV_CAMP_BLUE;
+    p->lower_bound = 80;
+    p->morph = RMCV_MORPH_CLOSE;
+    p->tilt_max = 70.0f;
+    p->ratio_lo = 1.5f;
+    p->ratio_hi = 80.0f;
+    p->area_lo = 10.0;
+    p->area_hi = 99999.0;
+    p->angle_diff_max = 12.0f;
+    p->shear_max = 22.0f;
+    p->length_ratio_max = 0.4f;
+}
+
+void rmcv_default_limits(rmcv_limits* l)
+{
+    memset(l, 0, sizeof(*l));
+    l->max_frames = 256;
+    l->max_width = 1920;
+    l->max_height = 1200;
+    l->max_contours = 2048;
+    l->max_points = 65536;
+    l->max_blobs = 256;
+    l->max_armours = 256;
+}
+
+const char* rmcv_last_error(const rmcv_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+void rmcv_ctx_destroy(rmcv_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->own_frames) hipFree(c->own_frames);
+    for (auto& e : c->ev)
+        if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
+{
+    if (!out) return RMCV_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return RMCV_ERR_NO_DEVICE;
+    rmcv_limits d;
+    rmcv_default_limits(&d);
+    if (limits) {
+        if (limits->max_frames > 0) d.max_frames = limits->max_frames;
+        if (limits->max_width > 0) d.max_width = limits->max_width;
+        if (limits->max_height > 0) d.max_height = limits->max_height;
+        if (limits->max_contours > 0) d.max_contours = limits->max_contours;
+        if (limits->max_points > 0) d.max_points = limits->max_points;
+        if (limits->max_blobs > 0) d.max_blobs = limits->max_blobs;
+        if (limits->max_armours > 0) d.max_armours = limits->max_armours;
+    }
+    rmcv_ctx* c = new (std::nothrow) rmcv_ctx();
+    if (!c) return RMCV_ERR_NOMEM;
+    c->device = device;
+    c->lim = Limits{d.max_frames, d.max_width, d.max_height, d.max_contours, d.max_points, d.max_blobs, d.max_armours};
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    const size_t F = (size_t)d.max_frames;
+    const size_t plane = (size_t)(d.max_height + 2) * ((d.max_width + 63) / 64 + 2);
+    Bufs& b = c->bufs;
+    if (e == hipSuccess) e = dalloc(c, &b.binary, F * d.max_width * d.max_height);
+    if (e == hipSuccess) e = dalloc(c, &b.bits, F * plane);
+    if (e == hipSuccess) e = dalloc(c, &b.lab, F * plane);
+    if (e == hipSuccess) e = dalloc(c, &b.neg, F * plane);
+    if (e == hipSuccess) e = dalloc(c, &b.points, F * d.max_points);
+    if (e == hipSuccess) e = dalloc(c, &c->pack_pts, F * d.max_points);
+    if (e == hipSuccess) e = dalloc(c, &c->pack_offs, F * (d.max_contours + 1));
+    if (e == hipSuccess) e = dalloc(c, &b.cont_start, F * d.max_contours);
+    if (e == hipSuccess) e = dalloc(c, &b.cont_len, F * d.max_contours);
+    if (e == hipSuccess) e = dalloc(c, &b.n_contours, F);
+    if (e == hipSuccess) e = dalloc(c, &b.n_points, F);
+    if (e == hipSuccess) e = dalloc(c, &b.blobs, F * d.max_blobs);
+    if (e == hipSuccess) e = dalloc(c, &b.blob_src, F * d.max_blobs);
+    if (e == hipSuccess) e = dalloc(c, &b.ellipses, F * d.max_blobs);
+    if (e == hipSuccess) e = dalloc(c, &b.neg_idx, F * d.max_contours);
+    if (e == hipSuccess) e = dalloc(c, &b.n_blobs, F);
+    if (e == hipSuccess) e = dalloc(c, &b.n_neg, F);
+    if (e == hipSuccess) e = dalloc(c, &b.armours, F * d.max_armours);
+    if (e == hipSuccess) e = dalloc(c, &b.n_armours, F);
+    if (e == hipSuccess) e = dalloc(c, &b.status, F);
+    if (e == hipSuccess) {
+        hipMemset(b.n_contours, 0, F * 4);
+        hipMemset(b.n_points, 0, F * 4);
+        hipMemset(b.n_blobs, 0, F * 4);
+        hipMemset(b.n_neg, 0, F * 4);
+        hipMemset(b.n_armours, 0, F * 4);
+        e = hipMemset(b.status, 0, F * 4);
+    }
+    if (e != hipSuccess) {
+        fprintf(stderr, "rmcv_ctx_create: %s\n", hipGetErrorString(e));
+        rmcv_ctx_destroy(c);
+        return e == hipErrorOutOfMemory ? RMCV_ERR_NOMEM : RMCV_ERR_HIP;
+    }
+    *out = c;
+    return RMCV_OK;
+}
+
+} // extern "C"
+
+// bind a geometry; zero the padded planes when it changes (their pads must read 0)
+static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t frame_pitch)
+{
+    if (n_frames < 1 || n_frames > c->lim.max_frames) return fail(c, RMCV_ERR_BAD_ARG, "n_frames out of range");
+    if (w < 1 || h < 1 || w > c->lim.max_width || h > c->lim.max_height) return fail(c, RMCV_ERR_BAD_ARG, "frame size out of range");
+    if (stride < 3 * w || frame_pitch < (int64_t)stride * (h - 1) + 3 * w) return fail(c, RMCV_ERR_BAD_ARG, "bad stride/pitch");
+    Geom& g = c->geom;
+    g.n_frames = n_frames;
+    g.w = w;
+    g.h = h;
+    g.stride = stride;
+    g.frame_pitch = frame_pitch;
+    g.ww = (w + 63) / 64;
+    g.prow = g.ww + 2;
+    g.plane_pitch = (int64_t)(h + 2) * g.prow;
+    if (c->geom_w != w || c->geom_h != h) {
+        const size_t plane = (size_t)(c->lim.max_height + 2) * ((c->lim.max_width + 63) / 64 + 2);
+        HIPCHK(c, hipMemsetAsync(c->bufs.bits, 0, (size_t)c->lim.max_frames * plane * 8, c->stream), "memset planes");
+        HIPCHK(c, hipStreamSynchronize(c->stream), "memset planes");
+        c->geom_w = w;
+        c->geom_h = h;
+    }
+    return RMCV_OK;
+}
+
+static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t s, bool timed)
+{
+    const Geom& g = c->geom;
+    const Bufs& b = c->bufs;
+    int k = 0;
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
+    HIPCHK(c, hipMemsetAsync(b.status, 0, (size_t)g.n_frames * 4, s), "memset status");
+    if (stages & RMCV_STAGE_BINARY) HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, s), "k_binary");
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
+    if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
+    if (stages & RMCV_STAGE_BLOBS) HIPCHK(c, launch_blobs(g, b, c->lim, *p, s), "k_blobs");
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
+    if (stages & RMCV_STAGE_ARMOURS) HIPCHK(c, launch_armours(g, b, c->lim, *p, s), "k_armours");
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
+    c->last_stream = s;
+    return RMCV_OK;
+}
+
+static int check_params(rmcv_ctx* c, const rmcv_params* p, int stages)
+{
+    if (!c) return RMCV_ERR_BAD_ARG;
+    if (!p) return fail(c, RMCV_ERR_BAD_ARG, "null params");
+    if (p->morph < RMCV_MORPH_NONE || p->morph > RMCV_MORPH_CLOSE) return fail(c, RMCV_ERR_BAD_ARG, "bad morph");
+    if (stages <= 0 || stages > RMCV_STAGE_ALL) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
+    if (c->geom.n_frames <= 0 || !c->bufs.frames) {
+        if (stages & RMCV_STAGE_BINARY) return fail(c, RMCV_ERR_BAD_ARG, "no frames bound");
+    }
+    return RMCV_OK;
+}
+
+extern "C" {
+
+int rmcv_batch_upload(rmcv_ctx* c, const uint8_t* frames, int n_frames, int w, int h, int stride, int64_t frame_pitch)
+{
+    if (!c || !frames) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    // device layout: tightly packed rows (stride 3*w rounded up to 16 bytes), frames back to back
+    const int dstride = (3 * w + 15) & ~15;
+    const int64_t dpitch = (int64_t)dstride * h;
+    int rc = set_geom(c, n_frames, w, h, dstride, dpitch);
+    if (rc) return rc;
+    const size_t need = (size_t)dpitch * n_frames;
+    if (need > c->own_frames_bytes) {
+        if (c->own_frames) hipFree(c->own_frames);
+        c->own_frames = nullptr;
+        c->own_frames_bytes = 0;
+        size_t cap = (size_t)((3 * c->lim.max_width + 15) & ~15) * c->lim.max_height * c->lim.max_frames;
+        if (cap < need) cap = need;
+        HIPCHK(c, hipMalloc((void**)&c->own_frames, cap), "hipMalloc frames");
+        c->own_frames_bytes = cap;
+    }
+    if (stride == dstride && frame_pitch == dpitch) {
+        HIPCHK(c, hipMemcpyAsync(c->own_frames, frames, need, hipMemcpyHostToDevice, c->stream), "H2D frames");
+    } else {
+        for (int f = 0; f < n_frames; f++)
+            HIPCHK(c, hipMemcpy2DAsync(c->own_frames + (size_t)f * dpitch, dstride, frames + (size_t)f * frame_pitch, stride,
+                                       (size_t)3 * w, h, hipMemcpyHostToDevice, c->stream),
+                   "H2D frames 2D");
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream), "H2D frames");
+    c->bufs.frames = c->own_frames;
+    return RMCV_OK;
+}
+
+int rmcv_batch_set_device_frames(rmcv_ctx* c, const void* d_frames, int n_frames, int w, int h, int stride,
+                                 int64_t frame_pitch)
+{
+    if (!c || !d_frames) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = set_geom(c, n_frames, w, h, stride, frame_pitch);
+    if (rc) return rc;
+    c->bufs.frames = (const uint8_t*)d_frames;
+    return RMCV_OK;
+}
+
+int rmcv_batch_run(rmcv_ctx* c, const rmcv_params* p, int stages, void* hip_stream)
+{
+    int rc = check_params(c, p, stages);
+    if (rc) return rc;
+    hipSetDevice(c->device);
+    return run_stages(c, p, stages, hip_stream ? (hipStream_t)hip_stream : c->stream, false);
+}
+
+int rmcv_batch_sync(rmcv_ctx* c)
+{
+    if (!c) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream), "sync");
+    return RMCV_OK;
+}
+
+int rmcv_batch_run_timed(rmcv_ctx* c, const rmcv_params* p, int stages, void* hip_stream, float stage_ms[5])
+{
+    int rc = check_params(c, p, stages);
+    if (rc) return rc;
+    if (!stage_ms) return fail(c, RMCV_ERR_BAD_ARG, "null stage_ms");
+    hipSetDevice(c->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    rc = run_stages(c, p, stages, s, true);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(s), "sync");
+    for (int i = 0; i < 4; i++) HIPCHK(c, hipEventElapsedTime(&stage_ms[i], c->ev[i], c->ev[i + 1]), "elapsed");
+    HIPCHK(c, hipEventElapsedTime(&stage_ms[4], c->ev[0], c->ev[4]), "elapsed");
+    return RMCV_OK;
+}
+
+int rmcv_batch_counts(rmcv_ctx* c, int32_t* n_contours, int32_t* n_points, int32_t* n_blobs, int32_t* n_armours,
+                      int32_t* status)
+{
+    if (!c) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->geom.n_frames * 4;
+    if (n_contours) HIPCHK(c, hipMemcpy(n_contours, c->bufs.n_contours, n, hipMemcpyDeviceToHost), "D2H");
+    if (n_points) HIPCHK(c, hipMemcpy(n_points, c->bufs.n_points, n, hipMemcpyDeviceToHost), "D2H");
+    if (n_blobs) HIPCHK(c, hipMemcpy(n_blobs, c->bufs.n_blobs, n, hipMemcpyDeviceToHost), "D2H");
+    if (n_armours) HIPCHK(c, hipMemcpy(n_armours, c->bufs.n_armours, n, hipMemcpyDeviceToHost), "D2H");
+    if (status) HIPCHK(c, hipMemcpy(status, c->bufs.status, n, hipMemcpyDeviceToHost), "D2H");
+    return RMCV_OK;
+}
+
+int rmcv_batch_get_binary(rmcv_ctx* c, int frame, uint8_t* out)
+{
+    if (!c || !out || frame < 0 || frame >= c->geom.n_frames) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    const size_t sz = (size_t)c->geom.w * c->geom.h;
+    HIPCHK(c, hipMemcpy(out, c->bufs.binary + (size_t)frame * sz, sz, hipMemcpyDeviceToHost), "D2H binary");
+    return RMCV_OK;
+}
+
+int rmcv_batch_get_contours(rmcv_ctx* c, int frame, rmcv_point* pts_out, int pts_cap, int32_t* offs_out, int contours_cap,
+                            int32_t* n_contours, int32_t* n_points)
+{
+    if (!c || frame < 0 || frame >= c->geom.n_frames) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    // pack this frame only: a one-frame view of the buffers
+    Geom g1 = c->geom;
+    g1.n_frames = 1;
+    Bufs b1 = c->bufs;
+    b1.points += (size_t)frame * c->lim.max_points;
+    b1.cont_start += (size_t)frame * c->lim.max_contours;
+    b1.cont_len += (size_t)frame * c->lim.max_contours;
+    b1.n_contours += frame;
+    HIPCHK(c, launch_pack_contours(g1, b1, c->lim, c->pack_pts, c->pack_offs, s), "k_pack_contours");
+    int32_t nc = 0, st = 0;
+    HIPCHK(c, hipMemcpyAsync(&nc, c->bufs.n_contours + frame, 4, hipMemcpyDeviceToHost, s), "D2H");
+    HIPCHK(c, hipMemcpyAsync(&st, c->bufs.status + frame, 4, hipMemcpyDeviceToHost, s), "D2H");
+    HIPCHK(c, hipStreamSynchronize(s), "sync");
+    int32_t total = 0;
+    HIPCHK(c, hipMemcpy(&total, c->pack_offs + nc, 4, hipMemcpyDeviceToHost), "D2H");
+    if (n_contours) *n_contours = nc;
+    if (n_points) *n_points = total;
+    if (st & (RMCV_FRAME_OVF_CONTOURS | RMCV_FRAME_OVF_POINTS)) return fail(c, RMCV_ERR_CAPACITY, "context limits exceeded (max_contours/max_points)");
+    if (nc > contours_cap || total > pts_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    if (offs_out) HIPCHK(c, hipMemcpy(offs_out, c->pack_offs, (size_t)(nc + 1) * 4, hipMemcpyDeviceToHost), "D2H offs");
+    if (pts_out && total) HIPCHK(c, hipMemcpy(pts_out, c->pack_pts, (size_t)total * sizeof(rmcv_point), hipMemcpyDeviceToHost), "D2H pts");
+    return RMCV_OK;
+}
+
+int rmcv_batch_get_blobs(rmcv_ctx* c, int frame, rmcv_lightblob* blobs_out, int cap, int32_t* n_blobs, int32_t* blob_src)
+{
+    if (!c || frame < 0 || frame >= c->geom.n_frames) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    int32_t nb = 0, st = 0;
+    HIPCHK(c, hipMemcpy(&nb, c->bufs.n_blobs + frame, 4, hipMemcpyDeviceToHost), "D2H");
+    HIPCHK(c, hipMemcpy(&st, c->bufs.status + frame, 4, hipMemcpyDeviceToHost), "D2H");
+    if (n_blobs) *n_blobs = nb;
+    if (st & RMCV_FRAME_OVF_BLOBS) return fail(c, RMCV_ERR_CAPACITY, "context limit exceeded (max_blobs)");
+    if (nb > cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    if (blobs_out && nb)
+        HIPCHK(c, hipMemcpy(blobs_out, c->bufs.blobs + (size_t)frame * c->lim.max_blobs, (size_t)nb * sizeof(rmcv_lightblob), hipMemcpyDeviceToHost), "D2H blobs");
+    if (blob_src && nb)
+        HIPCHK(c, hipMemcpy(blob_src, c->bufs.blob_src + (size_t)frame * c->lim.max_blobs, (size_t)nb * 4, hipMemcpyDeviceToHost), "D2H blob_src");
+    return RMCV_OK;
+}
+
+int rmcv_batch_get_armours(rmcv_ctx* c, rmcv_armour* armours_out, int cap, int32_t* frame_offs, int32_t* n_total)
+{
+    if (!c) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    const int nf = c->geom.n_frames;
+    std::vector<int32_t> cnt(nf), st(nf);
+    HIPCHK(c, hipMemcpy(cnt.data(), c->bufs.n_armours, (size_t)nf * 4, hipMemcpyDeviceToHost), "D2H");
+    HIPCHK(c, hipMemcpy(st.data(), c->bufs.status, (size_t)nf * 4, hipMemcpyDeviceToHost), "D2H");
+    int64_t total = 0;
+    int ovf = 0;
+    for (int f = 0; f < nf; f++) {
+        if (frame_offs) frame_offs[f] = (int32_t)total;
+        total += cnt[f];
+        ovf |= st[f] & (RMCV_FRAME_OVF_CONTOURS | RMCV_FRAME_OVF_POINTS | RMCV_FRAME_OVF_BLOBS | RMCV_FRAME_OVF_ARMOURS);
+    }
+    if (frame_offs) frame_offs[nf] = (int32_t)total;
+    if (n_total) *n_total = (int32_t)total;
+    if (ovf) return fail(c, RMCV_ERR_CAPACITY, "context limits exceeded on at least one frame (see status)");
+    if (total > cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    if (armours_out && total) {
+        std::vector<rmcv_armour> all((size_t)nf * c->lim.max_armours);
+        HIPCHK(c, hipMemcpy(all.data(), c->bufs.armours, all.size() * sizeof(rmcv_armour), hipMemcpyDeviceToHost), "D2H armours");
+        int64_t o = 0;
+        for (int f = 0; f < nf; f++) {
+            memcpy(armours_out + o, all.data() + (size_t)f * c->lim.max_armours, (size_t)cnt[f] * sizeof(rmcv_armour));
+            o += cnt[f];
+        }
+    }
+    return RMCV_OK;
+}
+
+int rmcv_batch_device_views(rmcv_ctx* c, void** d_armours, void** d_counts, int32_t* per_frame_cap, int32_t* n_frames)
+{
+    if (!c) return RMCV_ERR_BAD_ARG;
+    if (d_armours) *d_armours = c->bufs.armours;
+    if (d_counts) *d_counts = c->bufs.n_armours;
+    if (per_frame_cap) *per_frame_cap = c->lim.max_armours;
+    if (n_frames) *n_frames = c->geom.n_frames;
+    return RMCV_OK;
+}
+
+/* ---------------- single-frame, host-buffer entry points ---------------- */
+
+int rmcv_extract_color(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride, int camp, int lower_bound, int morph,
+                       uint8_t* binary_out, rmcv_point* pts_out, int pts_cap, int32_t* offs_out, int contours_cap,
+                       int32_t* n_contours, int32_t* n_points)
+{
+    if (!c || !bgr) return RMCV_ERR_BAD_ARG;
+    int rc = rmcv_batch_upload(c, bgr, 1, w, h, stride, (int64_t)stride * h);
+    if (rc) return rc;
+    rmcv_params p;
+    rmcv_default_params(&p);
+    p.camp = camp;
+    p.lower_bound = lower_bound;
+    p.morph = morph;
+    rc = rmcv_batch_run(c, &p, RMCV_STAGE_BINARY | RMCV_STAGE_CONTOURS, nullptr);
+    if (rc) return rc;
+    if (binary_out) {
+        rc = rmcv_batch_get_binary(c, 0, binary_out);
+        if (rc) return rc;
+    }
+    return rmcv_batch_get_contours(c, 0, pts_out, pts_cap, offs_out, contours_cap, n_contours, n_points);
+}
+
+// load host CSR contours (findContours order) into frame slot 0 (stored in discovery order = reversed)
+static int load_contours(rmcv_ctx* c, const rmcv_point* pts, const int32_t* offs, int n)
+{
+    if (n < 0 || n > c->lim.max_contours) return fail(c, RMCV_ERR_CAPACITY, "too many contours for this context");
+    const int total = n ? offs[n] : 0;
+    if (total > c->lim.max_points) return fail(c, RMCV_ERR_CAPACITY, "too many points for this context");
+    std::vector<int32_t> cs(n > 0 ? n : 1), cl(n > 0 ? n : 1);
+    for (int i = 0; i < n; i++) {
+        if (offs[i + 1] < offs[i]) return fail(c, RMCV_ERR_BAD_ARG, "offs not monotone");
+        cs[n - 1 - i] = offs[i];
+        cl[n - 1 - i] = offs[i + 1] - offs[i];
+    }
+    if (c->geom.n_frames < 1) c->geom.n_frames = 1;
+    const Bufs& b = c->bufs;
+    int32_t z = 0;
+    if (total) HIPCHK(c, hipMemcpy(b.points, pts, (size_t)total * sizeof(rmcv_point), hipMemcpyHostToDevice), "H2D points");
+    if (n) {
+        HIPCHK(c, hipMemcpy(b.cont_start, cs.data(), (size_t)n * 4, hipMemcpyHostToDevice), "H2D");
+        HIPCHK(c, hipMemcpy(b.cont_len, cl.data(), (size_t)n * 4, hipMemcpyHostToDevice), "H2D");
+    }
+    HIPCHK(c, hipMemcpy(b.n_contours, &n, 4, hipMemcpyHostToDevice), "H2D");
+    HIPCHK(c, hipMemcpy(b.n_points, &total, 4, hipMemcpyHostToDevice), "H2D");
+    HIPCHK(c, hipMemcpy(b.status, &z, 4, hipMemcpyHostToDevice), "H2D");
+    return RMCV_OK;
+}
+
+int rmcv_filter_lightblobs(rmcv_ctx* c, const rmcv_point* pts, const int32_t* offs, int n_contours, float tilt_max,
+                           float ratio_lo, float ratio_hi, double area_lo, double area_hi, int enemy,
+                           rmcv_lightblob* blobs_out, int blobs_cap, int32_t* n_blobs, int32_t* blob_src,
+                           int32_t* neg_idx_out, int32_t* n_neg)
+{
+    if (!c || (n_contours > 0 && (!pts || !offs))) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = load_contours(c, pts, offs, n_contours);
+    if (rc) return rc;
+    rmcv_params p;
+    rmcv_default_params(&p);
+    p.tilt_max = tilt_max;
+    p.ratio_lo = ratio_lo;
+    p.ratio_hi = ratio_hi;
+    p.area_lo = area_lo;
+    p.area_hi = area_hi;
+    p.camp = enemy;
+    Geom g1 = c->geom;
+    g1.n_frames = 1;
+    HIPCHK(c, launch_blobs(g1, c->bufs, c->lim, p, c->stream), "k_blobs");
+    c->last_stream = c->stream;
+    const int saved = c->geom.n_frames;
+    c->geom.n_frames = saved < 1 ? 1 : saved;
+    rc = rmcv_batch_get_blobs(c, 0, blobs_out, blobs_cap, n_blobs, blob_src);
+    if (rc) return rc;
+    int32_t nn = 0;
+    HIPCHK(c, hipMemcpy(&nn, c->bufs.n_neg, 4, hipMemcpyDeviceToHost), "D2H");
+    if (n_neg) *n_neg = nn;
+    if (neg_idx_out && nn) HIPCHK(c, hipMemcpy(neg_idx_out, c->bufs.neg_idx, (size_t)nn * 4, hipMemcpyDeviceToHost), "D2H neg");
+    return RMCV_OK;
+}
+
+int rmcv_filter_armours(rmcv_ctx* c, const rmcv_lightblob* blobs, int n_blobs, float angle_diff_max, float shear_max,
+                        float length_ratio_max, int enemy, rmcv_armour* armours_out, int armours_cap, int32_t* n_armours)
+{
+    if (!c || (n_blobs > 0 && !blobs) || n_blobs < 0) return RMCV_ERR_BAD_ARG;
+    if (n_blobs > c->lim.max_blobs) return fail(c, RMCV_ERR_CAPACITY, "too many blobs for this context");
+    hipSetDevice(c->device);
+    int32_t z = 0;
+    if (n_blobs) HIPCHK(c, hipMemcpy(c->bufs.blobs, blobs, (size_t)n_blobs * sizeof(rmcv_lightblob), hipMemcpyHostToDevice), "H2D blobs");
+    HIPCHK(c, hipMemcpy(c->bufs.n_blobs, &n_blobs, 4, hipMemcpyHostToDevice), "H2D");
+    HIPCHK(c, hipMemcpy(c->bufs.status, &z, 4, hipMemcpyHostToDevice), "H2D");
+    rmcv_params p;
+    rmcv_default_params(&p);
+    p.angle_diff_max = angle_diff_max;
+    p.shear_max = shear_max;
+    p.length_ratio_max = length_ratio_max;
+    p.camp = enemy;
+    Geom g1 = c->geom;
+    g1.n_frames = 1;
+    HIPCHK(c, launch_armours(g1, c->bufs, c->lim, p, c->stream), "k_armours");
+    HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+    int32_t na = 0, st = 0;
+    HIPCHK(c, hipMemcpy(&na, c->bufs.n_armours, 4, hipMemcpyDeviceToHost), "D2H");
+    HIPCHK(c, hipMemcpy(&st, c->bufs.status, 4, hipMemcpyDeviceToHost), "D2H");
+    if (n_armours) *n_armours = na;
+    if (st & RMCV_FRAME_OVF_ARMOURS) return fail(c, RMCV_ERR_CAPACITY, "context limit exceeded (max_armours)");
+    if (na > armours_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    if (armours_out && na) HIPCHK(c, hipMemcpy(armours_out, c->bufs.armours, (size_t)na * sizeof(rmcv_armour), hipMemcpyDeviceToHost), "D2H armours");
+    return RMCV_OK;
+}
+
+int rmcv_fit_ellipse(rmcv_ctx* c, const rmcv_point* pts, int n, rmcv_rrect* out)
+{
+    if (!c || !pts || !out || n < 5) return RMCV_ERR_BAD_ARG;
+    // run the blob stage on one contour with every gate open; the fitted ellipse is kept next to each blob
+    int32_t offs[2] = {0, n};
+    hipSetDevice(c->device);
+    int rc = load_contours(c, pts, offs, 1);
+    if (rc) return rc;
+    rmcv_params p;
+    rmcv_default_params(&p);
+    p.tilt_max = 1e30f;
+    p.ratio_lo = -1e30f;
+    p.ratio_hi = 1e30f;
+    p.area_lo = -1.0;
+    p.area_hi = 1e300;
+    Geom g1 = c->geom;
+    g1.n_frames = 1;
+    HIPCHK(c, launch_blobs(g1, c->bufs, c->lim, p, c->stream), "k_blobs");
+    HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+    int32_t nb = 0, nn = 0;
+    HIPCHK(c, hipMemcpy(&nb, c->bufs.n_blobs, 4, hipMemcpyDeviceToHost), "D2H");
+    HIPCHK(c, hipMemcpy(&nn, c->bufs.n_neg, 4, hipMemcpyDeviceToHost), "D2H");
+    if (nb != 1) return fail(c, RMCV_ERR_BAD_ARG, n < 6 ? "contour has fewer than 6 points" : "ellipse fit produced NaN");
+    HIPCHK(c, hipMemcpy(out, c->bufs.ellipses, sizeof(rmcv_rrect), hipMemcpyDeviceToHost), "D2H ellipse");
+    return RMCV_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,65 @@
+// rmcv_internal.h -- shared declarations of the HIP translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rmcv_abi.h"
+
+namespace rmcv {
+
+// Geometry of the frames currently bound to a context and of the bit planes derived from them.
+// Bit planes (foreground F, "labelled" LAB, "right-exit" NEG) hold one bit per pixel in u64 words,
+// bit b of word k = pixel x = 64*k + b.  Each plane is padded with one zero word left and right of
+// every row and one zero row above and below the image, so a 3x3 neighbourhood never needs a
+// bounds check:  word(y, k) lives at (y + 1) * prow + (k + 1).
+struct Geom {
+    int n_frames;
+    int w, h;
+    int stride;          // bytes between rows of the BGR input
+    int64_t frame_pitch; // bytes between frames of the BGR input
+    int ww;              // words per row = ceil(w / 64)
+    int prow;            // padded words per row = ww + 2
+    int64_t plane_pitch; // words per frame = (h + 2) * prow
+};
+
+struct Limits {
+    int max_frames, max_width, max_height, max_contours, max_points, max_blobs, max_armours;
+};
+
+// Device buffers of one context (all sized by Limits at creation, reused by every call).
+struct Bufs {
+    const uint8_t* frames; // BGR input (owned upload buffer or borrowed)
+    uint8_t* binary;       // [frame][h][w]          0/255           (imgproc.cpp:74 returns it)
+    uint64_t* bits;        // [frame] padded plane F (closed binary as bits)
+    uint64_t* lab;         // [frame] padded plane: pixel was visited by a border trace
+    uint64_t* neg;         // [frame] padded plane: ... and got the negative ("right exit") label
+    // contours in DISCOVERY order; cv::findContours returns them reversed (oracle/rmcv_oracle.c)
+    rmcv_point* points;    // [frame][max_points]
+    int32_t* cont_start;   // [frame][max_contours]
+    int32_t* cont_len;     // [frame][max_contours]
+    int32_t* n_contours;   // [frame]
+    int32_t* n_points;     // [frame]
+    // light blobs (positive list, in findContours order) and the negative list (contour indices)
+    rmcv_lightblob* blobs; // [frame][max_blobs]
+    int32_t* blob_src;     // [frame][max_blobs]   contour index (findContours order)
+    rmcv_rrect* ellipses;  // [frame][max_blobs]   the fitted ellipse of each positive
+    int32_t* neg_idx;      // [frame][max_contours]
+    int32_t* n_blobs;      // [frame]
+    int32_t* n_neg;        // [frame]
+    rmcv_armour* armours;  // [frame][max_armours]
+    int32_t* n_armours;    // [frame]
+    int32_t* status;       // [frame] RMCV_FRAME_* bits
+};
+
+// kernel launchers (each enqueues on `s` and returns the launch error)
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, hipStream_t s);
+hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
+hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
+hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
+// stage-wise helpers: binary (host-supplied 0/255 image) -> bit plane
+hipError_t launch_pack_bits(const Geom& g, const Bufs& b, hipStream_t s);
+// contours in findContours order as CSR (for download); d_offs has max_contours+1 entries per frame
+hipError_t launch_pack_contours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_point* d_pts_out, int32_t* d_offs_out,
+                                hipStream_t s);
+
+} // namespace rmcv

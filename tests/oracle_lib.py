@@ -1,0 +1,185 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under rmcv_amd/ may import this module; it is
+used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "_build", "liboracle.so")
+
+POINT = np.dtype([("x", "<i4"), ("y", "<i4")])
+RRECT = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("w", "<f4"), ("h", "<f4"), ("angle", "<f4")])
+LIGHTBLOB = np.dtype([("angle", "<f4"), ("target", "<i4"), ("center", "<f4", (2,)),
+                      ("vertices", "<f4", (4, 2)), ("size", "<f4", (2,))])
+ARMOUR = np.dtype([("icon", "<f4", (4, 2)), ("vertices", "<f4", (4, 2)), ("bbox", "<f4", (4,)),
+                   ("blob_i", "<i4"), ("blob_j", "<i4")])
+assert LIGHTBLOB.itemsize == 56 and ARMOUR.itemsize == 88
+
+CAMP_RED, CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL = 0, 1, 2, -1
+MORPH_NONE, MORPH_DILATE, MORPH_CLOSE = 0, 1, 2
+
+
+class Params(C.Structure):
+    _fields_ = [("camp", C.c_int32), ("lower_bound", C.c_int32), ("morph", C.c_int32), ("tilt_max", C.c_float),
+                ("ratio_lo", C.c_float), ("ratio_hi", C.c_float), ("area_lo", C.c_double), ("area_hi", C.c_double),
+                ("angle_diff_max", C.c_float), ("shear_max", C.c_float), ("length_ratio_max", C.c_float),
+                ("_pad", C.c_int32)]
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", os.path.join(_ROOT, "oracle")], check=True)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_contour_area.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def set_math_mode(mode):
+    lib().orc_set_math_mode(int(mode))
+
+
+def default_params(**kw):
+    p = Params()
+    lib().orc_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def extract_binary(bgr, camp=CAMP_BLUE, lower_bound=80, morph=MORPH_CLOSE):
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w, _ = bgr.shape
+    out = np.empty((h, w), np.uint8)
+    rc = lib().orc_extract_binary(_p(bgr), w, h, 3 * w, camp, lower_bound, morph, _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def dilate3x3(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib().orc_dilate3x3(_p(img), _p(out), img.shape[1], img.shape[0])
+    return out
+
+
+def erode3x3(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib().orc_erode3x3(_p(img), _p(out), img.shape[1], img.shape[0])
+    return out
+
+
+def find_contours(binary, cap_pts=None, cap_contours=None):
+    """returns (points[n_points] POINT, offs[n_contours+1] int32)"""
+    binary = np.ascontiguousarray(binary, np.uint8)
+    h, w = binary.shape
+    cap_pts = cap_pts or max(16, 4 * int(np.count_nonzero(binary)) + 16)
+    cap_contours = cap_contours or max(16, int(np.count_nonzero(binary)) + 16)
+    pts = np.zeros(cap_pts, POINT)
+    offs = np.zeros(cap_contours + 1, np.int32)
+    nc, npnt = C.c_int32(0), C.c_int32(0)
+    rc = lib().orc_find_contours(_p(binary), w, h, _p(pts), cap_pts, _p(offs), cap_contours, C.byref(nc), C.byref(npnt))
+    assert rc == 0, rc
+    return pts[:npnt.value].copy(), offs[:nc.value + 1].copy()
+
+
+def contours_as_lists(pts, offs):
+    return [[(int(p["x"]), int(p["y"])) for p in pts[offs[i]:offs[i + 1]]] for i in range(len(offs) - 1)]
+
+
+def contour_area(pts):
+    pts = np.ascontiguousarray(pts, POINT)
+    return lib().orc_contour_area(_p(pts), len(pts))
+
+
+def fit_ellipse_direct(pts):
+    pts = np.ascontiguousarray(pts, POINT)
+    out = np.zeros(1, RRECT)
+    path = lib().orc_fit_ellipse_direct(_p(pts), len(pts), _p(out))
+    return out[0], path
+
+
+def make_lightblob(rrect, camp):
+    r = np.zeros(1, RRECT)
+    r[0] = rrect
+    out = np.zeros(1, LIGHTBLOB)
+    lib().orc_make_lightblob(_p(r), camp, _p(out))
+    return out[0]
+
+
+def make_armour(a, b):
+    aa = np.zeros(1, LIGHTBLOB)
+    bb = np.zeros(1, LIGHTBLOB)
+    aa[0], bb[0] = a, b
+    out = np.zeros(1, ARMOUR)
+    lib().orc_make_armour(_p(aa), _p(bb), _p(out))
+    return out[0]
+
+
+def filter_lightblobs(pts, offs, p=None, want_ellipses=False):
+    p = p or default_params()
+    pts = np.ascontiguousarray(pts, POINT)
+    offs = np.ascontiguousarray(offs, np.int32)
+    n = len(offs) - 1
+    blobs = np.zeros(max(n, 1), LIGHTBLOB)
+    src = np.zeros(max(n, 1), np.int32)
+    neg = np.zeros(max(n, 1), np.int32)
+    ell = np.zeros(max(n, 1), RRECT)
+    nb, nn = C.c_int32(0), C.c_int32(0)
+    rc = lib().orc_filter_lightblobs(_p(pts), _p(offs), n, C.c_float(p.tilt_max), C.c_float(p.ratio_lo),
+                                     C.c_float(p.ratio_hi), C.c_double(p.area_lo), C.c_double(p.area_hi), p.camp,
+                                     _p(blobs), len(blobs), C.byref(nb), _p(src), _p(neg), C.byref(nn), _p(ell))
+    assert rc == 0, rc
+    if want_ellipses:
+        return blobs[:nb.value].copy(), src[:nb.value].copy(), neg[:nn.value].copy(), ell[:nb.value].copy()
+    return blobs[:nb.value].copy(), src[:nb.value].copy(), neg[:nn.value].copy()
+
+
+def filter_armours(blobs, p=None):
+    p = p or default_params()
+    blobs = np.ascontiguousarray(blobs, LIGHTBLOB)
+    n = len(blobs)
+    cap = max(1, n * (n - 1) // 2)
+    out = np.zeros(cap, ARMOUR)
+    na = C.c_int32(0)
+    rc = lib().orc_filter_armours(_p(blobs), n, C.c_float(p.angle_diff_max), C.c_float(p.shear_max),
+                                  C.c_float(p.length_ratio_max), p.camp, _p(out), cap, C.byref(na))
+    assert rc == 0, rc
+    return out[:na.value].copy()
+
+
+def detect_frame(bgr, p=None, cap_pts=1 << 18, cap_contours=1 << 14, cap_blobs=4096, cap_armours=4096):
+    """whole per-frame path; returns dict(binary, pts, offs, blobs, armours)"""
+    p = p or default_params()
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    binary = np.empty((h, w), np.uint8)
+    pts = np.zeros(cap_pts, POINT)
+    offs = np.zeros(cap_contours + 1, np.int32)
+    blobs = np.zeros(cap_blobs, LIGHTBLOB)
+    arm = np.zeros(cap_armours, ARMOUR)
+    nc, nb, na = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    rc = lib().orc_detect_frame(_p(bgr), w, h, 3 * w, C.byref(p), _p(binary), _p(pts), cap_pts, _p(offs), cap_contours,
+                                C.byref(nc), _p(blobs), cap_blobs, C.byref(nb), _p(arm), cap_armours, C.byref(na))
+    assert rc == 0, rc
+    o = offs[:nc.value + 1].copy()
+    return dict(binary=binary, pts=pts[:o[-1] if nc.value else 0].copy(), offs=o, blobs=blobs[:nb.value].copy(),
+                armours=arm[:na.value].copy())
