@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the armour-detection hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path over one batch of 256 synthetic 1280x1024 BGR frames that are
+already resident in HBM: rm::extract_color -> rm::filter_lightblobs -> rm::filter_armours
+(reference executable/main.cpp:172-176), followed by the device-side compaction of the armour
+lists and -- for N > 1 -- the RCCL gather of those lists to rank 0 (BASELINE config 4).  Weak
+scaling: every rank owns its own 256 frames, no collective on the data path.
+
+Prints ONE JSON line on rank 0: the contract fields plus
+  roofline      k_binary (the kernel that moves the algorithmic 4 B/px), timed with HIP events on
+                its own launch stream inside this process
+  cpu_baseline  the CPU oracle (a port/restatement of the reference path, oracle/) timed on this
+                box's host cores on a bounded sample of the same frames (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 1280, 1024
+FRAMES = 256
+BYTES_PER_FRAME = 4 * W * H          # 3 B/px BGR read + 1 B/px binary written
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES, help="frames per GPU per step")
+    ap.add_argument("--variant", type=int, default=0, help="0 plain stream, 1 stress stream")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C2 (binary only) side measurements")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_BINARY, Context, default_params,
+                          synth)
+    from rmcv_amd import dist as rdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the detection path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.frames
+    host = synth.batch(rank * n, n, W, H, CAMP_BLUE, args.variant, threads=min(16, os.cpu_count() or 1))
+    frames = torch.from_numpy(host).to(dev)                      # resident in HBM before any timing
+    ctx = Context(device=local_rank, max_frames=n, max_width=W, max_height=H)
+    ctx.bind_device_frames(frames.data_ptr(), n, H, W, keepalive=frames)
+    params = default_params()                                     # main.cpp:172-176: BLUE, lb 80, close, ...
+    cap = n * 16
+    head, _ = rdist.record_layout(n, cap)
+    rec = rdist.new_record(n, cap, dev)
+    stream = torch.cuda.Stream(device=dev)
+    sh = stream.cuda_stream
+
+    def step():
+        with torch.cuda.stream(stream):
+            ctx.run(params, STAGE_ALL, sh)
+            ctx.compact_armours_into(rec.data_ptr() + head, cap, rec.data_ptr(), sh)
+            return rdist.gather_records(rec) if world > 1 else [rec]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        recs = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        recs = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n * args.steps / dt
+
+    # ---- what was computed (outside the timed region): status + gathered list sanity
+    cnt = ctx.counts()
+    bad = int(np.count_nonzero(cnt["status"] & 15))
+    n_arm_local = int(cnt["n_armours"].sum())
+    gathered = None
+    if rank == 0:
+        arm, offs = rdist.unpack_records(recs, n, cap)
+        gathered = int(arm.shape[0])
+        assert offs[-1] == gathered and len(offs) == world * n + 1
+
+    # ---- per-kernel durations with HIP events on the launch stream (same command, extra passes)
+    stage = np.zeros(5)
+    reps = max(5, min(args.steps, 20))
+    for _ in range(reps):
+        stage += np.asarray(ctx.run_timed(params, STAGE_ALL, sh))
+    stage /= reps
+    k1_ms = float(stage[0])
+    achieved = n * BYTES_PER_FRAME / (k1_ms * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "k_binary_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("frames") == n and tj.get("width") == W and tj.get("height") == H:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "frames/sec (1280x1024 BGR) armour detect", "value": round(value, 1), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "C3: batch=%d/GPU 1280x1024 BGR, blue lb=80, close3x3 + findContours + lightblob fit + armour "
+                               "pairing%s" % (n, " + RCCL gather of armour lists (C4)" if world > 1 else ""),
+                   "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
+                   "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad},
+        "path_hbm_frac": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
+        "stage_ms": {"binary": round(float(stage[0]), 4), "contours": round(float(stage[1]), 4),
+                     "blobs": round(float(stage[2]), 4), "armours": round(float(stage[3]), 4),
+                     "sum": round(float(stage[4]), 4)},
+        "roofline": {"kernel": "k_binary", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME, "avg_launch_ms": round(k1_ms, 4)},
+    }
+
+    if not args.no_extras and rank == 0:
+        # BASELINE config 2: red team, subtract + threshold + morphology only
+        ex = {}
+        for name, morph in (("dilate", MORPH_DILATE), ("close", MORPH_CLOSE)):
+            p2 = default_params(camp=CAMP_RED, morph=morph)
+            for _ in range(2):
+                ctx.run(p2, STAGE_BINARY, sh)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ctx.run(p2, STAGE_BINARY, sh)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t0
+            ex[name + "_fps"] = round(n * args.steps / d2, 1)
+        out["c2_binary_only"] = ex
+
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O                                   # checker/baseline only, never the product path
+        O.set_math_mode(0)
+        m = min(args.cpu_frames, n)
+        p = O.default_params()
+        t0 = time.perf_counter()
+        tot = 0
+        for f in range(m):
+            tot += len(O.detect_frame(host[f], p)["armours"])
+        dc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(m / dc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "first %d frames of the same batch, oracle/ full path, 1 thread (the reference "
+                                         "runs detection on one process_thread)" % m,
+                               "armours": tot}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -172,6 +172,11 @@ int rmcv_batch_get_armours(rmcv_ctx* ctx, rmcv_armour* armours_out, int cap, int
 int rmcv_batch_device_views(rmcv_ctx* ctx, void** d_armours, void** d_counts, int32_t* per_frame_cap,
                             int32_t* n_frames);
 
+/* device-side, frame-major compaction into caller-provided HBM (e.g. torch tensors): d_armours_out has room
+ * for `cap` armours, d_frame_offs for n_frames+1 int32 (last entry = total, which may exceed cap: then only the
+ * first `cap` were written).  Asynchronous on hip_stream.  This is the payload of the multi-GPU gather. */
+int rmcv_batch_compact_armours(rmcv_ctx* ctx, void* d_armours_out, int cap, void* d_frame_offs, void* hip_stream);
+
 /* ---- synthetic stream: host generator, integer-only, bit-reproducible --- */
 int      rmcv_synth_frame(uint8_t* bgr, int w, int h, int stride, uint64_t frame_index, int camp, int variant);
 uint64_t rmcv_synth_checksum(const uint8_t* bgr, int w, int h, int stride);

@@ -30,7 +30,7 @@ EXPORTS = [
     "rmcv_last_error", "rmcv_extract_color", "rmcv_filter_lightblobs", "rmcv_filter_armours", "rmcv_fit_ellipse",
     "rmcv_batch_upload", "rmcv_batch_set_device_frames", "rmcv_batch_run", "rmcv_batch_sync", "rmcv_batch_run_timed",
     "rmcv_batch_counts", "rmcv_batch_get_binary", "rmcv_batch_get_contours", "rmcv_batch_get_blobs",
-    "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_synth_frame", "rmcv_synth_checksum",
+    "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_batch_compact_armours", "rmcv_synth_frame", "rmcv_synth_checksum",
 ]
 
 

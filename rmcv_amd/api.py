@@ -182,6 +182,11 @@ class Context:
         self._chk(lib().rmcv_batch_device_views(self._h, C.byref(a), C.byref(c), C.byref(cap), C.byref(n)))
         return a.value, c.value, cap.value, n.value
 
+    def compact_armours_into(self, d_armours_ptr, cap, d_frame_offs_ptr, stream=None):
+        """device-side compaction into caller HBM (async on `stream`)"""
+        self._chk(lib().rmcv_batch_compact_armours(self._h, C.c_void_p(d_armours_ptr), int(cap), C.c_void_p(d_frame_offs_ptr),
+                                                   C.c_void_p(stream or 0)))
+
     def detect_batch(self, frames, params=None):
         """the whole path of executable/main.cpp:172-176 on a batch of host frames"""
         self.upload(frames)

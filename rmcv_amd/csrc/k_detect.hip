@@ -141,6 +141,52 @@ __global__ __launch_bounds__(64) void k_armours(const rmcv_lightblob* __restrict
     }
 }
 
+// frame-major compaction of the per-frame armour slots into one list + offsets (the payload of the
+// multi-GPU detection gather).  One workgroup; n_frames is a few hundred.
+__global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __restrict__ armours,
+                                                        const int32_t* __restrict__ n_armours, int n_frames, int max_armours,
+                                                        rmcv_armour* __restrict__ out, int cap, int32_t* __restrict__ frame_offs)
+{
+    __shared__ int s_part[256];
+    __shared__ int s_base;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int f0 = 0; f0 < n_frames; f0 += 256) {
+        const int f = f0 + tid;
+        const int c = f < n_frames ? n_armours[f] : 0;
+        s_part[tid] = c;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) { // inclusive Hillis-Steele scan
+            int v = tid >= d ? s_part[tid - d] : 0;
+            __syncthreads();
+            s_part[tid] += v;
+            __syncthreads();
+        }
+        const int excl = s_base + s_part[tid] - c;
+        if (f < n_frames) {
+            frame_offs[f] = excl;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(armours + (int64_t)f * max_armours);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(out + excl);
+            for (int k = 0; k < c; k++)
+                if (excl + k < cap)
+                    for (int w = 0; w < (int)(sizeof(rmcv_armour) / 4); w++) dst[k * (sizeof(rmcv_armour) / 4) + w] = src[k * (sizeof(rmcv_armour) / 4) + w];
+        }
+        __syncthreads();
+        if (tid == 255) s_base += s_part[255];
+        __syncthreads();
+    }
+    if (tid == 0) frame_offs[n_frames] = s_base;
+}
+
+hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
+                                  int32_t* d_frame_offs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compact_armours, dim3(1), dim3(256), 0, s, b.armours, b.n_armours, g.n_frames, lim.max_armours, d_out,
+                       cap, d_frame_offs);
+    return hipGetLastError();
+}
+
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s)
 {
     hipLaunchKernelGGL(k_blobs, dim3(g.n_frames), dim3(64), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,

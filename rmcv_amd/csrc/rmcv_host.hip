@@ -424,6 +424,16 @@ int rmcv_batch_device_views(rmcv_ctx* c, void** d_armours, void** d_counts, int3
     return RMCV_OK;
 }
 
+int rmcv_batch_compact_armours(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* hip_stream)
+{
+    if (!c || !d_armours_out || !d_frame_offs || cap < 0) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    HIPCHK(c, launch_compact_armours(c->geom, c->bufs, c->lim, (rmcv_armour*)d_armours_out, cap, (int32_t*)d_frame_offs, s), "k_compact_armours");
+    c->last_stream = s;
+    return RMCV_OK;
+}
+
 /* ---------------- single-frame, host-buffer entry points ---------------- */
 
 int rmcv_extract_color(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride, int camp, int lower_bound, int morph,

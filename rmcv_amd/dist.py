@@ -1,0 +1,86 @@
+"""Multi-GPU: a batch of independent camera frames sharded over the ranks of one node.
+
+The reference is single-process (one process_thread, executable/main.cpp:55); frames carry no
+cross-frame state on this path, so rank r simply owns the contiguous block of frames
+[r*n/R, (r+1)*n/R).  There is no collective on the data path; the only exchange is the final gather
+of the (tiny, variable-length) armour lists to rank 0:
+
+    ONE torch.distributed.gather of a fixed-size record per rank
+        [ frame_offs : n_local+1 int32, padded to 16 B | armours : cap x 88 bytes ]
+    (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)
+
+The device-side compaction kernel (rmcv_batch_compact_armours) writes straight into the record, so a
+step is: detect -> compact -> gather, with no host round trip.  A gather lowers to grouped send/recv,
+i.e. every peer uses its own direct xGMI link to the root: the payload is O(100 KB), latency-bound,
+and must not be pushed round a ring.  frame_offs[-1] is the rank's true armour count; a count above
+`cap` is detected by unpack_records (the caller then re-gathers with a larger cap).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ARMOUR_BYTES = 88
+
+
+def shard(n_total, rank, world):
+    """contiguous block of frame indices owned by `rank`"""
+    return n_total * rank // world, n_total * (rank + 1) // world
+
+
+def record_layout(n_local, cap):
+    """(offset of armours, total bytes) of a rank's record"""
+    head = ((n_local + 1) * 4 + 15) // 16 * 16
+    return head, head + cap * ARMOUR_BYTES
+
+
+def new_record(n_local, cap, device):
+    _, total = record_layout(n_local, cap)
+    return torch.zeros(total, dtype=torch.uint8, device=device)
+
+
+def fill_record(rec, n_local, cap, frame_offs, armours_u8):
+    """host-side/packaged fill (tests, CPU): frame_offs int32[n_local+1], armours uint8[total*88]"""
+    head, _ = record_layout(n_local, cap)
+    rec[:(n_local + 1) * 4] = torch.as_tensor(np.ascontiguousarray(frame_offs, np.int32).view(np.uint8)).to(rec.device)
+    a = torch.as_tensor(np.ascontiguousarray(armours_u8, np.uint8).reshape(-1)).to(rec.device)
+    k = min(a.numel(), cap * ARMOUR_BYTES)
+    rec[head:head + k] = a[:k]
+    return rec
+
+
+def gather_records(rec, group=None, dst=0):
+    """the one collective of the path; returns the list of records on dst, None elsewhere"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [rec]
+    rank = dist.get_rank(group)
+    recs = [torch.empty_like(rec) for _ in range(dist.get_world_size(group))] if rank == dst else None
+    dist.gather(rec, recs, dst=dst, group=group)
+    return recs
+
+
+def unpack_records(recs, n_local, cap):
+    """records (rank order) -> (armours uint8 [total, 88], global frame_offs int64 [R*n_local+1]).
+    Raises OverflowError if some rank had more than `cap` armours."""
+    head, _ = record_layout(n_local, cap)
+    arms, offs, base = [], [0], 0
+    for r, rec in enumerate(recs):
+        h = rec.detach().cpu().numpy()
+        fo = h[:(n_local + 1) * 4].view(np.int32).astype(np.int64)
+        tot = int(fo[-1])
+        if tot > cap:
+            raise OverflowError("rank %d produced %d armours > record capacity %d" % (r, tot, cap))
+        arms.append(h[head:head + tot * ARMOUR_BYTES].reshape(tot, ARMOUR_BYTES))
+        offs.extend((fo[1:] + base).tolist())
+        base += tot
+    arm = np.concatenate(arms, axis=0) if arms else np.zeros((0, ARMOUR_BYTES), np.uint8)
+    return arm, np.asarray(offs, np.int64)
+
+
+def gather_detections(frame_offs, armours_u8, cap, device="cpu", group=None, dst=0):
+    """convenience form for host-side lists: pack, gather, unpack (on dst; None elsewhere)"""
+    n_local = len(frame_offs) - 1
+    rec = fill_record(new_record(n_local, cap, device), n_local, cap, frame_offs, armours_u8)
+    recs = gather_records(rec, group, dst)
+    if recs is None:
+        return None
+    return unpack_records(recs, n_local, cap)
