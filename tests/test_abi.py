@@ -1,0 +1,70 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/rmcv_abi.h declares
+(no compute calls here); struct layouts match the header; the product package never touches oracle/."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    h = open(os.path.join(ROOT, "include", "rmcv_abi.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(rmcv_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_exports_match_header():
+    from rmcv_amd import abi
+    L = abi.lib()
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "librmcv_hip.so does not export %s" % n
+    assert sorted(abi.EXPORTS) == names
+    assert L.rmcv_abi_version() == 1
+
+
+def test_struct_layouts_and_defaults():
+    from rmcv_amd import abi
+    assert C.sizeof(abi.Params) == 56 and C.sizeof(abi.Limits) == 32
+    assert abi.POINT.itemsize == 8 and abi.RRECT.itemsize == 20 and abi.LIGHTBLOB.itemsize == 56 and abi.ARMOUR.itemsize == 88
+    p = abi.default_params()   # executable/main.cpp:172-176
+    assert (p.camp, p.lower_bound, p.morph) == (1, 80, 2)
+    assert (p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi) == (70.0, 1.5, 80.0, 10.0, 99999.0)
+    assert p.angle_diff_max == 12.0 and p.shear_max == 22.0 and abs(p.length_ratio_max - 0.4) < 1e-7
+    lim = abi.Limits()
+    abi.lib().rmcv_default_limits(C.byref(lim))
+    assert lim.max_frames == 256 and lim.max_points == 65536
+
+
+def test_no_device_fails_loudly():
+    """without a GPU the product refuses to run -- it must never fall back to a CPU path"""
+    import torch
+    if torch.cuda.is_available():
+        return
+    import pytest
+    from rmcv_amd import Context, RmcvError
+    with pytest.raises(RmcvError) as e:
+        Context(device=0)
+    assert e.value.code == -5
+
+
+def test_product_does_not_import_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "rmcv_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c", ".hpp")) or f == "Makefile":
+                s = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle_lib" not in s and "liboracle" not in s, os.path.join(dp, f)
+                assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', s), os.path.join(dp, f)
+                assert not re.search(r"^\s*(from|import)\s+\S*oracle", s, flags=re.M), os.path.join(dp, f)
+
+
+def test_synth_is_deterministic():
+    from rmcv_amd import synth
+    a, b = synth.frame(3, 320, 256), synth.frame(3, 320, 256)
+    assert np.array_equal(a, b) and synth.checksum(a) == synth.checksum(b)
+    assert not np.array_equal(a, synth.frame(4, 320, 256))
+    red = synth.frame(3, 320, 256, camp=0)
+    assert np.array_equal(red[..., 0], a[..., 2]) and np.array_equal(red[..., 2], a[..., 0])   # the mirrored stream
