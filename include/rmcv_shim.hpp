@@ -1,0 +1,162 @@
+// rmcv_shim.hpp -- the reference's own rm:: signatures re-hosted on the C-ABI (include/rmcv_abi.h).
+//
+// Drop-in for the three functions executable/main.cpp:172-176 calls:
+//   rm::extract_color      include/imgproc.h:29       (body: src/imgproc.cpp:50-75)
+//   rm::filter_lightblobs  include/objdetect.h:47-49  (body: src/objdetect.cpp:55-87)
+//   rm::filter_armours     include/objdetect.h:70-71  (body: src/objdetect.cpp:114-166)
+//
+// Usage: compile this header into ONE translation unit of librmcv in place of
+// those three bodies, after including the reference's own "core.h" (it supplies rm::camp, rm::range,
+// rm::contour, rm::lightblob, rm::armour and the cv:: types), and link librmcv_hip.so.
+// The legacy names of the north star are aliased at the bottom (docs/core_8h_source.html:101,114).
+//
+// Every signature mentions cv:: types, so this header only compiles where OpenCV headers exist.
+#pragma once
+#if __has_include(<opencv2/opencv.hpp>)
+
+#include <stdexcept>
+#include <tuple>
+#include <vector>
+
+#include "rmcv_abi.h"
+
+#ifndef RMCV_CORE_H
+#error "include the reference's core.h before rmcv_shim.hpp"
+#endif
+
+namespace rm {
+namespace hip_detail {
+
+// one context per calling thread (the reference runs detection on a single process_thread,
+// executable/main.cpp:55); created on first use on device RMCV_DEVICE (default 0)
+inline rmcv_ctx* ctx()
+{
+    static thread_local rmcv_ctx* c = [] {
+        rmcv_ctx* p = nullptr;
+        rmcv_limits lim;
+        rmcv_default_limits(&lim);
+        lim.max_frames = 1;
+        const char* dev = std::getenv("RMCV_DEVICE");
+        const int rc = rmcv_ctx_create(dev ? std::atoi(dev) : 0, &lim, &p);
+        if (rc != RMCV_OK) throw std::runtime_error("rmcv: no usable MI355X device (this build has no CPU path)");
+        return p;
+    }();
+    return c;
+}
+
+inline void check(int rc)
+{ // the reference would let a cv::Exception escape (no try/catch in main.cpp); keep that shape
+    if (rc != RMCV_OK) throw std::runtime_error(std::string("rmcv: ") + rmcv_last_error(ctx()));
+}
+
+inline lightblob to_lightblob(const rmcv_lightblob& b)
+{
+    lightblob out(cv::RotatedRect(cv::Point2f(b.center[0], b.center[1]), cv::Size2f(b.size[0], b.size[1]), 0.f),
+                  static_cast<camp>(b.target));
+    out.angle = b.angle;
+    out.target = static_cast<camp>(b.target);
+    out.center = {b.center[0], b.center[1]};
+    for (int i = 0; i < 4; i++) out.vertices[i] = {b.vertices[i][0], b.vertices[i][1]};
+    out.size = {b.size[0], b.size[1]};
+    return out;
+}
+
+inline rmcv_lightblob from_lightblob(const lightblob& b)
+{
+    rmcv_lightblob o{};
+    o.angle = b.angle;
+    o.target = static_cast<int32_t>(b.target);
+    o.center[0] = b.center.x;
+    o.center[1] = b.center.y;
+    for (int i = 0; i < 4; i++) { o.vertices[i][0] = b.vertices[i].x; o.vertices[i][1] = b.vertices[i].y; }
+    o.size[0] = b.size.width;
+    o.size[1] = b.size.height;
+    return o;
+}
+
+} // namespace hip_detail
+
+inline std::tuple<std::vector<contour>, cv::Mat> extract_color(cv::InputArray image, camp target, int lower_bound)
+{
+    cv::Mat img = image.getMat();
+    CV_Assert(img.type() == CV_8UC3);
+    cv::Mat binary(img.rows, img.cols, CV_8UC1);
+    static thread_local std::vector<rmcv_point> pts;
+    static thread_local std::vector<int32_t> offs;
+    rmcv_limits lim;
+    rmcv_default_limits(&lim);
+    pts.resize(lim.max_points);
+    offs.resize(lim.max_contours + 1);
+    int32_t nc = 0, np = 0;
+    hip_detail::check(rmcv_extract_color(hip_detail::ctx(), img.data, img.cols, img.rows, (int)img.step, (int)target,
+                                         lower_bound, RMCV_MORPH_CLOSE, binary.data, pts.data(), (int)pts.size(),
+                                         offs.data(), (int)offs.size() - 1, &nc, &np));
+    std::vector<contour> contours(nc);
+    for (int i = 0; i < nc; i++) {
+        contours[i].reserve(offs[i + 1] - offs[i]);
+        for (int k = offs[i]; k < offs[i + 1]; k++) contours[i].emplace_back(pts[k].x, pts[k].y);
+    }
+    return {contours, binary};
+}
+
+inline auto filter_lightblobs(const std::vector<contour>& contours, const float tilt_max, const range<float> ratio_range,
+                              const range<double> area_range, camp enemy)
+    -> std::tuple<std::vector<lightblob>, std::vector<contour>>
+{
+    std::vector<rmcv_point> pts;
+    std::vector<int32_t> offs(contours.size() + 1, 0);
+    for (size_t i = 0; i < contours.size(); i++) {
+        for (const auto& p : contours[i]) pts.push_back({p.x, p.y});
+        offs[i + 1] = (int32_t)pts.size();
+    }
+    rmcv_limits lim;
+    rmcv_default_limits(&lim);
+    std::vector<rmcv_lightblob> blobs(lim.max_blobs);
+    std::vector<int32_t> neg(contours.size() + 1);
+    int32_t nb = 0, nn = 0;
+    hip_detail::check(rmcv_filter_lightblobs(hip_detail::ctx(), pts.data(), offs.data(), (int)contours.size(), tilt_max,
+                                             ratio_range.lower_bound, ratio_range.upper_bound, area_range.lower_bound,
+                                             area_range.upper_bound, (int)enemy, blobs.data(), (int)blobs.size(), &nb, nullptr,
+                                             neg.data(), &nn));
+    std::vector<lightblob> positive;
+    std::vector<contour> negative;
+    positive.reserve(nb);
+    for (int i = 0; i < nb; i++) positive.push_back(hip_detail::to_lightblob(blobs[i]));
+    for (int i = 0; i < nn; i++) negative.push_back(contours[neg[i]]);
+    return {positive, negative};
+}
+
+inline std::vector<armour> filter_armours(std::vector<lightblob>& lightblobs, const float angle_difference_max,
+                                          const float shear_max, const float lenght_ratio_max, const camp enemy)
+{
+    std::vector<rmcv_lightblob> in;
+    in.reserve(lightblobs.size());
+    for (const auto& b : lightblobs) in.push_back(hip_detail::from_lightblob(b));
+    rmcv_limits lim;
+    rmcv_default_limits(&lim);
+    std::vector<rmcv_armour> out(lim.max_armours);
+    int32_t na = 0;
+    hip_detail::check(rmcv_filter_armours(hip_detail::ctx(), in.data(), (int)in.size(), angle_difference_max, shear_max,
+                                          lenght_ratio_max, (int)enemy, out.data(), (int)out.size(), &na));
+    std::vector<armour> armours;
+    armours.reserve(na);
+    for (int k = 0; k < na; k++) {
+        // the reference's own constructor allocates the per-target Kalman state (core.cpp:21); the geometry
+        // members are then overwritten with the device results (identical bits, tests/test_gpu_parity.py)
+        armour a({lightblobs[out[k].blob_i], lightblobs[out[k].blob_j]});
+        for (int i = 0; i < 4; i++) {
+            a.icon[i] = {out[k].icon[i][0], out[k].icon[i][1]};
+            a.vertices[i] = {out[k].vertices[i][0], out[k].vertices[i][1]};
+        }
+        a.bounding_box = {out[k].bbox[0], out[k].bbox[1], out[k].bbox[2], out[k].bbox[3]};
+        armours.push_back(a);
+    }
+    return armours;
+}
+
+using LightBlob = lightblob; // pre-2024 API names used by the north star
+using Armour = armour;
+
+} // namespace rm
+
+#endif // __has_include(<opencv2/opencv.hpp>)

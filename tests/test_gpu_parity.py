@@ -71,3 +71,170 @@ def test_full_path_synthetic(ctx, oracle, variant):
         a = arm[aoffs[f]:aoffs[f + 1]]
         assert a["vertices"].tobytes() == ref["armours"]["vertices"].tobytes(), f
         assert a.tobytes() == ref["armours"].tobytes(), f
+
+
+# ---------------------------------------------------------------- stage-wise C-ABI entry points
+def test_stagewise_lightblobs_and_armours(ctx, oracle):
+    for idx in (11, 12, 1013):
+        f = synth.frame(idx, 1280, 1024, CAMP_BLUE, 1 if idx > 1000 else 0)
+        ref = oracle.detect_frame(f)
+        blobs, src, neg = ctx.filter_lightblobs(ref["pts"], ref["offs"])
+        rb, rs, rn = oracle.filter_lightblobs(ref["pts"], ref["offs"])
+        assert blobs.tobytes() == rb.tobytes() and np.array_equal(src, rs) and np.array_equal(neg, rn)
+        arm = ctx.filter_armours(rb)
+        assert arm.tobytes() == oracle.filter_armours(rb).tobytes()
+    assert len(ctx.filter_armours(np.zeros(0, blobs.dtype))) == 0
+    b, s, n = ctx.filter_lightblobs(np.zeros(0, ref["pts"].dtype), np.zeros(1, np.int32))
+    assert len(b) == 0 and len(n) == 0
+
+
+def test_fit_ellipse_both_paths(ctx, oracle):
+    import math
+    from test_oracle_kat import ellipse_points
+    for (A, B, n) in [(400, 150, 720), (36, 12, 40), (90, 14, 230), (12, 5, 24)]:
+        for deg in (0, 17, 60, 90, 133):
+            p = ellipse_points(700, 600, A, B, math.radians(deg), n)
+            r, _ = oracle.fit_ellipse_direct(p)
+            g = ctx.fit_ellipse(p)
+            assert g.tobytes() == r.tobytes(), (A, B, n, deg, g, r)
+
+
+def test_pairing_kats_on_gpu(ctx, oracle):
+    from test_oracle_kat import blob
+    sets = [[blob(100, 100, 40), blob(200, 100, 40)], [blob(100, 100, 40), blob(170, 100, 40), blob(240, 100, 40)],
+            [blob(100, 100, 40), blob(130, 118, 40)], [blob(100, 100, 40), blob(200, 100, 12)],
+            [blob(100 + 37 * k, 100 + (k % 3) * 5, 30 + k) for k in range(70)]]
+    for s in sets:
+        arr = np.array(s, oracle.LIGHTBLOB)
+        for kw in ({}, dict(shear_max=40.0), dict(length_ratio_max=0.2), dict(angle_diff_max=999.0, shear_max=999.0, length_ratio_max=0.01)):
+            p = oracle.default_params(**kw)
+            ref = oracle.filter_armours(arr, p)
+            if len(ref) > ctx.limits.max_armours:
+                continue
+            got = ctx.filter_armours(arr, p.angle_diff_max, p.shear_max, p.length_ratio_max)
+            assert got.tobytes() == ref.tobytes()
+
+
+# ---------------------------------------------------------------- nested components: the external rule
+def test_contours_nested_shapes(ctx, oracle):
+    h, w = 96, 192
+    canvas = np.zeros((h, w), np.uint8)
+    canvas[4:40, 4:60] = 255
+    canvas[10:34, 10:54] = 0            # ring
+    canvas[16:28, 20:44] = 255          # island in the hole
+    canvas[19:25, 26:38] = 0            # with its own hole
+    canvas[21:23, 30:33] = 255          # and an island in that
+    canvas[50:90, 70:130] = 255
+    canvas[50:80, 80:120] = 0           # U cavity
+    canvas[60:70, 90:100] = 255         # blob in the cavity: kept
+    canvas[5:90, 150] = 255             # 1-px vertical line
+    canvas[45, 140:190] = 255           # crossing 1-px horizontal line
+    canvas[0, 0] = canvas[h - 1, w - 1] = canvas[0, w - 1] = 255
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        img = np.zeros((h, w, 3), np.uint8)
+        c = canvas.copy()
+        if trial:
+            c[rng.random((h, w)) < 0.01 * trial] ^= 255
+        img[..., 0] = c
+        pts, offs, binary = ctx.extract_color_csr(img, CAMP_BLUE, 80, MORPH_NONE)
+        assert np.array_equal(binary, c)
+        rp, ro = oracle.find_contours(c)
+        assert np.array_equal(offs, ro) and np.array_equal(pts, rp), trial
+
+
+@pytest.mark.parametrize("density", [0.02, 0.2, 0.5, 0.8])
+def test_contours_noise(ctx, oracle, density):
+    """salt-and-pepper at several densities: thousands of tiny, touching and nested components"""
+    rng = np.random.default_rng(int(density * 100))
+    h, w = 120, 200
+    c = ((rng.random((h, w)) < density) * 255).astype(np.uint8)
+    img = np.zeros((h, w, 3), np.uint8)
+    img[..., 0] = c
+    pts, offs, binary = ctx.extract_color_csr(img, CAMP_BLUE, 80, MORPH_NONE)
+    rp, ro = oracle.find_contours(c)
+    assert np.array_equal(offs, ro) and np.array_equal(pts, rp)
+
+
+# ---------------------------------------------------------------- committed golden vectors
+def test_golden_vectors_gpu(ctx):
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synthetic_armours.json")))
+    frames = np.stack([synth.frame(r["index"], g["width"], g["height"], g["camp"], r["variant"]) for r in g["frames"]])
+    arm, offs = ctx.detect_batch(frames)
+    cnt = ctx.counts()
+    for k, rec in enumerate(g["frames"]):
+        a = arm[offs[k]:offs[k + 1]]
+        got = [[float.hex(float(v)) for v in x["vertices"].reshape(-1)] for x in a]
+        assert got == rec["armour_vertices_hex"], rec["index"]
+        assert cnt["n_contours"][k] == rec["n_contours"] and cnt["n_points"][k] == rec["n_points"]
+        assert cnt["n_blobs"][k] == rec["n_blobs"]
+
+
+# ---------------------------------------------------------------- capacity errors and geometry changes
+def test_capacity_is_reported(oracle):
+    from rmcv_amd import Context, RmcvError
+    small = Context(device=0, max_frames=1, max_width=256, max_height=128, max_contours=4, max_points=64, max_blobs=2,
+                    max_armours=1)
+    img = np.zeros((128, 256, 3), np.uint8)
+    for k in range(8):
+        img[10:60, 10 + 30 * k:16 + 30 * k, 0] = 255
+    with pytest.raises(RmcvError) as e:
+        small.extract_color_csr(img, CAMP_BLUE, 80)
+    assert e.value.code == -2
+    with pytest.raises(RmcvError):
+        small.extract_color_csr(np.zeros((200, 300, 3), np.uint8), CAMP_BLUE, 80)   # larger than the context
+    rb = np.array([oracle.make_lightblob(np.array((100 + 70 * k, 100, 10, 40, 0), oracle.RRECT), 1) for k in range(2)])
+    assert len(small.filter_armours(rb)) == 1
+    rb3 = np.array([oracle.make_lightblob(np.array((100 + 70 * k, 100, 10, 40, 0), oracle.RRECT), 1) for k in range(3)])
+    with pytest.raises(RmcvError) as e:
+        small.filter_armours(rb3)
+    assert e.value.code == -2
+    small.close()
+
+
+def test_geometry_changes_on_one_context(ctx, oracle):
+    rng = np.random.default_rng(9)
+    for (h, w) in [(200, 333), (64, 64), (130, 640), (64, 64), (1024, 1280), (90, 100)]:
+        img = rand_bgr(rng, h, w) if h < 1000 else synth.frame(77, w, h, CAMP_BLUE, 1)
+        pts, offs, binary = ctx.extract_color_csr(img, CAMP_BLUE, 80, MORPH_CLOSE)
+        rb = oracle.extract_binary(img, CAMP_BLUE, 80, MORPH_CLOSE)
+        rp, ro = oracle.find_contours(rb)
+        assert np.array_equal(binary, rb) and np.array_equal(offs, ro) and np.array_equal(pts, rp), (h, w)
+
+
+# ---------------------------------------------------------------- BASELINE full size: 256 x 1280x1024
+def test_full_size_batch_properties(oracle):
+    """size-independent properties at BASELINE.json's full batch, plus the oracle on every frame's armour list"""
+    from rmcv_amd import Context
+    n = 256
+    big = Context(device=0, max_frames=n, max_width=1280, max_height=1024)
+    frames = synth.batch(0, n, 1280, 1024, CAMP_BLUE, 0, threads=16)
+    arm, offs = big.detect_batch(frames)
+    cnt = big.counts()
+    assert not (cnt["status"] & 15).any()
+    bin7 = big.binary(7)
+    # (1) determinism: a second run gives the same bytes
+    arm2, offs2 = big.detect_batch(frames)
+    assert arm.tobytes() == arm2.tobytes() and np.array_equal(offs, offs2)
+    # (2) frames are independent: two half batches == the full batch (the sharding property of config 4)
+    a0, o0 = big.detect_batch(frames[:n // 2])
+    a1, o1 = big.detect_batch(frames[n // 2:])
+    assert a0.tobytes() + a1.tobytes() == arm.tobytes()
+    assert np.array_equal(np.concatenate([o0, o1[1:] + o0[-1]]), offs)
+    # (3) closing is idempotent: feed a closed binary back in as the blue channel
+    fb = np.zeros((2, 1024, 1280, 3), np.uint8)
+    fb[0, ..., 0] = bin7
+    fb[1, ..., 0] = bin7
+    big.upload(fb)
+    big.run(default_params(), STAGE_BINARY)
+    big.sync()
+    assert np.array_equal(big.binary(0), bin7) and np.array_equal(big.binary(1), bin7)
+    # (4) the reference path (oracle) on every frame: the emitted armour vertex lists are identical
+    p = oracle.default_params()
+    for f in range(n):
+        ref = oracle.detect_frame(frames[f], p)["armours"]
+        assert arm[offs[f]:offs[f + 1]].tobytes() == ref.tobytes(), f
+    assert offs[-1] > n
+    big.close()
