@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librmcv_hip.so")
+LIB_PATH = os.environ.get("RMCV_LIB_PATH") or os.path.join(_HERE, "lib", "librmcv_hip.so")  # env: dev A/B builds
 
 # PODs of include/rmcv_abi.h as numpy dtypes
 POINT = np.dtype([("x", "<i4"), ("y", "<i4")])

@@ -18,11 +18,38 @@
 // mapped so that consecutive strips of a frame land on the same XCD (blockIdx % 8 groups), where the
 // halo rows they share are L2 hits.  Border semantics (OpenCV morphologyDefaultBorderValue): samples
 // outside the image never win, i.e. they read 0 for the dilate and 1 for the erode.
+#include <stdlib.h>
+
 #include "rmcv_internal.h"
 
 namespace rmcv {
 
-static constexpr int SR = 64; // strip rows per workgroup
+#ifndef RMCV_SR
+#define RMCV_SR 32
+#endif
+static constexpr int SR = RMCV_SR; // strip rows per workgroup
+
+// streaming hints (dev knobs): frames are read once, `binary` is written once
+__device__ __forceinline__ uint4 ld_stream(const uint4* p)
+{
+#ifdef RMCV_NT_LOAD
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint4* p, uint4 v)
+{
+#ifndef RMCV_NO_NT_STORE
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+#else
+    *p = v;
+#endif
+}
 
 __device__ __forceinline__ uint32_t expand4(uint32_t nib)
 { // 4 mask bits -> 4 bytes of 0x00/0xFF
@@ -44,7 +71,10 @@ __device__ __forceinline__ uint32_t thresh16(const uint32_t d[12], int lb)
 }
 
 // lb is pre-clamped on the host to [1, 256]: lb <= 0 means "everything passes" (lb = -1 flag).
-template <int CA, int CB, bool FAST>
+// LOADV (FAST only): 0 = each lane loads its own 48 contiguous bytes (lane stride 48 B);
+//                    1 = wave-coalesced loads (lane stride 16 B, 3 x 1 KiB per wave) transposed through a
+//                        wave-private 3 KiB LDS buffer; needs contiguous rows (stride == 3*w)
+template <int CA, int CB, bool FAST, int LOADV>
 __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride,
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
@@ -67,7 +97,40 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     const int wq = ww * 4; // 16-pixel groups per row
 
     // ---------------- phase 1: load + threshold -> T
-    {
+    if (FAST && LOADV == 1) {
+        const int items = srh * wq;
+        const int lane = tid & 63;
+        uint8_t* wbuf = reinterpret_cast<uint8_t*>(smem + (size_t)2 * (SR + 4) * ww) + (tid >> 6) * 3072;
+        const int64_t frame_bytes = (int64_t)h * stride;
+        const int64_t strip_off = (int64_t)(y0 - halo) * stride;
+        int rr = tid / wq, q = tid - rr * wq;
+        const int dr = 256 / wq, dq = 256 - dr * wq;
+        for (int it = tid; it - lane < items; it += 256) {
+            const int64_t seg = strip_off + (int64_t)(it - lane) * 48 + lane * 16;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int64_t off = seg + k * 1024;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (off >= 0 && off < frame_bytes) v = ld_stream(reinterpret_cast<const uint4*>(frame + off));
+                *reinterpret_cast<uint4*>(wbuf + k * 1024 + lane * 16) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint4* src = reinterpret_cast<const uint4*>(wbuf + lane * 48);
+            uint4 v0 = src[0], v1 = src[1], v2 = src[2];
+            __builtin_amdgcn_wave_barrier();
+            uint32_t d[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+            const int y = y0 - halo + rr;
+            uint32_t m = 0;
+            if (it < items && y >= 0 && y < h) m = all_pass ? 0xFFFFu : thresh16<CA, CB>(d, lb);
+            uint32_t v = m << (16 * (q & 1));
+            v |= __shfl_xor(v, 1);
+            uint32_t o = __shfl_xor(v, 2);
+            if (it < items && (q & 3) == 0) T[rr * ww + (q >> 2)] = ((uint64_t)o << 32) | v;
+            rr += dr;
+            q += dq;
+            if (q >= wq) { q -= wq; rr++; }
+        }
+    } else {
         const int items = srh * wq;
         int rr = tid / wq, q = tid - rr * wq;
         const int dr = 256 / wq, dq = 256 - dr * wq;
@@ -77,7 +140,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
             if (y >= 0 && y < h) {
                 if (FAST) {
                     const uint4* src = reinterpret_cast<const uint4*>(frame + (int64_t)y * stride + q * 48);
-                    uint4 v0 = src[0], v1 = src[1], v2 = src[2];
+                    uint4 v0 = ld_stream(src), v1 = ld_stream(src + 1), v2 = ld_stream(src + 2);
                     uint32_t d[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
                     m = all_pass ? 0xFFFFu : thresh16<CA, CB>(d, lb);
                 } else {
@@ -170,7 +233,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
                     o.y = expand4(m >> 4);
                     o.z = expand4(m >> 8);
                     o.w = expand4(m >> 12);
-                    *reinterpret_cast<uint4*>(bin + (int64_t)y * w + q * 16) = o;
+                    st_stream(reinterpret_cast<uint4*>(bin + (int64_t)y * w + q * 16), o);
                 } else {
                     for (int p = 0; p < 16; p++) {
                         int x = q * 16 + p;
@@ -194,15 +257,18 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     int lb = lower_bound, all_pass = 0;
     if (lb <= 0) { all_pass = 1; lb = 1; }
     if (lb > 256) lb = 256;
-    const size_t lds = (size_t)2 * (SR + 4) * g.ww * sizeof(uint64_t);
+    const size_t planes = (size_t)2 * (SR + 4) * g.ww * sizeof(uint64_t);
     const bool fast = (g.w % 64 == 0) && (g.stride % 16 == 0) && (g.frame_pitch % 16 == 0) &&
                       ((uintptr_t)b.frames % 16 == 0);
-    if (fast)
-        hipLaunchKernelGGL((k_binary<CA, CB, true>), dim3(n_blocks), dim3(256), lds, s, b.frames, g.frame_pitch, g.stride,
-                           g.w, g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks);
-    else
-        hipLaunchKernelGGL((k_binary<CA, CB, false>), dim3(n_blocks), dim3(256), lds, s, b.frames, g.frame_pitch, g.stride,
-                           g.w, g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks);
+    static const int forced = getenv("RMCV_K1_LOADV") ? atoi(getenv("RMCV_K1_LOADV")) : -1; // dev knob for A/B runs
+    const bool coalesced = fast && g.stride == 3 * g.w && forced != 0;
+#define RMCV_K1_LAUNCH(F, V, LDS)                                                                                          \
+    hipLaunchKernelGGL((k_binary<CA, CB, F, V>), dim3(n_blocks), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, \
+                       g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks)
+    if (coalesced) RMCV_K1_LAUNCH(true, 1, planes + 4 * 3072);
+    else if (fast) RMCV_K1_LAUNCH(true, 0, planes);
+    else RMCV_K1_LAUNCH(false, 0, planes);
+#undef RMCV_K1_LAUNCH
     return hipGetLastError();
 }
 
