@@ -22,22 +22,6 @@ namespace rmcv {
 __device__ __forceinline__ double dabs(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ double dsqrt(double x) { return ::sqrt(x); }
 
-// cv::contourArea(contour, false): shoelace in double over float-converted points
-__device__ inline double contour_area(const rmcv_point* pts, int n)
-{
-    if (n == 0) return 0.0;
-    double a00 = 0;
-    float px = (float)pts[n - 1].x, py = (float)pts[n - 1].y;
-    for (int i = 0; i < n; i++) {
-        float x = (float)pts[i].x, y = (float)pts[i].y;
-        a00 += (double)px * y - (double)py * x;
-        px = x;
-        py = y;
-    }
-    a00 *= 0.5;
-    return dabs(a00);
-}
-
 // ---- 3x3 real non-symmetric eigen-solver: JAMA orthes + hqr2 (cv::eigenNonSymmetric) -------------
 __device__ inline void cdiv_(double xr, double xi, double yr, double yi, double* cr, double* ci)
 {
@@ -489,80 +473,25 @@ __device__ __forceinline__ void get_ofs(int i, float eps, float* ox, float* oy)
     *oy = (float)(((i & 2) - 1)) * eps;
 }
 
-// general conic ("LIN") fit: the fallback of fitEllipseDirect
-__device__ inline void fit_ellipse_general(const rmcv_point* pts, int n, rmcv_rrect* box)
+// ---- scalar tails of the ellipse fits (the point sums are accumulated by the caller, wave-cooperatively,
+//      in contour order: see k_detect.hip) -------------------------------------------------------------
+
+// general conic ("LIN") fit, after the 5-parameter solve: centre from the conic gradient
+__device__ inline void general_centre(const double gfp[5], double rp[5])
+{
+    const double a00 = 2 * gfp[0], a01 = gfp[2], a11 = 2 * gfp[1];
+    const double det = a00 * a11 - a01 * a01;
+    rp[0] = rp[1] = 0.0;
+    if (det != 0.0) {
+        rp[0] = (gfp[3] * a11 - gfp[4] * a01) / det;
+        rp[1] = (a00 * gfp[4] - a01 * gfp[3]) / det;
+    }
+}
+
+// general fit, after the 3-parameter re-fit: angle, radii, RotatedRect
+__device__ inline void general_finish(const double gfp[3], double rp[5], double scale, float cx, float cy, rmcv_rrect* box)
 {
     const double min_eps = 1e-8;
-    float cx = 0, cy = 0;
-    for (int i = 0; i < n; i++) {
-        cx += (float)pts[i].x;
-        cy += (float)pts[i].y;
-    }
-    cx /= (float)n;
-    cy /= (float)n;
-    double s = 0;
-    for (int i = 0; i < n; i++) {
-        float px = (float)pts[i].x - cx, py = (float)pts[i].y - cy;
-        s += dabs((double)px) + dabs((double)py);
-    }
-    const double scale = 100.0 / (s > FLT_EPSILON ? s : (double)FLT_EPSILON);
-    double gfp[5], rp[5] = {0, 0, 0, 0, 0};
-    float eps = 0.0f;
-    for (int iter = 0; iter < 2; iter++) {
-        double G[25], g[5], wmax, wmin;
-        for (int i = 0; i < 25; i++) G[i] = 0.0;
-        for (int i = 0; i < 5; i++) g[i] = 0.0;
-        for (int i = 0; i < n; i++) {
-            float ox = 0, oy = 0;
-            if (iter) get_ofs(i, eps, &ox, &oy);
-            float fx = ((float)pts[i].x + ox) - cx, fy = ((float)pts[i].y + oy) - cy;
-            double px = fx * scale, py = fy * scale;
-            double row[5] = {-px * px, -py * py, -px * py, px, py};
-#pragma unroll
-            for (int a = 0; a < 5; a++) {
-#pragma unroll
-                for (int b = a; b < 5; b++) G[a * 5 + b] += row[a] * row[b];
-                g[a] += row[a] * 10000.0;
-            }
-        }
-        for (int a = 0; a < 5; a++)
-            for (int b = 0; b < a; b++) G[a * 5 + b] = G[b * 5 + a];
-        normal_solve(G, g, 5, gfp, &wmax, &wmin);
-        if (iter == 0 && wmax * FLT_EPSILON > wmin) {
-            eps = (float)(s / (n * 2) * 1e-3);
-            continue;
-        }
-        break;
-    }
-    {
-        double a00 = 2 * gfp[0], a01 = gfp[2], a11 = 2 * gfp[1];
-        double det = a00 * a11 - a01 * a01;
-        if (det != 0.0) {
-            rp[0] = (gfp[3] * a11 - gfp[4] * a01) / det;
-            rp[1] = (a00 * gfp[4] - a01 * gfp[3]) / det;
-        }
-    }
-    {
-        double G[9], g[3];
-        for (int i = 0; i < 9; i++) G[i] = 0.0;
-        for (int i = 0; i < 3; i++) g[i] = 0.0;
-        for (int i = 0; i < n; i++) {
-            float ox = 0, oy = 0;
-            if (eps != 0.0f) get_ofs(i, eps, &ox, &oy);
-            float fx = ((float)pts[i].x + ox) - cx, fy = ((float)pts[i].y + oy) - cy;
-            double px = fx * scale, py = fy * scale;
-            double row[3] = {(px - rp[0]) * (px - rp[0]), (py - rp[1]) * (py - rp[1]), (px - rp[0]) * (py - rp[1])};
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-#pragma unroll
-                for (int b = a; b < 3; b++) G[a * 3 + b] += row[a] * row[b];
-                g[a] += row[a] * 1.0;
-            }
-        }
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < a; b++) G[a * 3 + b] = G[b * 3 + a];
-        normal_solve(G, g, 3, gfp, 0, 0);
-    }
     double t;
     rp[4] = -0.5 * pm_atan2(gfp[2], gfp[1] - gfp[0]);
     if (dabs(gfp[2]) > min_eps) t = gfp[2] / pm_sin(-2.0 * rp[4]);
@@ -588,113 +517,76 @@ __device__ inline void fit_ellipse_general(const rmcv_point* pts, int n, rmcv_rr
 
 __device__ __forceinline__ bool is_good_box(const rmcv_rrect* b) { return (b->h <= b->w * 30) && (b->w <= b->h * 30); }
 
-// cv::fitEllipseDirect; returns 0 = direct solution, 1 = general fit
-__device__ inline int fit_ellipse_direct(const rmcv_point* pts, int n, rmcv_rrect* box)
+// direct fit: scatter matrix DM (6x6, already divided by n) -> TM, Ts, M; returns det(M)
+__device__ inline double direct_reduce(const double DM[6][6], double TM[3][3], double* Ts_out, double M[3][3])
 {
-    double cx = 0, cy = 0;
-    for (int i = 0; i < n; i++) {
-        cx += (float)pts[i].x;
-        cy += (float)pts[i].y;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        TM[0][c] = DM[c][5] * DM[3][5] * DM[4][4] - DM[c][5] * DM[3][4] * DM[4][5] - DM[c][4] * DM[3][5] * DM[5][4] +
+                   DM[c][3] * DM[4][5] * DM[5][4] + DM[c][4] * DM[3][4] * DM[5][5] - DM[c][3] * DM[4][4] * DM[5][5];
+        TM[1][c] = DM[c][5] * DM[3][3] * DM[4][5] - DM[c][5] * DM[3][5] * DM[4][3] + DM[c][4] * DM[3][5] * DM[5][3] -
+                   DM[c][3] * DM[4][5] * DM[5][3] - DM[c][4] * DM[3][3] * DM[5][5] + DM[c][3] * DM[4][3] * DM[5][5];
+        TM[2][c] = DM[c][5] * DM[3][4] * DM[4][3] - DM[c][5] * DM[3][3] * DM[4][4] - DM[c][4] * DM[3][4] * DM[5][3] +
+                   DM[c][3] * DM[4][4] * DM[5][3] + DM[c][4] * DM[3][3] * DM[5][4] - DM[c][3] * DM[4][3] * DM[5][4];
     }
-    cx /= n;
-    cy /= n;
-    double s = 0;
-    for (int i = 0; i < n; i++) s += dabs((float)pts[i].x - cx) + dabs((float)pts[i].y - cy);
-    const double scale = 100.0 / (s > FLT_EPSILON ? s : (double)FLT_EPSILON);
+    const double Ts = (-(DM[3][5] * DM[4][4] * DM[5][3]) + DM[3][4] * DM[4][5] * DM[5][3] + DM[3][5] * DM[4][3] * DM[5][4] -
+                       DM[3][3] * DM[4][5] * DM[5][4] - DM[3][4] * DM[4][3] * DM[5][5] + DM[3][3] * DM[4][4] * DM[5][5]);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        M[0][c] = (DM[2][c] + (DM[2][3] * TM[0][c] + DM[2][4] * TM[1][c] + DM[2][5] * TM[2][c]) / Ts) / 2.;
+        M[1][c] = -DM[1][c] - (DM[1][3] * TM[0][c] + DM[1][4] * TM[1][c] + DM[1][5] * TM[2][c]) / Ts;
+        M[2][c] = (DM[0][c] + (DM[0][3] * TM[0][c] + DM[0][4] * TM[1][c] + DM[0][5] * TM[2][c]) / Ts) / 2.;
+    }
+    *Ts_out = Ts;
+    return M[0][0] * (M[1][1] * M[2][2] - M[2][1] * M[1][2]) - M[0][1] * (M[1][0] * M[2][2] - M[2][0] * M[1][2]) +
+           M[0][2] * (M[1][0] * M[2][1] - M[2][0] * M[1][1]);
+}
 
-    double DM[6][6], TM[3][3], M[3][3], Ts = 0;
-    float eps = 0;
-    int iter;
-    for (iter = 0; iter < 2; iter++) {
-        double acc[6][6];
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = 0; b < 6; b++) acc[a][b] = 0.0;
-        for (int i = 0; i < n; i++) {
-            float ox, oy;
-            get_ofs(i, eps, &ox, &oy);
-            double px = (((float)pts[i].x + ox) - cx) * scale, py = (((float)pts[i].y + oy) - cy) * scale;
-            double row[6] = {px * px, px * py, py * py, px, py, 1.0};
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int b = a; b < 6; b++) acc[a][b] += row[a] * row[b];
-        }
-        const double inv_n = 1.0 / n;
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = a; b < 6; b++) DM[a][b] = DM[b][a] = acc[a][b] * inv_n;
-
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            TM[0][c] = DM[c][5] * DM[3][5] * DM[4][4] - DM[c][5] * DM[3][4] * DM[4][5] - DM[c][4] * DM[3][5] * DM[5][4] +
-                       DM[c][3] * DM[4][5] * DM[5][4] + DM[c][4] * DM[3][4] * DM[5][5] - DM[c][3] * DM[4][4] * DM[5][5];
-            TM[1][c] = DM[c][5] * DM[3][3] * DM[4][5] - DM[c][5] * DM[3][5] * DM[4][3] + DM[c][4] * DM[3][5] * DM[5][3] -
-                       DM[c][3] * DM[4][5] * DM[5][3] - DM[c][4] * DM[3][3] * DM[5][5] + DM[c][3] * DM[4][3] * DM[5][5];
-            TM[2][c] = DM[c][5] * DM[3][4] * DM[4][3] - DM[c][5] * DM[3][3] * DM[4][4] - DM[c][4] * DM[3][4] * DM[5][3] +
-                       DM[c][3] * DM[4][4] * DM[5][3] + DM[c][4] * DM[3][3] * DM[5][4] - DM[c][3] * DM[4][3] * DM[5][4];
-        }
-        Ts = (-(DM[3][5] * DM[4][4] * DM[5][3]) + DM[3][4] * DM[4][5] * DM[5][3] + DM[3][5] * DM[4][3] * DM[5][4] -
-              DM[3][3] * DM[4][5] * DM[5][4] - DM[3][4] * DM[4][3] * DM[5][5] + DM[3][3] * DM[4][4] * DM[5][5]);
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            M[0][c] = (DM[2][c] + (DM[2][3] * TM[0][c] + DM[2][4] * TM[1][c] + DM[2][5] * TM[2][c]) / Ts) / 2.;
-            M[1][c] = -DM[1][c] - (DM[1][3] * TM[0][c] + DM[1][4] * TM[1][c] + DM[1][5] * TM[2][c]) / Ts;
-            M[2][c] = (DM[0][c] + (DM[0][3] * TM[0][c] + DM[0][4] * TM[1][c] + DM[0][5] * TM[2][c]) / Ts) / 2.;
-        }
-        double det = M[0][0] * (M[1][1] * M[2][2] - M[2][1] * M[1][2]) - M[0][1] * (M[1][0] * M[2][2] - M[2][0] * M[1][2]) +
-                     M[0][2] * (M[1][0] * M[2][1] - M[2][0] * M[1][1]);
-        if (dabs(det) > 1.0e-10) break;
-        eps = (float)(s / (n * 2) * 1e-2);
+// direct fit: eigenvector selection, conic -> RotatedRect (width <= height, angle in [0,180))
+__device__ inline void direct_finish(const double M[3][3], const double TM[3][3], double Ts, double scale, double cx,
+                                     double cy, rmcv_rrect* box)
+{
+    double eval[3], ev[3][3], cond[3];
+    int i;
+    eigen_nonsymmetric3(M, eval, ev);
+    cond[0] = (4.0 * ev[0][0] * ev[0][2] - ev[0][1] * ev[0][1]);
+    cond[1] = (4.0 * ev[1][0] * ev[1][2] - ev[1][1] * ev[1][1]);
+    cond[2] = (4.0 * ev[2][0] * ev[2][2] - ev[2][1] * ev[2][1]);
+    if (cond[0] < cond[1]) i = (cond[1] < cond[2]) ? 2 : 1;
+    else i = (cond[0] < cond[2]) ? 2 : 0;
+    const double e0 = ev[i][0], e1 = ev[i][1], e2 = ev[i][2];
+    double norm = dsqrt(e0 * e0 + e1 * e1 + e2 * e2);
+    if (((e0 < 0.0 ? -1 : 1) * (e1 < 0.0 ? -1 : 1) * (e2 < 0.0 ? -1 : 1)) <= 0.0) norm = -1.0 * norm;
+    const double pv0 = e0 / norm, pv1 = e1 / norm, pv2 = e2 / norm;
+    const double q0 = (TM[0][0] * pv0 + TM[0][1] * pv1 + TM[0][2] * pv2) / Ts;
+    const double q1 = (TM[1][0] * pv0 + TM[1][1] * pv1 + TM[1][2] * pv2) / Ts;
+    const double q2 = (TM[2][0] * pv0 + TM[2][1] * pv1 + TM[2][2] * pv2) / Ts;
+    const double u1 = pv2 * q0 * q0 - pv1 * q0 * q1 + pv0 * q1 * q1 + pv1 * pv1 * q2;
+    const double u2 = pv0 * pv2 * q2;
+    const double l1 = dsqrt(pv1 * pv1 + (pv0 - pv2) * (pv0 - pv2));
+    const double l2 = pv0 + pv2;
+    const double l3 = pv1 * pv1 - 4 * pv0 * pv2;
+    const double p1 = 2 * pv2 * q0 - pv1 * q1;
+    const double p2 = 2 * pv0 * q1 - pv1 * q0;
+    const double x0 = (p1 / l3 / scale) + cx;
+    const double y0 = (p2 / l3 / scale) + cy;
+    const double a = dsqrt(2.) * dsqrt((u1 - 4.0 * u2) / ((l1 - l2) * l3)) / scale;
+    const double b = dsqrt(2.) * dsqrt(-1.0 * ((u1 - 4.0 * u2) / ((l1 + l2) * l3))) / scale;
+    double theta;
+    if (pv1 == 0) theta = (pv0 < pv2) ? 0 : RMCV_PI / 2.;
+    else theta = RMCV_PI / 2. + 0.5 * pm_atan2(pv1, (pv0 - pv2));
+    box->cx = (float)x0;
+    box->cy = (float)y0;
+    box->w = (float)(2.0 * a);
+    box->h = (float)(2.0 * b);
+    if (box->w > box->h) {
+        float tmp = box->w;
+        box->w = box->h;
+        box->h = tmp;
+        box->angle = (float)(pm_fmod180(90 + theta * 180 / RMCV_PI));
+    } else {
+        box->angle = (float)(pm_fmod180(theta * 180 / RMCV_PI));
     }
-    if (iter < 2) {
-        double eval[3], ev[3][3], cond[3];
-        int i;
-        eigen_nonsymmetric3(M, eval, ev);
-        cond[0] = (4.0 * ev[0][0] * ev[0][2] - ev[0][1] * ev[0][1]);
-        cond[1] = (4.0 * ev[1][0] * ev[1][2] - ev[1][1] * ev[1][1]);
-        cond[2] = (4.0 * ev[2][0] * ev[2][2] - ev[2][1] * ev[2][1]);
-        if (cond[0] < cond[1]) i = (cond[1] < cond[2]) ? 2 : 1;
-        else i = (cond[0] < cond[2]) ? 2 : 0;
-        const double e0 = ev[i][0], e1 = ev[i][1], e2 = ev[i][2];
-        double norm = dsqrt(e0 * e0 + e1 * e1 + e2 * e2);
-        if (((e0 < 0.0 ? -1 : 1) * (e1 < 0.0 ? -1 : 1) * (e2 < 0.0 ? -1 : 1)) <= 0.0) norm = -1.0 * norm;
-        const double pv0 = e0 / norm, pv1 = e1 / norm, pv2 = e2 / norm;
-        const double q0 = (TM[0][0] * pv0 + TM[0][1] * pv1 + TM[0][2] * pv2) / Ts;
-        const double q1 = (TM[1][0] * pv0 + TM[1][1] * pv1 + TM[1][2] * pv2) / Ts;
-        const double q2 = (TM[2][0] * pv0 + TM[2][1] * pv1 + TM[2][2] * pv2) / Ts;
-        const double u1 = pv2 * q0 * q0 - pv1 * q0 * q1 + pv0 * q1 * q1 + pv1 * pv1 * q2;
-        const double u2 = pv0 * pv2 * q2;
-        const double l1 = dsqrt(pv1 * pv1 + (pv0 - pv2) * (pv0 - pv2));
-        const double l2 = pv0 + pv2;
-        const double l3 = pv1 * pv1 - 4 * pv0 * pv2;
-        const double p1 = 2 * pv2 * q0 - pv1 * q1;
-        const double p2 = 2 * pv0 * q1 - pv1 * q0;
-        const double x0 = (p1 / l3 / scale) + cx;
-        const double y0 = (p2 / l3 / scale) + cy;
-        const double a = dsqrt(2.) * dsqrt((u1 - 4.0 * u2) / ((l1 - l2) * l3)) / scale;
-        const double b = dsqrt(2.) * dsqrt(-1.0 * ((u1 - 4.0 * u2) / ((l1 + l2) * l3))) / scale;
-        double theta;
-        if (pv1 == 0) theta = (pv0 < pv2) ? 0 : RMCV_PI / 2.;
-        else theta = RMCV_PI / 2. + 0.5 * pm_atan2(pv1, (pv0 - pv2));
-        box->cx = (float)x0;
-        box->cy = (float)y0;
-        box->w = (float)(2.0 * a);
-        box->h = (float)(2.0 * b);
-        if (box->w > box->h) {
-            float tmp = box->w;
-            box->w = box->h;
-            box->h = tmp;
-            box->angle = (float)(pm_fmod180(90 + theta * 180 / RMCV_PI));
-        } else {
-            box->angle = (float)(pm_fmod180(theta * 180 / RMCV_PI));
-        }
-        if (is_good_box(box)) return 0;
-    }
-    fit_ellipse_general(pts, n, box);
-    return 1;
 }
 
 // ---- cv::RotatedRect::points, rm::lightblob (core.cpp:9-19, 265-283) ----------------------------

@@ -17,6 +17,8 @@
 // LAB/NEG, and re-scans only the rows the trace touched below the start.  Exact for every input.
 //
 // Output is kept in DISCOVERY order (cont_start/cont_len); findContours order is its reverse.
+#include <stdlib.h>
+
 #include "rmcv_internal.h"
 
 namespace rmcv {
@@ -150,24 +152,16 @@ __device__ int scan_row(const uint64_t* F, const uint64_t* LAB, const uint64_t* 
     return -1;
 }
 
-__global__ __launch_bounds__(64) void k_contours_literal(const uint64_t* __restrict__ bits, uint64_t* lab, uint64_t* neg, int w,
-                                                        int h, int ww, int prow, int64_t plane_pitch, rmcv_point* points,
-                                                        int32_t* cont_start, int32_t* cont_len, int32_t* n_contours,
-                                                        int32_t* n_points, int32_t* status, int max_contours, int max_points)
+// The literal scanner for one frame, run by ONE wavefront (lane = 0..63).  Exact for every input; it is the
+// fallback of k_contours for frames with nested components.  LAB/NEG must be zero on entry.
+__device__ void literal_frame(int lane, const uint64_t* F, uint64_t* LAB, uint64_t* NEG, int h, int ww, int prow, rmcv_point* pts,
+                              int32_t* cs, int32_t* cl, int max_contours, int max_points, int* nc_out, int* np_out, int* st_out)
 {
-    const int f = blockIdx.x, lane = threadIdx.x;
-    const uint64_t* F = bits + (int64_t)f * plane_pitch;
-    uint64_t* LAB = lab + (int64_t)f * plane_pitch;
-    uint64_t* NEG = neg + (int64_t)f * plane_pitch;
-    rmcv_point* pts = points + (int64_t)f * max_points;
-    int32_t* cs = cont_start + (int64_t)f * max_contours;
-    int32_t* cl = cont_len + (int64_t)f * max_contours;
     Tracer t;
     t.F32 = reinterpret_cast<const uint32_t*>(F);
     t.LAB = LAB;
     t.NEG = NEG;
     t.prow = prow;
-
     int nc = 0, np = 0, st = 0; // wave-uniform
     for (int band = 0; band * 64 < h; band++) {
         const int y = band * 64 + lane;
@@ -200,22 +194,358 @@ __global__ __launch_bounds__(64) void k_contours_literal(const uint64_t* __restr
             else if (lane > L && y <= ymax) dirty = true;
         }
     }
-    if (lane == 0) {
-        n_contours[f] = nc < max_contours ? nc : max_contours;
-        n_points[f] = np;
-        status[f] = st;
+    *nc_out = nc < max_contours ? nc : max_contours;
+    *np_out = np;
+    *st_out = st;
+}
+
+// ---- wave-cooperative border following ------------------------------------------------------------------
+// The 64 lanes of a wavefront hold a 64-row x 64-column window of F (lane i = row wy0+i) in registers; the walk
+// itself is wave-uniform scalar work that fetches the three rows it needs with v_readlane -- no memory access per
+// step.  Labels are ORed into two more per-lane registers and flushed with at most two L2 atomics per lane when
+// the walk leaves the window; points are parked one per lane and stored 64 at a time, coalesced.
+struct WWin {
+    uint64_t fw, lw, nw;
+    int xb, wy0;
+};
+
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ void wwin_load(WWin& W, const uint32_t* F32, int prow, int h, int x, int y, int lane)
+{
+    W.xb = ((x - 24) >> 5) * 32;
+    W.wy0 = y - 12;
+    const int r = W.wy0 + lane;
+    W.fw = (r >= -1 && r <= h) ? win_load(F32, prow, r, W.xb) : 0ull;
+    W.lw = 0;
+    W.nw = 0;
+}
+
+__device__ __forceinline__ void wwin_flush(WWin& W, uint64_t* LAB, uint64_t* NEG, int prow, int lane)
+{
+    if (W.lw) {
+        const int r = W.wy0 + lane;
+        const int sh = W.xb & 63; // 0 or 32
+        const int64_t idx = (int64_t)(r + 1) * prow + 1 + (W.xb >> 6);
+        const uint64_t llo = W.lw << sh, lhi = sh ? (W.lw >> (64 - sh)) : 0ull;
+        if (llo) atomicOr((unsigned long long*)(LAB + idx), (unsigned long long)llo);
+        if (lhi) atomicOr((unsigned long long*)(LAB + idx + 1), (unsigned long long)lhi);
+        const uint64_t nlo = W.nw << sh, nhi = sh ? (W.nw >> (64 - sh)) : 0ull;
+        if (nlo) atomicOr((unsigned long long*)(NEG + idx), (unsigned long long)nlo);
+        if (nhi) atomicOr((unsigned long long*)(NEG + idx + 1), (unsigned long long)nhi);
+    }
+    W.lw = 0;
+    W.nw = 0;
+}
+
+__device__ __forceinline__ uint32_t nbmask3(uint64_t r0, uint64_t r1, uint64_t r2, int sh)
+{
+    const uint32_t u = (uint32_t)(r0 >> sh) & 7u, m = (uint32_t)(r1 >> sh) & 7u, d = (uint32_t)(r2 >> sh) & 7u;
+    return ((m >> 2) & 1u) | (((u >> 2) & 1u) << 1) | (((u >> 1) & 1u) << 2) | ((u & 1u) << 3) | ((m & 1u) << 4) |
+           ((d & 1u) << 5) | (((d >> 1) & 1u) << 6) | (((d >> 2) & 1u) << 7);
+}
+
+// icvFetchContour by one wavefront.  emit_pts=false: count the points and find the raster-smallest pixel visited
+// (returned through *minkey).  emit_pts=true: also store the points at `out` and label the visited pixels.
+// The window must hold (x0,y0).  Everything except the per-lane window/label/parking registers is wave-uniform.
+__device__ int trace_wave(const bool emit_pts, WWin& W, const uint32_t* F32, uint64_t* LAB, uint64_t* NEG, int prow, int h,
+                          int x0, int y0, int lane, rmcv_point* out, uint32_t* minkey)
+{
+    int x = x0, y = y0, n = 0;
+    uint32_t mk = ((uint32_t)y0 << 16) | (uint32_t)x0;
+    int bx = 0, by = 0; // the point parked in this lane
+    int x1 = x0, y1 = y0;
+    bool single = false, first = true;
+    int s = 4;
+    for (;;) {
+        const int ly = y - W.wy0;
+        const uint32_t nb = nbmask3(rl64(W.fw, ly - 1), rl64(W.fw, ly), rl64(W.fw, ly + 1), x - W.xb - 1);
+        bool right_exit;
+        if (first) {
+            // clockwise search for the first neighbour, starting just past west: s = 3,2,1,0,7,6,5,(4)
+            do { s = (s - 1) & 7; } while (!((nb >> s) & 1u) && s != 4);
+            single = (s == 4);
+            x1 = x0 + ((s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0));
+            y1 = y0 + ((s >= 1 && s <= 3) ? -1 : ((s >= 5) ? 1 : 0));
+            first = false;
+        }
+        if (single) {
+            right_exit = true;
+        } else {
+            const int s_end = s;
+            const int k = (s_end + 1) & 7;
+            const uint32_t rot = ((nb | (nb << 8)) >> k) & 0xFFu;
+            s = (k + (__ffs((int)rot) - 1)) & 7; // counter-clockwise sweep to the first foreground neighbour
+            right_exit = (unsigned)(s - 1) < (unsigned)s_end;
+        }
+        // ---- visit (x, y)
+        if (emit_pts) {
+            if (lane == ly) {
+                const uint64_t bit = 1ull << (x - W.xb);
+                W.lw |= bit;
+                if (right_exit) W.nw |= bit;
+            }
+            if (lane == (n & 63)) { bx = x; by = y; }
+            if ((n & 63) == 63) {
+                rmcv_point p;
+                p.x = bx;
+                p.y = by;
+                out[n - 63 + lane] = p;
+            }
+        } else {
+            const uint32_t key = ((uint32_t)y << 16) | (uint32_t)x;
+            mk = key < mk ? key : mk;
+        }
+        n++;
+        if (single) break;
+        const int cx = x, cy = y;
+        x += (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0);
+        y += (s >= 1 && s <= 3) ? -1 : ((s >= 5) ? 1 : 0);
+        if (x == x0 && y == y0 && cx == x1 && cy == y1) break; // i4 == i0 && i3 == i1
+        if (n >= (1 << 22)) break; // cannot happen on a consistent plane; keeps a corrupted one from hanging the GPU
+        const int wx = x - W.xb, wy = y - W.wy0;
+        if (wx < 1 || wx > 62 || wy < 1 || wy > 62) {
+            if (emit_pts) wwin_flush(W, LAB, NEG, prow, lane);
+            wwin_load(W, F32, prow, h, x, y, lane);
+        }
+        s = (s + 4) & 7;
+    }
+    if (emit_pts) {
+        wwin_flush(W, LAB, NEG, prow, lane);
+        if (lane < (n & 63)) {
+            rmcv_point p;
+            p.x = bx;
+            p.y = by;
+            out[(n & ~63) + lane] = p;
+        }
+    }
+    *minkey = mk;
+    return n;
+}
+
+// ---- k_contours: one workgroup (4 wavefronts) per frame ---------------------------------------------------
+//  T  every thread scans rows for LOCAL TOPS (run starts whose run touches nothing in the row above): the
+//     raster-first pixel of every 8-connected component is one of them
+//  S  wavefronts pull tops from a queue and trace them speculatively; a trace whose raster-smallest pixel is its
+//     own start is the outer border of a component seen from its first pixel -> kept, traced again to store
+//     points + labels.  Traces are independent, so all components of a frame are followed concurrently.
+//  V  verification of OpenCV's RETR_EXTERNAL bookkeeping on the merged labels: every kept start must have been
+//     accepted (nearest labelled pixel to its left negative or absent) and every other unlabelled run start
+//     rejected.  True for frames without nested components; then discovery order = raster order of the starts.
+//  F  otherwise the frame is redone by the literal scanner (exact for every input).
+// LAB/NEG are zero between launches: whoever set labels clears them (labels only exist where F is set).
+static constexpr int CAND_CAP = 4096;
+static constexpr int KEPT_CAP = 2048;
+
+__device__ void clear_labels(int tid, const uint64_t* F, uint64_t* LAB, uint64_t* NEG, int h, int ww, int prow)
+{
+    for (int y = tid; y < h; y += 256) {
+        const int64_t base = (int64_t)(y + 1) * prow + 1;
+        for (int k = 0; k < ww; k++)
+            if (F[base + k]) { LAB[base + k] = 0; NEG[base + k] = 0; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ bits, uint64_t* lab, uint64_t* neg, int w, int h,
+                                                 int ww, int prow, int64_t plane_pitch, rmcv_point* points, int32_t* cont_start,
+                                                 int32_t* cont_len, int32_t* n_contours, int32_t* n_points, int32_t* status,
+                                                 int max_contours, int max_points, int force_literal)
+{
+    __shared__ uint32_t s_cand[CAND_CAP];
+    __shared__ uint32_t s_kkey[KEPT_CAP];
+    __shared__ int32_t s_koff[KEPT_CAP], s_klen[KEPT_CAP];
+    __shared__ int s_ncand, s_next, s_nkept, s_cursor, s_flags, s_lit[3];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t* F = bits + (int64_t)f * plane_pitch;
+    const uint32_t* F32 = reinterpret_cast<const uint32_t*>(F);
+    uint64_t* LAB = lab + (int64_t)f * plane_pitch;
+    uint64_t* NEG = neg + (int64_t)f * plane_pitch;
+    rmcv_point* pts = points + (int64_t)f * max_points;
+    int32_t* cs = cont_start + (int64_t)f * max_contours;
+    int32_t* cl = cont_len + (int64_t)f * max_contours;
+    enum { FL_COMPLEX = 1, FL_OVF_POINTS = 2, FL_OVF_CONTOURS = 4 };
+    if (tid == 0) { s_ncand = 0; s_next = 0; s_nkept = 0; s_cursor = 0; s_flags = force_literal ? FL_COMPLEX : 0; }
+    __syncthreads();
+
+    // ---------------- T: local tops
+    if (!force_literal)
+        for (int y = tid; y < h; y += 256) {
+            const int64_t base = (int64_t)(y + 1) * prow + 1, up = base - prow;
+            bool in_run = false, touched = false;
+            int run_x = 0;
+            for (int k = 0; k < ww; k++) {
+                const uint64_t fwd = F[base + k];
+                if (!fwd && !in_run) continue;
+                const uint64_t a = F[up + k];
+                const uint64_t ad = a | (a << 1) | (F[up + k - 1] >> 63) | (a >> 1) | (F[up + k + 1] << 63);
+                const uint64_t touch = fwd & ad;
+                uint64_t rem = fwd;
+                if (in_run) {
+                    const int lead = (~fwd) ? __ffsll((long long)~fwd) - 1 : 64;
+                    const uint64_t mask = lead == 64 ? ~0ull : ((1ull << lead) - 1);
+                    touched |= (touch & mask) != 0;
+                    if (lead == 64) continue;
+                    if (!touched) {
+                        const int i = atomicAdd(&s_ncand, 1);
+                        if (i < CAND_CAP) s_cand[i] = ((uint32_t)y << 16) | (uint32_t)run_x;
+                    }
+                    in_run = false;
+                    rem = fwd & ~mask;
+                }
+                while (rem) {
+                    const int st = __ffsll((long long)rem) - 1;
+                    const uint64_t t = rem >> st;
+                    const int len = (~t) ? __ffsll((long long)~t) - 1 : 64;
+                    const uint64_t mask = (len == 64 ? ~0ull : ((1ull << len) - 1)) << st;
+                    const bool tch = (touch & mask) != 0;
+                    if (st + len == 64) { in_run = true; touched = tch; run_x = k * 64 + st; break; }
+                    if (!tch) {
+                        const int i = atomicAdd(&s_ncand, 1);
+                        if (i < CAND_CAP) s_cand[i] = ((uint32_t)y << 16) | (uint32_t)(k * 64 + st);
+                    }
+                    rem &= ~mask;
+                }
+            }
+            if (in_run && !touched) {
+                const int i = atomicAdd(&s_ncand, 1);
+                if (i < CAND_CAP) s_cand[i] = ((uint32_t)y << 16) | (uint32_t)run_x;
+            }
+        }
+    __syncthreads();
+    const int ncand = s_ncand;
+    if (ncand > CAND_CAP && tid == 0) s_flags |= FL_COMPLEX;
+    __syncthreads();
+
+    // ---------------- S: speculative traces, one wavefront per candidate
+    if (!(s_flags & FL_COMPLEX)) {
+        WWin W;
+        for (;;) {
+            int i = 0;
+            if (lane == 0) i = atomicAdd(&s_next, 1);
+            i = __builtin_amdgcn_readfirstlane(i);
+            if (i >= ncand) break;
+            const uint32_t key0 = s_cand[i];
+            const int x0 = (int)(key0 & 0xFFFFu), y0 = (int)(key0 >> 16);
+            uint32_t mk = 0;
+            int len = 0, off = 0, slot = 0;
+            bool keep = true;
+            for (int pass = 0; pass < 2 && keep; pass++) { // pass 0: measure; pass 1: store points + labels
+                wwin_load(W, F32, prow, h, x0, y0, lane);
+                const int n = trace_wave(pass == 1, W, F32, LAB, NEG, prow, h, x0, y0, lane, pts + off, &mk);
+                if (pass == 0) {
+                    len = n;
+                    keep = (mk == key0); // else: not the first pixel of its component (or a hole border)
+                    if (keep) {
+                        if (lane == 0) {
+                            off = atomicAdd(&s_cursor, len);
+                            slot = atomicAdd(&s_nkept, 1);
+                        }
+                        off = __builtin_amdgcn_readfirstlane(off);
+                        slot = __builtin_amdgcn_readfirstlane(slot);
+                        if (slot >= KEPT_CAP || slot >= max_contours || off + len > max_points) {
+                            if (lane == 0) atomicOr(&s_flags, FL_COMPLEX); // let the literal path report the overflow exactly
+                            keep = false;
+                        }
+                    }
+                } else if (lane == 0) {
+                    s_kkey[slot] = key0;
+                    s_koff[slot] = off;
+                    s_klen[slot] = len;
+                }
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+
+    // ---------------- V: verification against the merged labels
+    const int nkept = s_nkept;
+    if (!(s_flags & FL_COMPLEX)) {
+        // V1: every kept start was acceptable: nearest labelled pixel to its left is negative, or there is none
+        for (int e = tid; e < nkept; e += 256) {
+            const uint32_t key = s_kkey[e];
+            const int x0 = (int)(key & 0xFFFFu), y0 = (int)(key >> 16);
+            const int64_t base = (int64_t)(y0 + 1) * prow + 1;
+            int k = x0 >> 6;
+            uint64_t l = ld_l2(LAB + base + k) & ((1ull << (x0 & 63)) - 1);
+            while (!l && k > 0) { k--; l = ld_l2(LAB + base + k); }
+            if (l) {
+                const int top = 63 - __clzll((long long)l);
+                if (!((ld_l2(NEG + base + k) >> top) & 1ull)) atomicOr(&s_flags, FL_COMPLEX);
+            }
+        }
+        // V2: every unlabelled run start would have been rejected
+        for (int y = tid; y < h; y += 256) {
+            const int64_t base = (int64_t)(y + 1) * prow + 1;
+            uint64_t carry = 0;
+            bool last_pos = false;
+            for (int k = 0; k < ww; k++) {
+                const uint64_t fwd = F[base + k];
+                if (!fwd) { carry = 0; continue; }
+                const uint64_t l = ld_l2(LAB + base + k), ng = ld_l2(NEG + base + k);
+                uint64_t cand = fwd & ~((fwd << 1) | carry) & ~l;
+                while (cand) {
+                    const int b = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const uint64_t below = l & ((1ull << b) - 1);
+                    const bool pos = below ? !((ng >> (63 - __clzll((long long)below))) & 1ull) : last_pos;
+                    if (!pos) atomicOr(&s_flags, FL_COMPLEX);
+                }
+                if (l) last_pos = !((ng >> (63 - __clzll((long long)l))) & 1ull);
+                carry = fwd >> 63;
+            }
+        }
+    }
+    __syncthreads();
+    const bool complex = (s_flags & FL_COMPLEX) != 0;
+    if (!force_literal) clear_labels(tid, F, LAB, NEG, h, ww, prow);
+    __threadfence();
+    __syncthreads();
+
+    if (complex) {
+        // ---------------- F: literal scanner (one wavefront), exact for nested components
+        if (wave == 0) {
+            int nc, np, st;
+            literal_frame(lane, F, LAB, NEG, h, ww, prow, pts, cs, cl, max_contours, max_points, &nc, &np, &st);
+            if (lane == 0) { s_lit[0] = nc; s_lit[1] = np; s_lit[2] = st; }
+        }
+        __threadfence();
+        __syncthreads();
+        clear_labels(tid, F, LAB, NEG, h, ww, prow);
+        if (tid == 0) {
+            n_contours[f] = s_lit[0];
+            n_points[f] = s_lit[1];
+            status[f] = s_lit[2] | RMCV_FRAME_SLOW_PATH;
+        }
+        return;
+    }
+
+    // discovery order = raster order of the starts: rank the kept entries by key
+    for (int e = tid; e < nkept; e += 256) {
+        const uint32_t key = s_kkey[e];
+        int rank = 0;
+        for (int j = 0; j < nkept; j++) rank += s_kkey[j] < key;
+        cs[rank] = s_koff[e];
+        cl[rank] = s_klen[e];
+    }
+    if (tid == 0) {
+        n_contours[f] = nkept;
+        n_points[f] = s_cursor;
+        status[f] = 0;
     }
 }
 
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)
 {
-    hipError_t e;
-    const size_t plane_bytes = (size_t)g.n_frames * g.plane_pitch * sizeof(uint64_t);
-    if ((e = hipMemsetAsync(b.lab, 0, plane_bytes, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(b.neg, 0, plane_bytes, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_contours_literal, dim3(g.n_frames), dim3(64), 0, s, b.bits, b.lab, b.neg, g.w, g.h, g.ww, g.prow,
-                       g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status, lim.max_contours,
-                       lim.max_points);
+    static const int force_literal = getenv("RMCV_CONTOURS_LITERAL") ? atoi(getenv("RMCV_CONTOURS_LITERAL")) : 0; // dev/test knob
+    hipLaunchKernelGGL(k_contours, dim3(g.n_frames), dim3(256), 0, s, b.bits, b.lab, b.neg, g.w, g.h, g.ww, g.prow, g.plane_pitch,
+                       b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status, lim.max_contours, lim.max_points,
+                       force_literal);
     return hipGetLastError();
 }
 

@@ -1,10 +1,9 @@
 // k_detect.hip -- rm::filter_lightblobs (/root/reference/src/objdetect.cpp:55-87) and
 // rm::filter_armours (/root/reference/src/objdetect.cpp:114-166) on the device.
 //
-// k_blobs:   one wavefront per frame; lane l takes contour 64*chunk + l (findContours order), runs the
-//            size/area gate, the ellipse fit and the ratio/tilt tests on its own contour (the moment sums
-//            are order dependent, so a contour is never split across lanes), then the wave compacts the
-//            positives / negatives IN ORDER with a ballot + prefix popcount.
+// k_fit:     one wavefront per contour (findContours order): size/area gate, ellipse fit, ratio/tilt tests.
+// k_blob_compact: one wavefront per frame appends the positives / negatives IN ORDER (ballot + prefix
+//            popcount) and builds the rm::lightblob PODs.
 // k_armours: one wavefront per frame; for each i the lanes test 64 partners j > i at once and append the
 //            accepted pairs in (i, j) lexicographic order, again by ballot + prefix popcount.
 #include "device_fit.h"
@@ -14,50 +13,276 @@ namespace rmcv {
 
 __device__ __forceinline__ int lanes_below(uint64_t m, int lane) { return __popcll(m & ((1ull << lane) - 1)); }
 
-__global__ __launch_bounds__(64) void k_blobs(const rmcv_point* __restrict__ points, const int32_t* __restrict__ cont_start,
-                                             const int32_t* __restrict__ cont_len, const int32_t* __restrict__ n_contours,
-                                             int max_contours, int max_points, float tilt_max, float ratio_lo, float ratio_hi,
-                                             double area_lo, double area_hi, int enemy, rmcv_lightblob* __restrict__ blobs,
-                                             int32_t* __restrict__ blob_src, rmcv_rrect* __restrict__ ellipses,
-                                             int32_t* __restrict__ neg_idx, int32_t* __restrict__ n_blobs,
-                                             int32_t* __restrict__ n_neg, int32_t* __restrict__ status, int max_blobs)
+// ---- wave-cooperative per-contour work ------------------------------------------------------------------
+// One wavefront owns one contour.  What is order dependent (the double-precision sums of scaled coordinates)
+// stays a strictly sequential chain in contour order, but the chains are independent of each other, so the 21
+// entries of the 6x6 scatter matrix (resp. 20 and 9 sums of the general fit) are accumulated by 21 different
+// lanes at once: per 64-point chunk every lane prepares the design-matrix row of ITS point (order independent)
+// in wave-private LDS, then lane e walks the 64 rows in order for ITS entry.  Integer-exact sums (shoelace area,
+// coordinate sums) are reduced in any order -- every partial sum is an exactly representable integer.
+struct WaveLds {
+    double rows[64][6];
+    double terms[64];
+    double dm[32];
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v)
 {
-    const int f = blockIdx.x, lane = threadIdx.x;
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// sequential sum, in point order, of one double per point (the per-point term is computed by the point's lane)
+template <typename F>
+__device__ __forceinline__ double seq_sum_terms(int n, int lane, WaveLds& L, F term)
+{
+    double s = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        if (i < n) L.terms[lane] = term(i);
+        __builtin_amdgcn_wave_barrier();
+        const int m = n - base < 64 ? n - base : 64;
+        for (int j = 0; j < m; j++) s += L.terms[j];
+        __builtin_amdgcn_wave_barrier();
+    }
+    return s;
+}
+
+// NR = row length, NS = number of sums; lane e < NS accumulates rows[j][la] * (lb < 0 ? konst : rows[j][lb])
+template <int NR, typename F>
+__device__ __forceinline__ double seq_sum_products(int n, int lane, WaveLds& L, int ns, int la, int lb, double konst, F make_row)
+{
+    double acc = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        if (i < n) {
+            double r[NR];
+            make_row(i, r);
+#pragma unroll
+            for (int k = 0; k < NR; k++) L.rows[lane][k] = r[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int m = n - base < 64 ? n - base : 64;
+        if (lane < ns) {
+            if (lb >= 0)
+                for (int j = 0; j < m; j++) acc += L.rows[j][la] * L.rows[j][lb];
+            else
+                for (int j = 0; j < m; j++) acc += L.rows[j][la] * konst;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return acc;
+}
+
+// upper-triangle index e -> (a, b), a <= b, row-major, for a k x k symmetric matrix
+__device__ __forceinline__ void tri_index(int e, int k, int* a, int* b)
+{
+    int r = 0, rem = e;
+    while (r < k && rem >= k - r) { rem -= k - r; r++; }
+    *a = r;
+    *b = r + rem;
+}
+
+// cv::fitEllipseDirect (objdetect.cpp:68) for one contour, by one wavefront.  sumx/sumy = integer coordinate sums.
+// returns 0 = direct solution, 1 = general fit.  All results are wave-uniform.
+__device__ int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n, long long sumx, long long sumy, WaveLds& L, int lane,
+                                rmcv_rrect* box)
+{
+    // ------------------------------------------------ direct (Fitzgibbon / Halir-Flusser)
+    {
+        const double cx = (double)sumx / n, cy = (double)sumy / n;
+        const double s = seq_sum_terms(n, lane, L, [&](int i) {
+            return dabs((float)pts[i].x - cx) + dabs((float)pts[i].y - cy);
+        });
+        const double scale = 100.0 / (s > FLT_EPSILON ? s : (double)FLT_EPSILON);
+        int la = 0, lb = 0;
+        tri_index(lane < 21 ? lane : 0, 6, &la, &lb);
+        double DM[6][6], TM[3][3], M[3][3], Ts = 0;
+        float eps = 0;
+        int iter;
+        for (iter = 0; iter < 2; iter++) {
+            const double acc = seq_sum_products<6>(n, lane, L, 21, la, lb, 0.0, [&](int i, double* r) {
+                float ox, oy;
+                get_ofs(i, eps, &ox, &oy);
+                const double px = (((float)pts[i].x + ox) - cx) * scale, py = (((float)pts[i].y + oy) - cy) * scale;
+                r[0] = px * px; r[1] = px * py; r[2] = py * py; r[3] = px; r[4] = py; r[5] = 1.0;
+            });
+            const double inv_n = 1.0 / n;
+            if (lane < 21) L.dm[lane] = acc * inv_n;
+            __builtin_amdgcn_wave_barrier();
+            {
+                int e = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = a; b < 6; b++, e++) DM[a][b] = DM[b][a] = L.dm[e];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double det = direct_reduce(DM, TM, &Ts, M);
+            if (dabs(det) > 1.0e-10) break;
+            eps = (float)(s / (n * 2) * 1e-2);
+        }
+        if (iter < 2) {
+            direct_finish(M, TM, Ts, scale, cx, cy, box);
+            if (is_good_box(box)) return 0;
+        }
+    }
+    // ------------------------------------------------ general conic fit (fallback)
+    {
+        float cx, cy;
+        if (sumx < (1ll << 24) && sumy < (1ll << 24)) { // float accumulation is exact below 2^24
+            cx = (float)sumx;
+            cy = (float)sumy;
+        } else {
+            cx = 0;
+            cy = 0;
+            for (int i = 0; i < n; i++) { cx += (float)pts[i].x; cy += (float)pts[i].y; }
+        }
+        cx /= (float)n;
+        cy /= (float)n;
+        const double s = seq_sum_terms(n, lane, L, [&](int i) {
+            const float px = (float)pts[i].x - cx, py = (float)pts[i].y - cy;
+            return dabs((double)px) + dabs((double)py);
+        });
+        const double scale = 100.0 / (s > FLT_EPSILON ? s : (double)FLT_EPSILON);
+        double gfp[5], rp[5] = {0, 0, 0, 0, 0};
+        float eps = 0.0f;
+        int la = 0, lb = 0;
+        if (lane < 15) tri_index(lane, 5, &la, &lb);
+        else { la = lane < 20 ? lane - 15 : 0; lb = -1; }
+        for (int iter = 0; iter < 2; iter++) {
+            const double acc = seq_sum_products<5>(n, lane, L, 20, la, lb, 10000.0, [&](int i, double* r) {
+                float ox = 0, oy = 0;
+                if (iter) get_ofs(i, eps, &ox, &oy);
+                const float fx = ((float)pts[i].x + ox) - cx, fy = ((float)pts[i].y + oy) - cy;
+                const double px = fx * scale, py = fy * scale;
+                r[0] = -px * px; r[1] = -py * py; r[2] = -px * py; r[3] = px; r[4] = py;
+            });
+            if (lane < 20) L.dm[lane] = acc;
+            __builtin_amdgcn_wave_barrier();
+            double G[25], g[5], wmax, wmin;
+            {
+                int e = 0;
+                for (int a = 0; a < 5; a++)
+                    for (int b = a; b < 5; b++, e++) G[a * 5 + b] = G[b * 5 + a] = L.dm[e];
+                for (int a = 0; a < 5; a++) g[a] = L.dm[15 + a];
+            }
+            __builtin_amdgcn_wave_barrier();
+            normal_solve(G, g, 5, gfp, &wmax, &wmin);
+            if (iter == 0 && wmax * FLT_EPSILON > wmin) {
+                eps = (float)(s / (n * 2) * 1e-3);
+                continue;
+            }
+            break;
+        }
+        general_centre(gfp, rp);
+        if (lane < 6) tri_index(lane, 3, &la, &lb);
+        else { la = lane < 9 ? lane - 6 : 0; lb = -1; }
+        const double r0 = rp[0], r1 = rp[1];
+        const double acc = seq_sum_products<3>(n, lane, L, 9, la, lb, 1.0, [&](int i, double* r) {
+            float ox = 0, oy = 0;
+            if (eps != 0.0f) get_ofs(i, eps, &ox, &oy);
+            const float fx = ((float)pts[i].x + ox) - cx, fy = ((float)pts[i].y + oy) - cy;
+            const double px = fx * scale, py = fy * scale;
+            r[0] = (px - r0) * (px - r0); r[1] = (py - r1) * (py - r1); r[2] = (px - r0) * (py - r1);
+        });
+        if (lane < 9) L.dm[lane] = acc;
+        __builtin_amdgcn_wave_barrier();
+        double G[9], g[3];
+        {
+            int e = 0;
+            for (int a = 0; a < 3; a++)
+                for (int b = a; b < 3; b++, e++) G[a * 3 + b] = G[b * 3 + a] = L.dm[e];
+            for (int a = 0; a < 3; a++) g[a] = L.dm[6 + a];
+        }
+        __builtin_amdgcn_wave_barrier();
+        normal_solve(G, g, 3, gfp, 0, 0);
+        general_finish(gfp, rp, scale, cx, cy, box);
+    }
+    return 1;
+}
+
+// kinds: 0 skipped, 1 positive, 2 negative.  grid (frames, FIT_CHUNKS), 4 wavefronts per block, one contour each.
+static constexpr int FIT_CHUNKS = 8;
+__global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ points, const int32_t* __restrict__ cont_start,
+                                            const int32_t* __restrict__ cont_len, const int32_t* __restrict__ n_contours,
+                                            int max_contours, int max_points, float tilt_max, float ratio_lo, float ratio_hi,
+                                            double area_lo, double area_hi, int32_t* __restrict__ slot_kind,
+                                            rmcv_rrect* __restrict__ slot_ell)
+{
+    __shared__ WaveLds lds[4];
+    const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WaveLds& L = lds[wave];
     const int n = n_contours[f];
     const rmcv_point* pts = points + (int64_t)f * max_points;
     const int32_t* cs = cont_start + (int64_t)f * max_contours;
     const int32_t* cl = cont_len + (int64_t)f * max_contours;
+    for (int c = blockIdx.y * 4 + wave; c < n; c += 4 * gridDim.y) { // c in findContours order; discovery index n-1-c
+        const int k = n - 1 - c;
+        const int start = cs[k], len = cl[k];
+        int kind = 0;
+        rmcv_rrect ell = {0, 0, 0, 0, 0};
+        if (len >= 6 && start + len <= max_points) { // objdetect.cpp:64
+            const rmcv_point* cp = pts + start;
+            // cv::contourArea + coordinate sums: integer-exact, any reduction order
+            double a00 = 0;
+            long long sx = 0, sy = 0;
+            for (int i = lane; i < len; i += 64) {
+                const rmcv_point p = cp[i], q = cp[i == 0 ? len - 1 : i - 1];
+                a00 += (double)(float)q.x * (float)p.y - (double)(float)q.y * (float)p.x;
+                sx += p.x;
+                sy += p.y;
+            }
+            a00 = wave_sum_f64(a00);
+            sx = wave_sum_i64(sx);
+            sy = wave_sum_i64(sy);
+            const double area = dabs(a00 * 0.5);
+            if (area >= area_lo && area <= area_hi) {
+                fit_ellipse_wave(cp, len, sx, sy, L, lane, &ell); // :68  (:69 minAreaRect is dead code in the reference)
+                bool negative = false;
+                const float mx = ell.w > ell.h ? ell.w : ell.h, mn = ell.w < ell.h ? ell.w : ell.h;
+                const float ratio = mx / mn; // :71-73
+                if (!(ratio >= ratio_lo && ratio <= ratio_hi)) negative = true;
+                const float angle = ell.angle > 90 ? ell.angle - 90 : ell.angle + 90; // :78
+                if (__builtin_fabsf(angle - 90) > tilt_max) negative = true;          // :79
+                kind = negative ? 2 : 1;
+            }
+        }
+        if (lane == 0) {
+            slot_kind[(int64_t)f * max_contours + c] = kind;
+            slot_ell[(int64_t)f * max_contours + c] = ell;
+        }
+    }
+}
+
+// ordered compaction of the per-contour results into the reference's `positive` / `negative` lists
+__global__ __launch_bounds__(64) void k_blob_compact(const int32_t* __restrict__ slot_kind, const rmcv_rrect* __restrict__ slot_ell,
+                                                    const int32_t* __restrict__ n_contours, int max_contours, int enemy,
+                                                    rmcv_lightblob* __restrict__ blobs, int32_t* __restrict__ blob_src,
+                                                    rmcv_rrect* __restrict__ ellipses, int32_t* __restrict__ neg_idx,
+                                                    int32_t* __restrict__ n_blobs, int32_t* __restrict__ n_neg,
+                                                    int32_t* __restrict__ status, int max_blobs)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int n = n_contours[f];
     rmcv_lightblob* ob = blobs + (int64_t)f * max_blobs;
     int32_t* osrc = blob_src + (int64_t)f * max_blobs;
     rmcv_rrect* oell = ellipses + (int64_t)f * max_blobs;
     int32_t* oneg = neg_idx + (int64_t)f * max_contours;
-    int np = 0, nn = 0, st = 0;
+    int np = 0, nn = 0;
     for (int base = 0; base < n; base += 64) {
-        const int c = base + lane; // findContours order; discovery index is n-1-c
-        int kind = 0;              // 0 skipped, 1 positive, 2 negative
-        rmcv_rrect ell;
-        if (c < n) {
-            const int k = n - 1 - c;
-            const int start = cs[k], len = cl[k];
-            if (len >= 6 && start + len <= max_points) { // objdetect.cpp:64
-                const rmcv_point* cp = pts + start;
-                const double area = contour_area(cp, len);
-                if (area >= area_lo && area <= area_hi) {
-                    fit_ellipse_direct(cp, len, &ell); // :68  (:69 minAreaRect is dead code in the reference)
-                    bool negative = false;
-                    const float mx = ell.w > ell.h ? ell.w : ell.h, mn = ell.w < ell.h ? ell.w : ell.h;
-                    const float ratio = mx / mn; // :71-73
-                    if (!(ratio >= ratio_lo && ratio <= ratio_hi)) negative = true;
-                    const float angle = ell.angle > 90 ? ell.angle - 90 : ell.angle + 90; // :78
-                    if (__builtin_fabsf(angle - 90) > tilt_max) negative = true;          // :79
-                    kind = negative ? 2 : 1;
-                }
-            }
-        }
+        const int c = base + lane;
+        const int kind = c < n ? slot_kind[(int64_t)f * max_contours + c] : 0;
         const uint64_t mp = __ballot(kind == 1), mn_ = __ballot(kind == 2);
         if (kind == 1) {
             const int o = np + lanes_below(mp, lane);
             if (o < max_blobs) {
+                const rmcv_rrect ell = slot_ell[(int64_t)f * max_contours + c];
                 make_lightblob(&ell, enemy, &ob[o]); // :83 -> core.cpp:9-19
                 osrc[o] = c;
                 oell[o] = ell;
@@ -68,11 +293,13 @@ __global__ __launch_bounds__(64) void k_blobs(const rmcv_point* __restrict__ poi
         np += __popcll(mp);
         nn += __popcll(mn_);
     }
-    if (np > max_blobs) { st |= RMCV_FRAME_OVF_BLOBS; np = max_blobs; }
     if (lane == 0) {
+        if (np > max_blobs) {
+            atomicOr(&status[f], RMCV_FRAME_OVF_BLOBS);
+            np = max_blobs;
+        }
         n_blobs[f] = np;
         n_neg[f] = nn;
-        if (st) atomicOr(&status[f], st);
     }
 }
 
@@ -189,9 +416,13 @@ hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& li
 
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_blobs, dim3(g.n_frames), dim3(64), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
-                       lim.max_contours, lim.max_points, p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi, p.camp,
-                       b.blobs, b.blob_src, b.ellipses, b.neg_idx, b.n_blobs, b.n_neg, b.status, lim.max_blobs);
+    hipLaunchKernelGGL(k_fit, dim3(g.n_frames, FIT_CHUNKS), dim3(256), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
+                       lim.max_contours, lim.max_points, p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi, b.slot_kind,
+                       b.slot_ell);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_blob_compact, dim3(g.n_frames), dim3(64), 0, s, b.slot_kind, b.slot_ell, b.n_contours, lim.max_contours,
+                       p.camp, b.blobs, b.blob_src, b.ellipses, b.neg_idx, b.n_blobs, b.n_neg, b.status, lim.max_blobs);
     return hipGetLastError();
 }
 

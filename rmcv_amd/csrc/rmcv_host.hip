@@ -147,6 +147,8 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.blob_src, F * d.max_blobs);
     if (e == hipSuccess) e = dalloc(c, &b.ellipses, F * d.max_blobs);
     if (e == hipSuccess) e = dalloc(c, &b.neg_idx, F * d.max_contours);
+    if (e == hipSuccess) e = dalloc(c, &b.slot_kind, F * d.max_contours);
+    if (e == hipSuccess) e = dalloc(c, &b.slot_ell, F * d.max_contours);
     if (e == hipSuccess) e = dalloc(c, &b.n_blobs, F);
     if (e == hipSuccess) e = dalloc(c, &b.n_neg, F);
     if (e == hipSuccess) e = dalloc(c, &b.armours, F * d.max_armours);
@@ -189,6 +191,8 @@ static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t
     if (c->geom_w != w || c->geom_h != h) {
         const size_t plane = (size_t)(c->lim.max_height + 2) * ((c->lim.max_width + 63) / 64 + 2);
         HIPCHK(c, hipMemsetAsync(c->bufs.bits, 0, (size_t)c->lim.max_frames * plane * 8, c->stream), "memset planes");
+        HIPCHK(c, hipMemsetAsync(c->bufs.lab, 0, (size_t)c->lim.max_frames * plane * 8, c->stream), "memset planes");
+        HIPCHK(c, hipMemsetAsync(c->bufs.neg, 0, (size_t)c->lim.max_frames * plane * 8, c->stream), "memset planes");
         HIPCHK(c, hipStreamSynchronize(c->stream), "memset planes");
         c->geom_w = w;
         c->geom_h = h;
