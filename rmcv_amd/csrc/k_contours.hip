@@ -127,12 +127,14 @@ __device__ int trace_border(Tracer& t, int x0, int y0, rmcv_point* out, int room
 }
 
 // first acceptable border-start candidate of row y at x >= xmin, or -1
-__device__ int scan_row(const uint64_t* F, const uint64_t* LAB, const uint64_t* NEG, int prow, int ww, int y, int xmin)
+__device__ int scan_row(const uint64_t* F, const uint64_t* LAB, const uint64_t* NEG, int prow, int ww, int y, int xmin,
+                        uint64_t occ)
 {
     const int64_t base = (int64_t)(y + 1) * prow + 1;
     uint64_t carry = 0;
     bool last_pos = false; // no labelled pixel yet -> lnbd is the zero frame column -> accept
     for (int k = 0; k < ww; k++) {
+        if (k < 64 && !((occ >> k) & 1ull)) { carry = 0; continue; }
         const uint64_t f = F[base + k];
         if (f == 0) { carry = 0; continue; }
         const uint64_t l = ld_l2(LAB + base + k), ng = ld_l2(NEG + base + k);
@@ -155,7 +157,8 @@ __device__ int scan_row(const uint64_t* F, const uint64_t* LAB, const uint64_t* 
 // The literal scanner for one frame, run by ONE wavefront (lane = 0..63).  Exact for every input; it is the
 // fallback of k_contours for frames with nested components.  LAB/NEG must be zero on entry.
 __device__ void literal_frame(int lane, const uint64_t* F, uint64_t* LAB, uint64_t* NEG, int h, int ww, int prow, rmcv_point* pts,
-                              int32_t* cs, int32_t* cl, int max_contours, int max_points, int* nc_out, int* np_out, int* st_out)
+                              int32_t* cs, int32_t* cl, int max_contours, int max_points, const uint32_t* rowmask,
+                              int* nc_out, int* np_out, int* st_out)
 {
     Tracer t;
     t.F32 = reinterpret_cast<const uint32_t*>(F);
@@ -165,11 +168,12 @@ __device__ void literal_frame(int lane, const uint64_t* F, uint64_t* LAB, uint64
     int nc = 0, np = 0, st = 0; // wave-uniform
     for (int band = 0; band * 64 < h; band++) {
         const int y = band * 64 + lane;
-        bool done = y >= h, dirty = true;
+        const uint64_t occ = (rowmask && y < h) ? (uint64_t)rowmask[y] : ~0ull;
+        bool done = y >= h || occ == 0, dirty = true;
         int xmin = 0, found = -1;
         for (;;) {
             if (dirty && !done) {
-                found = scan_row(F, LAB, NEG, prow, ww, y, xmin);
+                found = scan_row(F, LAB, NEG, prow, ww, y, xmin, occ);
                 dirty = false;
             }
             const uint64_t m = __ballot(!done && found >= 0);
@@ -202,10 +206,9 @@ __device__ void literal_frame(int lane, const uint64_t* F, uint64_t* LAB, uint64
 // ---- wave-cooperative border following ------------------------------------------------------------------
 // The 64 lanes of a wavefront hold a 64-row x 64-column window of F (lane i = row wy0+i) in registers; the walk
 // itself is wave-uniform scalar work that fetches the three rows it needs with v_readlane -- no memory access per
-// step.  Labels are ORed into two more per-lane registers and flushed with at most two L2 atomics per lane when
-// the walk leaves the window; points are parked one per lane and stored 64 at a time, coalesced.
+// step.  The window is re-centred (one load per lane) when the walk leaves it.
 struct WWin {
-    uint64_t fw, lw, nw;
+    uint64_t fw;
     int xb, wy0;
 };
 
@@ -222,25 +225,6 @@ __device__ __forceinline__ void wwin_load(WWin& W, const uint32_t* F32, int prow
     W.wy0 = y - 12;
     const int r = W.wy0 + lane;
     W.fw = (r >= -1 && r <= h) ? win_load(F32, prow, r, W.xb) : 0ull;
-    W.lw = 0;
-    W.nw = 0;
-}
-
-__device__ __forceinline__ void wwin_flush(WWin& W, uint64_t* LAB, uint64_t* NEG, int prow, int lane)
-{
-    if (W.lw) {
-        const int r = W.wy0 + lane;
-        const int sh = W.xb & 63; // 0 or 32
-        const int64_t idx = (int64_t)(r + 1) * prow + 1 + (W.xb >> 6);
-        const uint64_t llo = W.lw << sh, lhi = sh ? (W.lw >> (64 - sh)) : 0ull;
-        if (llo) atomicOr((unsigned long long*)(LAB + idx), (unsigned long long)llo);
-        if (lhi) atomicOr((unsigned long long*)(LAB + idx + 1), (unsigned long long)lhi);
-        const uint64_t nlo = W.nw << sh, nhi = sh ? (W.nw >> (64 - sh)) : 0ull;
-        if (nlo) atomicOr((unsigned long long*)(NEG + idx), (unsigned long long)nlo);
-        if (nhi) atomicOr((unsigned long long*)(NEG + idx + 1), (unsigned long long)nhi);
-    }
-    W.lw = 0;
-    W.nw = 0;
 }
 
 __device__ __forceinline__ uint32_t nbmask3(uint64_t r0, uint64_t r1, uint64_t r2, int sh)
@@ -250,82 +234,135 @@ __device__ __forceinline__ uint32_t nbmask3(uint64_t r0, uint64_t r1, uint64_t r
            ((d & 1u) << 5) | (((d >> 1) & 1u) << 6) | (((d >> 2) & 1u) << 7);
 }
 
-// icvFetchContour by one wavefront.  emit_pts=false: count the points and find the raster-smallest pixel visited
-// (returned through *minkey).  emit_pts=true: also store the points at `out` and label the visited pixels.
-// The window must hold (x0,y0).  Everything except the per-lane window/label/parking registers is wave-uniform.
-__device__ int trace_wave(const bool emit_pts, WWin& W, const uint32_t* F32, uint64_t* LAB, uint64_t* NEG, int prow, int h,
-                          int x0, int y0, int lane, rmcv_point* out, uint32_t* minkey)
+// ---- table-driven walk + parallel replay -----------------------------------------------------------------
+// One border-following step is a pure function of (direction back to the previous pixel, 3x3 neighbourhood):
+// a 4096-entry byte table in LDS, index = s_back<<9 | up<<6 | mid<<3 | down (each 3 bits: x-1, x, x+1), value =
+// s_new | right_exit<<3 | (dx+1)<<4 | (dy+1)<<6.  The walk records a 4-bit code per step in lane registers (lane
+// n>>5 holds steps 32*(n>>5)..+31), so a kept contour is not walked twice: the codes are replayed by all lanes in
+// parallel (prefix sum of the per-lane displacements) to write the points and the labels.
+static constexpr int CODE_CAP = 2048; // steps recorded per contour (64 lanes x 128 bits / 4); longer ones are re-walked
+
+__device__ __forceinline__ int dir_dx(int s) { return (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0); }
+__device__ __forceinline__ int dir_dy(int s) { return (s >= 1 && s <= 3) ? -1 : ((s >= 5) ? 1 : 0); }
+
+__device__ void lut_build(uint8_t* lut, int tid, int nthreads)
 {
-    int x = x0, y = y0, n = 0;
-    uint32_t mk = ((uint32_t)y0 << 16) | (uint32_t)x0;
-    int bx = 0, by = 0; // the point parked in this lane
-    int x1 = x0, y1 = y0;
-    bool single = false, first = true;
-    int s = 4;
-    for (;;) {
-        const int ly = y - W.wy0;
-        const uint32_t nb = nbmask3(rl64(W.fw, ly - 1), rl64(W.fw, ly), rl64(W.fw, ly + 1), x - W.xb - 1);
-        bool right_exit;
-        if (first) {
-            // clockwise search for the first neighbour, starting just past west: s = 3,2,1,0,7,6,5,(4)
-            do { s = (s - 1) & 7; } while (!((nb >> s) & 1u) && s != 4);
-            single = (s == 4);
-            x1 = x0 + ((s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0));
-            y1 = y0 + ((s >= 1 && s <= 3) ? -1 : ((s >= 5) ? 1 : 0));
-            first = false;
-        }
-        if (single) {
-            right_exit = true;
-        } else {
-            const int s_end = s;
+    for (int idx = tid; idx < 4096; idx += nthreads) {
+        const int s_end = idx >> 9;
+        const uint32_t u = (idx >> 6) & 7, m = (idx >> 3) & 7, d = idx & 7;
+        const uint32_t nb = ((m >> 2) & 1u) | (((u >> 2) & 1u) << 1) | (((u >> 1) & 1u) << 2) | ((u & 1u) << 3) | ((m & 1u) << 4) |
+                            ((d & 1u) << 5) | (((d >> 1) & 1u) << 6) | (((d >> 2) & 1u) << 7);
+        uint8_t e = 0;
+        if (nb) {
             const int k = (s_end + 1) & 7;
             const uint32_t rot = ((nb | (nb << 8)) >> k) & 0xFFu;
-            s = (k + (__ffs((int)rot) - 1)) & 7; // counter-clockwise sweep to the first foreground neighbour
-            right_exit = (unsigned)(s - 1) < (unsigned)s_end;
+            const int sn = (k + (__ffs((int)rot) - 1)) & 7;
+            const int rex = ((unsigned)(sn - 1) < (unsigned)s_end) ? 1 : 0;
+            e = (uint8_t)(sn | (rex << 3) | ((dir_dx(sn) + 1) << 4) | ((dir_dy(sn) + 1) << 6));
         }
-        // ---- visit (x, y)
-        if (emit_pts) {
-            if (lane == ly) {
-                const uint64_t bit = 1ull << (x - W.xb);
-                W.lw |= bit;
-                if (right_exit) W.nw |= bit;
-            }
-            if (lane == (n & 63)) { bx = x; by = y; }
-            if ((n & 63) == 63) {
-                rmcv_point p;
-                p.x = bx;
-                p.y = by;
-                out[n - 63 + lane] = p;
-            }
-        } else {
-            const uint32_t key = ((uint32_t)y << 16) | (uint32_t)x;
-            mk = key < mk ? key : mk;
+        lut[idx] = e;
+    }
+}
+
+// Walk the border from (x0,y0) without writing anything to memory.  Returns the number of points; *state:
+// 0 = complete, 1 = single pixel, 2 = aborted (a raster-earlier pixel was met: (x0,y0) is not a first pixel).
+__device__ int walk_record(WWin& W, const uint32_t* F32, int prow, int h, int x0, int y0, int lane, const uint8_t* lut,
+                           int* state, uint64_t* c0_out, uint64_t* c1_out)
+{
+    const uint32_t key0 = ((uint32_t)y0 << 16) | (uint32_t)x0;
+    int x = x0, y = y0, n = 0;
+    uint64_t c0 = 0, c1 = 0;
+    *state = 0;
+    int s_back;
+    int x1, y1;
+    {
+        const int ly = y - W.wy0;
+        const uint32_t nb = nbmask3(rl64(W.fw, ly - 1), rl64(W.fw, ly), rl64(W.fw, ly + 1), x - W.xb - 1);
+        int s = 4;
+        do { s = (s - 1) & 7; } while (!((nb >> s) & 1u) && s != 4);
+        if (s == 4) { // single pixel: one step, no move, negative label (icvFetchContour's isolated-pixel case)
+            *state = 1;
+            *c0_out = (lane == 0) ? 8ull : 0ull;
+            *c1_out = 0;
+            return 1;
+        }
+        x1 = x0 + dir_dx(s);
+        y1 = y0 + dir_dy(s);
+        s_back = s;
+    }
+    for (;;) {
+        const int ly = y - W.wy0, sh = x - W.xb - 1;
+        const uint32_t u = (uint32_t)(rl64(W.fw, ly - 1) >> sh) & 7u, m = (uint32_t)(rl64(W.fw, ly) >> sh) & 7u,
+                       d = (uint32_t)(rl64(W.fw, ly + 1) >> sh) & 7u;
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lut[(s_back << 9) | (u << 6) | (m << 3) | d]);
+        if ((((uint32_t)y << 16) | (uint32_t)x) < key0) { *state = 2; break; }
+        { // record the step in the lane that owns it -- branch-free (selects, no EXEC change in the hot loop)
+            const uint64_t code = (uint64_t)(e & 15u) << ((n & 15) * 4);
+            const bool mine = (lane == (n >> 5)) && (n < CODE_CAP);
+            c0 |= (mine && !(n & 16)) ? code : 0ull;
+            c1 |= (mine && (n & 16)) ? code : 0ull;
         }
         n++;
-        if (single) break;
         const int cx = x, cy = y;
-        x += (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0);
-        y += (s >= 1 && s <= 3) ? -1 : ((s >= 5) ? 1 : 0);
+        x += (int)((e >> 4) & 3u) - 1;
+        y += (int)((e >> 6) & 3u) - 1;
         if (x == x0 && y == y0 && cx == x1 && cy == y1) break; // i4 == i0 && i3 == i1
-        if (n >= (1 << 22)) break; // cannot happen on a consistent plane; keeps a corrupted one from hanging the GPU
+        if (n >= (1 << 22)) break;                             // cannot happen on a consistent plane
         const int wx = x - W.xb, wy = y - W.wy0;
-        if (wx < 1 || wx > 62 || wy < 1 || wy > 62) {
-            if (emit_pts) wwin_flush(W, LAB, NEG, prow, lane);
-            wwin_load(W, F32, prow, h, x, y, lane);
-        }
-        s = (s + 4) & 7;
+        if (wx < 1 || wx > 62 || wy < 1 || wy > 62) wwin_load(W, F32, prow, h, x, y, lane);
+        s_back = ((int)(e & 7u) + 4) & 7;
     }
-    if (emit_pts) {
-        wwin_flush(W, LAB, NEG, prow, lane);
-        if (lane < (n & 63)) {
-            rmcv_point p;
-            p.x = bx;
-            p.y = by;
-            out[(n & ~63) + lane] = p;
-        }
-    }
-    *minkey = mk;
+    *c0_out = c0;
+    *c1_out = c1;
     return n;
+}
+
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int lane)
+{
+    int inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    return inc - v;
+}
+
+// all lanes replay their 32 recorded steps: points -> out[0..n), labels -> LAB/NEG (n <= CODE_CAP)
+__device__ void replay_emit(int n, int x0, int y0, int lane, uint64_t c0, uint64_t c1, rmcv_point* out, uint64_t* LAB,
+                            uint64_t* NEG, int prow)
+{
+    int cnt = n - 32 * lane;
+    cnt = cnt < 0 ? 0 : (cnt > 32 ? 32 : cnt);
+    int dx = 0, dy = 0;
+    for (int j = 0; j < cnt; j++) {
+        const int sdir = (int)(((j < 16 ? c0 >> (4 * j) : c1 >> (4 * (j - 16)))) & 7u);
+        dx += dir_dx(sdir);
+        dy += dir_dy(sdir);
+    }
+    int x = x0 + wave_excl_scan_i32(dx, lane), y = y0 + wave_excl_scan_i32(dy, lane);
+    int64_t pidx = -1; // pending label word
+    uint64_t plab = 0, pneg = 0;
+    for (int j = 0; j < cnt; j++) {
+        const uint32_t code = (uint32_t)((j < 16 ? c0 >> (4 * j) : c1 >> (4 * (j - 16)))) & 15u;
+        rmcv_point p;
+        p.x = x;
+        p.y = y;
+        out[32 * lane + j] = p;
+        const int64_t idx = (int64_t)(y + 1) * prow + 1 + (x >> 6);
+        if (idx != pidx) {
+            if (plab) atomicOr((unsigned long long*)(LAB + pidx), (unsigned long long)plab);
+            if (pneg) atomicOr((unsigned long long*)(NEG + pidx), (unsigned long long)pneg);
+            pidx = idx;
+            plab = 0;
+            pneg = 0;
+        }
+        plab |= 1ull << (x & 63);
+        if (code & 8u) pneg |= 1ull << (x & 63);
+        x += dir_dx((int)(code & 7u));
+        y += dir_dy((int)(code & 7u));
+    }
+    if (plab) atomicOr((unsigned long long*)(LAB + pidx), (unsigned long long)plab);
+    if (pneg) atomicOr((unsigned long long*)(NEG + pidx), (unsigned long long)pneg);
 }
 
 // ---- k_contours: one workgroup (4 wavefronts) per frame ---------------------------------------------------
@@ -341,17 +378,27 @@ __device__ int trace_wave(const bool emit_pts, WWin& W, const uint32_t* F32, uin
 // LAB/NEG are zero between launches: whoever set labels clears them (labels only exist where F is set).
 static constexpr int CAND_CAP = 4096;
 static constexpr int KEPT_CAP = 2048;
+static constexpr int CT_THREADS = 512; // 8 wavefronts: the bars of a frame are traced concurrently
+static constexpr int CT_MAXH = 2048;   // rows covered by the LDS row summary (taller/wider frames take the literal path)
 
-__device__ void clear_labels(int tid, const uint64_t* F, uint64_t* LAB, uint64_t* NEG, int h, int ww, int prow)
+// labels only exist where F is set: clear LAB/NEG on the non-empty words of the non-empty rows
+__device__ void clear_labels(int tid, uint64_t* LAB, uint64_t* NEG, int prow, const uint32_t* rowmask, const uint16_t* rows,
+                             int nrows)
 {
-    for (int y = tid; y < h; y += 256) {
+    for (int r = tid; r < nrows; r += CT_THREADS) {
+        const int y = rows[r];
         const int64_t base = (int64_t)(y + 1) * prow + 1;
-        for (int k = 0; k < ww; k++)
-            if (F[base + k]) { LAB[base + k] = 0; NEG[base + k] = 0; }
+        uint32_t m = rowmask[y];
+        while (m) {
+            const int k = __ffs((int)m) - 1;
+            m &= m - 1;
+            LAB[base + k] = 0;
+            NEG[base + k] = 0;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ bits, uint64_t* lab, uint64_t* neg, int w, int h,
+__global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restrict__ bits, uint64_t* lab, uint64_t* neg, int w, int h,
                                                  int ww, int prow, int64_t plane_pitch, rmcv_point* points, int32_t* cont_start,
                                                  int32_t* cont_len, int32_t* n_contours, int32_t* n_points, int32_t* status,
                                                  int max_contours, int max_points, int force_literal)
@@ -359,7 +406,10 @@ __global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ b
     __shared__ uint32_t s_cand[CAND_CAP];
     __shared__ uint32_t s_kkey[KEPT_CAP];
     __shared__ int32_t s_koff[KEPT_CAP], s_klen[KEPT_CAP];
-    __shared__ int s_ncand, s_next, s_nkept, s_cursor, s_flags, s_lit[3];
+    __shared__ uint8_t s_lut[4096];         // border-following step table (lut_build)
+    __shared__ uint32_t s_rowmask[CT_MAXH]; // bit k: word k of the row is non-zero
+    __shared__ uint16_t s_rows[CT_MAXH];    // the non-empty rows (any order)
+    __shared__ int s_ncand, s_next, s_nkept, s_cursor, s_flags, s_nrows, s_lit[3];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t* F = bits + (int64_t)f * plane_pitch;
     const uint32_t* F32 = reinterpret_cast<const uint32_t*>(F);
@@ -369,20 +419,63 @@ __global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ b
     int32_t* cs = cont_start + (int64_t)f * max_contours;
     int32_t* cl = cont_len + (int64_t)f * max_contours;
     enum { FL_COMPLEX = 1, FL_OVF_POINTS = 2, FL_OVF_CONTOURS = 4 };
-    if (tid == 0) { s_ncand = 0; s_next = 0; s_nkept = 0; s_cursor = 0; s_flags = force_literal ? FL_COMPLEX : 0; }
+#ifdef RMCV_PROFILE
+    long long t_[8]; int ti_ = 0;
+#define STAMP() do { __syncthreads(); t_[ti_++] = wall_clock64(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+    STAMP();
+    const bool summarised = (h <= CT_MAXH && ww <= 32);
+    if (tid == 0) {
+        s_ncand = 0; s_next = 0; s_nkept = 0; s_cursor = 0; s_nrows = 0;
+        s_flags = (force_literal || !summarised) ? FL_COMPLEX : 0;
+    }
+    if (summarised)
+        for (int y = tid; y < h; y += CT_THREADS) s_rowmask[y] = 0;
+    lut_build(s_lut, tid, CT_THREADS);
     __syncthreads();
+    // ---------------- row summary: one coalesced, fully pipelined sweep over the bit plane
+    if (summarised) {
+        const int total = h * ww;
+        for (int i0 = tid; i0 < total; i0 += 4 * CT_THREADS) {
+            uint64_t v[4];
+            int yy[4], kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * CT_THREADS;
+                yy[u] = i / ww;
+                kk[u] = i - yy[u] * ww;
+                v[u] = i < total ? F[(int64_t)(yy[u] + 1) * prow + 1 + kk[u]] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (v[u]) atomicOr(&s_rowmask[yy[u]], 1u << kk[u]);
+        }
+        __syncthreads();
+        for (int y = tid; y < h; y += CT_THREADS)
+            if (s_rowmask[y]) s_rows[atomicAdd(&s_nrows, 1)] = (uint16_t)y;
+        __syncthreads();
+    }
+    const int nrows = s_nrows;
+    STAMP();
 
     // ---------------- T: local tops
-    if (!force_literal)
-        for (int y = tid; y < h; y += 256) {
+    if (!(s_flags & FL_COMPLEX))
+        for (int r = tid; r < nrows; r += CT_THREADS) {
+            const int y = s_rows[r];
             const int64_t base = (int64_t)(y + 1) * prow + 1, up = base - prow;
+            const uint32_t occ = s_rowmask[y], occ_up = y > 0 ? s_rowmask[y - 1] : 0u;
             bool in_run = false, touched = false;
             int run_x = 0;
             for (int k = 0; k < ww; k++) {
-                const uint64_t fwd = F[base + k];
+                const uint64_t fwd = ((occ >> k) & 1u) ? F[base + k] : 0ull;
                 if (!fwd && !in_run) continue;
-                const uint64_t a = F[up + k];
-                const uint64_t ad = a | (a << 1) | (F[up + k - 1] >> 63) | (a >> 1) | (F[up + k + 1] << 63);
+                uint64_t ad = 0;
+                if ((occ_up >> (k > 0 ? k - 1 : 0)) & (k > 0 ? 7u : 3u)) { // anything above in words k-1..k+1
+                    const uint64_t a = F[up + k];
+                    ad = a | (a << 1) | (F[up + k - 1] >> 63) | (a >> 1) | (F[up + k + 1] << 63);
+                }
                 const uint64_t touch = fwd & ad;
                 uint64_t rem = fwd;
                 if (in_run) {
@@ -417,6 +510,7 @@ __global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ b
             }
         }
     __syncthreads();
+    STAMP();
     const int ncand = s_ncand;
     if (ncand > CAND_CAP && tid == 0) s_flags |= FL_COMPLEX;
     __syncthreads();
@@ -425,49 +519,39 @@ __global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ b
     if (!(s_flags & FL_COMPLEX)) {
         WWin W;
         for (;;) {
-            int i = 0;
-            if (lane == 0) i = atomicAdd(&s_next, 1);
-            i = __builtin_amdgcn_readfirstlane(i);
+            // every lane issues the LDS atomic (lanes != 0 add 0), so the loop control stays wave-uniform
+            const int i = __builtin_amdgcn_readfirstlane(atomicAdd(&s_next, lane == 0 ? 1 : 0));
             if (i >= ncand) break;
             const uint32_t key0 = s_cand[i];
             const int x0 = (int)(key0 & 0xFFFFu), y0 = (int)(key0 >> 16);
-            uint32_t mk = 0;
-            int len = 0, off = 0, slot = 0;
-            bool keep = true;
-            for (int pass = 0; pass < 2 && keep; pass++) { // pass 0: measure; pass 1: store points + labels
-                wwin_load(W, F32, prow, h, x0, y0, lane);
-                const int n = trace_wave(pass == 1, W, F32, LAB, NEG, prow, h, x0, y0, lane, pts + off, &mk);
-                if (pass == 0) {
-                    len = n;
-                    keep = (mk == key0); // else: not the first pixel of its component (or a hole border)
-                    if (keep) {
-                        if (lane == 0) {
-                            off = atomicAdd(&s_cursor, len);
-                            slot = atomicAdd(&s_nkept, 1);
-                        }
-                        off = __builtin_amdgcn_readfirstlane(off);
-                        slot = __builtin_amdgcn_readfirstlane(slot);
-                        if (slot >= KEPT_CAP || slot >= max_contours || off + len > max_points) {
-                            if (lane == 0) atomicOr(&s_flags, FL_COMPLEX); // let the literal path report the overflow exactly
-                            keep = false;
-                        }
-                    }
-                } else if (lane == 0) {
-                    s_kkey[slot] = key0;
-                    s_koff[slot] = off;
-                    s_klen[slot] = len;
-                }
+            int state = 0;
+            uint64_t c0 = 0, c1 = 0;
+            wwin_load(W, F32, prow, h, x0, y0, lane);
+            const int len = walk_record(W, F32, prow, h, x0, y0, lane, s_lut, &state, &c0, &c1);
+            if (state == 2) continue; // not the first pixel of its component (or a hole border)
+            const int off = __builtin_amdgcn_readfirstlane(atomicAdd(&s_cursor, lane == 0 ? len : 0));
+            const int slot = __builtin_amdgcn_readfirstlane(atomicAdd(&s_nkept, lane == 0 ? 1 : 0));
+            if (slot >= KEPT_CAP || slot >= max_contours || off + len > max_points || len > CODE_CAP) {
+                // capacity, or a contour longer than the code registers (> 2048 points): the literal scanner
+                // redoes the frame and reports an overflow exactly
+                atomicOr(&s_flags, FL_COMPLEX);
+                continue;
             }
+            replay_emit(len, x0, y0, lane, c0, c1, pts + off, LAB, NEG, prow);
+            s_kkey[slot] = key0; // same value from every lane
+            s_koff[slot] = off;
+            s_klen[slot] = len;
         }
     }
     __threadfence();
     __syncthreads();
+    STAMP();
 
     // ---------------- V: verification against the merged labels
     const int nkept = s_nkept;
     if (!(s_flags & FL_COMPLEX)) {
         // V1: every kept start was acceptable: nearest labelled pixel to its left is negative, or there is none
-        for (int e = tid; e < nkept; e += 256) {
+        for (int e = tid; e < nkept; e += CT_THREADS) {
             const uint32_t key = s_kkey[e];
             const int x0 = (int)(key & 0xFFFFu), y0 = (int)(key >> 16);
             const int64_t base = (int64_t)(y0 + 1) * prow + 1;
@@ -480,13 +564,15 @@ __global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ b
             }
         }
         // V2: every unlabelled run start would have been rejected
-        for (int y = tid; y < h; y += 256) {
+        for (int r = tid; r < nrows; r += CT_THREADS) {
+            const int y = s_rows[r];
             const int64_t base = (int64_t)(y + 1) * prow + 1;
+            const uint32_t occ = s_rowmask[y];
             uint64_t carry = 0;
             bool last_pos = false;
             for (int k = 0; k < ww; k++) {
+                if (!((occ >> k) & 1u)) { carry = 0; continue; }
                 const uint64_t fwd = F[base + k];
-                if (!fwd) { carry = 0; continue; }
                 const uint64_t l = ld_l2(LAB + base + k), ng = ld_l2(NEG + base + k);
                 uint64_t cand = fwd & ~((fwd << 1) | carry) & ~l;
                 while (cand) {
@@ -502,8 +588,9 @@ __global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ b
         }
     }
     __syncthreads();
+    STAMP();
     const bool complex = (s_flags & FL_COMPLEX) != 0;
-    if (!force_literal) clear_labels(tid, F, LAB, NEG, h, ww, prow);
+    if (summarised && !force_literal) clear_labels(tid, LAB, NEG, prow, s_rowmask, s_rows, nrows);
     __threadfence();
     __syncthreads();
 
@@ -511,12 +598,21 @@ __global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ b
         // ---------------- F: literal scanner (one wavefront), exact for nested components
         if (wave == 0) {
             int nc, np, st;
-            literal_frame(lane, F, LAB, NEG, h, ww, prow, pts, cs, cl, max_contours, max_points, &nc, &np, &st);
+            literal_frame(lane, F, LAB, NEG, h, ww, prow, pts, cs, cl, max_contours, max_points,
+                          summarised ? s_rowmask : nullptr, &nc, &np, &st);
             if (lane == 0) { s_lit[0] = nc; s_lit[1] = np; s_lit[2] = st; }
         }
         __threadfence();
         __syncthreads();
-        clear_labels(tid, F, LAB, NEG, h, ww, prow);
+        if (summarised) {
+            clear_labels(tid, LAB, NEG, prow, s_rowmask, s_rows, nrows);
+        } else { // no summary: sweep every word
+            for (int y = tid; y < h; y += CT_THREADS) {
+                const int64_t base = (int64_t)(y + 1) * prow + 1;
+                for (int k = 0; k < ww; k++)
+                    if (F[base + k]) { LAB[base + k] = 0; NEG[base + k] = 0; }
+            }
+        }
         if (tid == 0) {
             n_contours[f] = s_lit[0];
             n_points[f] = s_lit[1];
@@ -525,8 +621,15 @@ __global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ b
         return;
     }
 
+    STAMP();
+#ifdef RMCV_PROFILE
+    if (tid == 0 && (f == 0 || f == 100))
+        printf("[f%d] rows=%d cand=%d kept=%d pts=%d | summary %.1f T %.1f S %.1f V %.1f clear %.1f us\n", f, nrows, ncand, nkept,
+               s_cursor, (t_[1] - t_[0]) / 100.0, (t_[2] - t_[1]) / 100.0, (t_[3] - t_[2]) / 100.0, (t_[4] - t_[3]) / 100.0,
+               (t_[5] - t_[4]) / 100.0);
+#endif
     // discovery order = raster order of the starts: rank the kept entries by key
-    for (int e = tid; e < nkept; e += 256) {
+    for (int e = tid; e < nkept; e += CT_THREADS) {
         const uint32_t key = s_kkey[e];
         int rank = 0;
         for (int j = 0; j < nkept; j++) rank += s_kkey[j] < key;
@@ -543,7 +646,7 @@ __global__ __launch_bounds__(256) void k_contours(const uint64_t* __restrict__ b
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)
 {
     static const int force_literal = getenv("RMCV_CONTOURS_LITERAL") ? atoi(getenv("RMCV_CONTOURS_LITERAL")) : 0; // dev/test knob
-    hipLaunchKernelGGL(k_contours, dim3(g.n_frames), dim3(256), 0, s, b.bits, b.lab, b.neg, g.w, g.h, g.ww, g.prow, g.plane_pitch,
+    hipLaunchKernelGGL(k_contours, dim3(g.n_frames), dim3(CT_THREADS), 0, s, b.bits, b.lab, b.neg, g.w, g.h, g.ww, g.prow, g.plane_pitch,
                        b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status, lim.max_contours, lim.max_points,
                        force_literal);
     return hipGetLastError();
