@@ -22,6 +22,47 @@ namespace rmcv {
 __device__ __forceinline__ double dabs(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ double dsqrt(double x) { return ::sqrt(x); }
 
+// ---- lane-resident small arrays -----------------------------------------------------------------
+// The scalar tails below (3x3 eigen-solver, 5x5 Jacobi) index small matrices with run-time subscripts.  As
+// thread-private arrays those would live in scratch memory (hundreds of cycles per access).  Every lane of the
+// wavefront executes the tail redundantly with identical values, so the arrays are kept "across the lanes" of ONE
+// register instead: element i lives in lane i; a read is a v_readlane pair (the subscript is wave-uniform), a
+// write is a select.  The proxy types keep the algorithm text identical to the CPU restatement.
+__device__ __forceinline__ double lane_get(double reg, int idx)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(reg);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, idx);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), idx);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+struct LaneRef {
+    double* reg;
+    int idx, lane;
+    __device__ __forceinline__ operator double() const { return lane_get(*reg, idx); }
+    __device__ __forceinline__ LaneRef& operator=(double v) { *reg = (lane == idx) ? v : *reg; return *this; }
+    __device__ __forceinline__ LaneRef& operator=(const LaneRef& o) { return *this = (double)o; }
+    __device__ __forceinline__ LaneRef& operator+=(double v) { return *this = (double)*this + v; }
+    __device__ __forceinline__ LaneRef& operator-=(double v) { return *this = (double)*this - v; }
+};
+struct LaneVec { // up to 64 doubles
+    double reg;
+    int lane;
+    __device__ __forceinline__ explicit LaneVec(int l) : reg(0.0), lane(l) {}
+    __device__ __forceinline__ LaneRef operator[](int i) { return LaneRef{&reg, i, lane}; }
+    __device__ __forceinline__ double get(int i) const { return lane_get(reg, i); }
+};
+struct LaneRow {
+    double* reg;
+    int base, lane;
+    __device__ __forceinline__ LaneRef operator[](int j) { return LaneRef{reg, base + j, lane}; }
+};
+struct LaneMat3 { // 3 x 3, row-major in lanes 0..8
+    double reg;
+    int lane;
+    __device__ __forceinline__ explicit LaneMat3(int l) : reg(0.0), lane(l) {}
+    __device__ __forceinline__ LaneRow operator[](int i) { return LaneRow{&reg, 3 * i, lane}; }
+};
+
 // ---- 3x3 real non-symmetric eigen-solver: JAMA orthes + hqr2 (cv::eigenNonSymmetric) -------------
 __device__ inline void cdiv_(double xr, double xi, double yr, double yi, double* cr, double* ci)
 {
@@ -39,9 +80,9 @@ __device__ inline void cdiv_(double xr, double xi, double yr, double yi, double*
     }
 }
 
-__device__ inline void eig_orthes(double H[3][3], double V[3][3])
+__device__ inline void eig_orthes(LaneMat3& H, LaneMat3& V, int lane)
 {
-    double ort[3] = {0, 0, 0};
+    LaneVec ort(lane);
     const int low = 0, high = 2;
     for (int m = low + 1; m <= high - 1; m++) {
         double scale = 0.0;
@@ -87,7 +128,7 @@ __device__ inline void eig_orthes(double H[3][3], double V[3][3])
     }
 }
 
-__device__ inline void eig_hqr2(double H[3][3], double V[3][3], double d[3], double e[3])
+__device__ inline void eig_hqr2(LaneMat3& H, LaneMat3& V, LaneVec& d, LaneVec& e)
 {
     const int nn = 3;
     int n = nn - 1;
@@ -376,30 +417,38 @@ __device__ inline void eig_hqr2(double H[3][3], double V[3][3], double d[3], dou
         }
 }
 
-__device__ inline void eigen_nonsymmetric3(const double M[3][3], double eval[3], double evec[3][3])
+// cv::eigenNonSymmetric: eigenvalues sorted descending (stable), eigenvectors as rows
+__device__ inline void eigen_nonsymmetric3(const double M[3][3], double eval[3], double evec[3][3], int lane)
 {
-    double H[3][3], V[3][3], d[3] = {0, 0, 0}, e[3] = {0, 0, 0};
+    LaneMat3 H(lane), V(lane);
+    LaneVec d(lane), e(lane);
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) H[i][j] = M[i][j];
-    eig_orthes(H, V);
+    eig_orthes(H, V, lane);
     eig_hqr2(H, V, d, e);
-    int idx[3] = {0, 1, 2};
-    for (int i = 1; i < 3; i++) {
-        int k = idx[i], j = i - 1;
-        while (j >= 0 && d[idx[j]] < d[k]) {
-            idx[j + 1] = idx[j];
-            j--;
-        }
-        idx[j + 1] = k;
+    const double d0 = d.get(0), d1 = d.get(1), d2 = d.get(2);
+    // insertion sort of (0,1,2) by d, descending, ties keep their order
+    int i0 = 0, i1 = 1, i2 = 2;
+    double e0 = d0, e1 = d1;
+    if (e0 < d1) { i0 = 1; i1 = 0; e0 = d1; e1 = d0; }
+    if (e1 < d2) {
+        i2 = i1;
+        if (e0 < d2) { i1 = i0; i0 = 2; }
+        else { i1 = 2; }
     }
+    const int idx[3] = {i0, i1, i2};
+#pragma unroll
     for (int i = 0; i < 3; i++) {
-        eval[i] = d[idx[i]];
-        for (int j = 0; j < 3; j++) evec[i][j] = V[j][idx[i]];
+        eval[i] = d.get(idx[i]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) evec[i][j] = lane_get(V.reg, 3 * j + idx[i]);
     }
 }
 
 // ---- symmetric k x k cyclic Jacobi + normal-equation least squares (general-fit fallback) --------
-__device__ inline void jacobi_sym(double* A, int k, double* lam, double* V)
+__device__ inline void jacobi_sym(LaneVec& A, int k, LaneVec& lam, LaneVec& V)
 {
     for (int i = 0; i < k; i++)
         for (int j = 0; j < k; j++) V[i * k + j] = (i == j) ? 1.0 : 0.0;
@@ -414,7 +463,8 @@ __device__ inline void jacobi_sym(double* A, int k, double* lam, double* V)
                 if (apq == 0.0) continue;
                 double app = A[p * k + p], aqq = A[q * k + q];
                 if (dabs(apq) < 1e-300 || dabs(apq) <= 1.1102230246251565e-16 * 1e-3 * dsqrt(dabs(app * aqq))) {
-                    A[p * k + q] = A[q * k + p] = 0.0;
+                    A[p * k + q] = 0.0;
+                    A[q * k + p] = 0.0;
                     continue;
                 }
                 double theta = (aqq - app) / (2.0 * apq);
@@ -424,14 +474,17 @@ __device__ inline void jacobi_sym(double* A, int k, double* lam, double* V)
                 double s = t * c;
                 A[p * k + p] = app - t * apq;
                 A[q * k + q] = aqq + t * apq;
-                A[p * k + q] = A[q * k + p] = 0.0;
+                A[p * k + q] = 0.0;
+                A[q * k + p] = 0.0;
                 for (int r = 0; r < k; r++) {
                     if (r != p && r != q) {
                         double arp = A[r * k + p], arq = A[r * k + q];
                         double nrp = c * arp - s * arq;
                         double nrq = s * arp + c * arq;
-                        A[r * k + p] = A[p * k + r] = nrp;
-                        A[r * k + q] = A[q * k + r] = nrq;
+                        A[r * k + p] = nrp;
+                        A[p * k + r] = nrp;
+                        A[r * k + q] = nrq;
+                        A[q * k + r] = nrq;
                     }
                     double vrp = V[r * k + p], vrq = V[r * k + q];
                     V[r * k + p] = c * vrp - s * vrq;
@@ -439,30 +492,34 @@ __device__ inline void jacobi_sym(double* A, int k, double* lam, double* V)
                 }
             }
     }
-    for (int i = 0; i < k; i++) lam[i] = A[i * k + i];
+    for (int i = 0; i < k; i++) lam[i] = (double)A[i * k + i];
 }
 
-__device__ inline void normal_solve(const double* G, const double* g, int k, double* x, double* wmax, double* wmin)
+// least squares through the normal equations: A (k x k, lanes 0..k*k-1, destroyed) x = g (lanes 0..k-1)
+__device__ inline void normal_solve(LaneVec& A, LaneVec& g, int k, double* x /* k <= 5 */, double* wmax, double* wmin, int lane)
 {
-    double A[25], lam[5], V[25], w[5];
-    for (int i = 0; i < k * k; i++) A[i] = G[i];
+    LaneVec lam(lane), V(lane), w(lane), xs(lane);
     jacobi_sym(A, k, lam, V);
     double wsum = 0, mx = 0, mn = 0;
     for (int i = 0; i < k; i++) {
-        w[i] = lam[i] > 0 ? dsqrt(lam[i]) : 0.0;
-        wsum += w[i];
-        if (i == 0 || w[i] > mx) mx = w[i];
-        if (i == 0 || w[i] < mn) mn = w[i];
+        const double li = lam[i];
+        const double wi = li > 0 ? dsqrt(li) : 0.0;
+        w[i] = wi;
+        wsum += wi;
+        if (i == 0 || wi > mx) mx = wi;
+        if (i == 0 || wi < mn) mn = wi;
     }
     const double thr = 2.0 * DBL_EPSILON * wsum;
-    for (int i = 0; i < k; i++) x[i] = 0.0;
+    for (int i = 0; i < k; i++) xs[i] = 0.0;
     for (int c = 0; c < k; c++) {
-        if (!(w[c] > thr)) continue;
+        if (!((double)w[c] > thr)) continue;
         double dot = 0.0;
-        for (int r = 0; r < k; r++) dot += V[r * k + c] * g[r];
-        dot = dot / lam[c];
-        for (int r = 0; r < k; r++) x[r] += dot * V[r * k + c];
+        for (int r = 0; r < k; r++) dot += (double)V[r * k + c] * (double)g[r];
+        dot = dot / (double)lam[c];
+        for (int r = 0; r < k; r++) xs[r] += dot * (double)V[r * k + c];
     }
+#pragma unroll
+    for (int i = 0; i < 5; i++) x[i] = i < k ? xs.get(i) : 0.0;
     if (wmax) *wmax = mx;
     if (wmin) *wmin = mn;
 }
@@ -544,17 +601,19 @@ __device__ inline double direct_reduce(const double DM[6][6], double TM[3][3], d
 
 // direct fit: eigenvector selection, conic -> RotatedRect (width <= height, angle in [0,180))
 __device__ inline void direct_finish(const double M[3][3], const double TM[3][3], double Ts, double scale, double cx,
-                                     double cy, rmcv_rrect* box)
+                                     double cy, rmcv_rrect* box, int lane)
 {
     double eval[3], ev[3][3], cond[3];
     int i;
-    eigen_nonsymmetric3(M, eval, ev);
+    eigen_nonsymmetric3(M, eval, ev, lane);
     cond[0] = (4.0 * ev[0][0] * ev[0][2] - ev[0][1] * ev[0][1]);
     cond[1] = (4.0 * ev[1][0] * ev[1][2] - ev[1][1] * ev[1][1]);
     cond[2] = (4.0 * ev[2][0] * ev[2][2] - ev[2][1] * ev[2][1]);
     if (cond[0] < cond[1]) i = (cond[1] < cond[2]) ? 2 : 1;
     else i = (cond[0] < cond[2]) ? 2 : 0;
-    const double e0 = ev[i][0], e1 = ev[i][1], e2 = ev[i][2];
+    const double e0 = i == 0 ? ev[0][0] : (i == 1 ? ev[1][0] : ev[2][0]);
+    const double e1 = i == 0 ? ev[0][1] : (i == 1 ? ev[1][1] : ev[2][1]);
+    const double e2 = i == 0 ? ev[0][2] : (i == 1 ? ev[1][2] : ev[2][2]);
     double norm = dsqrt(e0 * e0 + e1 * e1 + e2 * e2);
     if (((e0 < 0.0 ? -1 : 1) * (e1 < 0.0 ? -1 : 1) * (e2 < 0.0 ? -1 : 1)) <= 0.0) norm = -1.0 * norm;
     const double pv0 = e0 / norm, pv1 = e1 / norm, pv2 = e2 / norm;

@@ -90,9 +90,15 @@ __device__ __forceinline__ void tri_index(int e, int k, int* a, int* b)
 
 // cv::fitEllipseDirect (objdetect.cpp:68) for one contour, by one wavefront.  sumx/sumy = integer coordinate sums.
 // returns 0 = direct solution, 1 = general fit.  All results are wave-uniform.
+#ifdef RMCV_PROFILE
+#define FSTAMP(k) do { if (prof) prof[k] = wall_clock64(); } while (0)
+#else
+#define FSTAMP(k) do {} while (0)
+#endif
 __device__ int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n, long long sumx, long long sumy, WaveLds& L, int lane,
-                                rmcv_rrect* box)
+                                rmcv_rrect* box, long long* prof = nullptr)
 {
+    FSTAMP(0);
     // ------------------------------------------------ direct (Fitzgibbon / Halir-Flusser)
     {
         const double cx = (double)sumx / n, cy = (double)sumy / n;
@@ -100,6 +106,7 @@ __device__ int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n, long 
             return dabs((float)pts[i].x - cx) + dabs((float)pts[i].y - cy);
         });
         const double scale = 100.0 / (s > FLT_EPSILON ? s : (double)FLT_EPSILON);
+        FSTAMP(1);
         int la = 0, lb = 0;
         tri_index(lane < 21 ? lane : 0, 6, &la, &lb);
         double DM[6][6], TM[3][3], M[3][3], Ts = 0;
@@ -127,10 +134,13 @@ __device__ int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n, long 
             if (dabs(det) > 1.0e-10) break;
             eps = (float)(s / (n * 2) * 1e-2);
         }
+        FSTAMP(2);
         if (iter < 2) {
-            direct_finish(M, TM, Ts, scale, cx, cy, box);
+            direct_finish(M, TM, Ts, scale, cx, cy, box, lane);
+            FSTAMP(3);
             if (is_good_box(box)) return 0;
         }
+        FSTAMP(3);
     }
     // ------------------------------------------------ general conic fit (fallback)
     {
@@ -165,21 +175,24 @@ __device__ int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n, long 
             });
             if (lane < 20) L.dm[lane] = acc;
             __builtin_amdgcn_wave_barrier();
-            double G[25], g[5], wmax, wmin;
-            {
-                int e = 0;
-                for (int a = 0; a < 5; a++)
-                    for (int b = a; b < 5; b++, e++) G[a * 5 + b] = G[b * 5 + a] = L.dm[e];
-                for (int a = 0; a < 5; a++) g[a] = L.dm[15 + a];
+            double wmax, wmin;
+            LaneVec G(lane), g(lane);
+            { // lane a*5+b takes G(a,b) = G(b,a) from the upper-triangle sums; lane a takes g(a)
+                const int a = lane / 5, b = lane - 5 * a;
+                const int lo = a < b ? a : b, hi = a < b ? b : a;
+                const int e = lo * 5 - lo * (lo - 1) / 2 + (hi - lo);
+                G.reg = lane < 25 ? L.dm[e] : 0.0;
+                g.reg = lane < 5 ? L.dm[15 + lane] : 0.0;
             }
             __builtin_amdgcn_wave_barrier();
-            normal_solve(G, g, 5, gfp, &wmax, &wmin);
+            normal_solve(G, g, 5, gfp, &wmax, &wmin, lane);
             if (iter == 0 && wmax * FLT_EPSILON > wmin) {
                 eps = (float)(s / (n * 2) * 1e-3);
                 continue;
             }
             break;
         }
+        FSTAMP(4);
         general_centre(gfp, rp);
         if (lane < 6) tri_index(lane, 3, &la, &lb);
         else { la = lane < 9 ? lane - 6 : 0; lb = -1; }
@@ -193,16 +206,19 @@ __device__ int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n, long 
         });
         if (lane < 9) L.dm[lane] = acc;
         __builtin_amdgcn_wave_barrier();
-        double G[9], g[3];
+        LaneVec G(lane), g(lane);
         {
-            int e = 0;
-            for (int a = 0; a < 3; a++)
-                for (int b = a; b < 3; b++, e++) G[a * 3 + b] = G[b * 3 + a] = L.dm[e];
-            for (int a = 0; a < 3; a++) g[a] = L.dm[6 + a];
+            const int a = lane / 3, b = lane - 3 * a;
+            const int lo = a < b ? a : b, hi = a < b ? b : a;
+            const int e = lo * 3 - lo * (lo - 1) / 2 + (hi - lo);
+            G.reg = lane < 9 ? L.dm[e] : 0.0;
+            g.reg = lane < 3 ? L.dm[6 + lane] : 0.0;
         }
         __builtin_amdgcn_wave_barrier();
-        normal_solve(G, g, 3, gfp, 0, 0);
+        FSTAMP(5);
+        normal_solve(G, g, 3, gfp, 0, 0, lane);
         general_finish(gfp, rp, scale, cx, cy, box);
+        FSTAMP(6);
     }
     return 1;
 }
@@ -243,7 +259,16 @@ __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ poin
             sy = wave_sum_i64(sy);
             const double area = dabs(a00 * 0.5);
             if (area >= area_lo && area <= area_hi) {
+#ifdef RMCV_PROFILE
+                long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const int path = fit_ellipse_wave(cp, len, sx, sy, L, lane, &ell, pr);
+                if (lane == 0 && f == 0 && len > 150)
+                    printf("[fit f%d c%d n=%d path=%d] s %.1f moments+reduce %.1f finish %.1f | gen s+G+solve %.1f refit %.1f solve3+finish %.1f us\n", f, c,
+                           len, path, (pr[1] - pr[0]) / 100.0, (pr[2] - pr[1]) / 100.0, (pr[3] - pr[2]) / 100.0,
+                           (pr[4] - pr[3]) / 100.0, (pr[5] - pr[4]) / 100.0, (pr[6] - pr[5]) / 100.0);
+#else
                 fit_ellipse_wave(cp, len, sx, sy, L, lane, &ell); // :68  (:69 minAreaRect is dead code in the reference)
+#endif
                 bool negative = false;
                 const float mx = ell.w > ell.h ? ell.w : ell.h, mn = ell.w < ell.h ? ell.w : ell.h;
                 const float ratio = mx / mn; // :71-73
