@@ -563,7 +563,12 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
                 if (!((ld_l2(NEG + base + k) >> top) & 1ull)) atomicOr(&s_flags, FL_COMPLEX);
             }
         }
-        // V2: every unlabelled run start would have been rejected
+    }
+    __syncthreads();
+    if (summarised && !force_literal) {
+        // V2: every unlabelled run start would have been rejected.  The labels of a row are cleared right after
+        // they were read (LAB/NEG are zero between launches; nobody else reads this row's labels any more).
+        const bool check = !(s_flags & FL_COMPLEX);
         for (int r = tid; r < nrows; r += CT_THREADS) {
             const int y = s_rows[r];
             const int64_t base = (int64_t)(y + 1) * prow + 1;
@@ -574,7 +579,8 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
                 if (!((occ >> k) & 1u)) { carry = 0; continue; }
                 const uint64_t fwd = F[base + k];
                 const uint64_t l = ld_l2(LAB + base + k), ng = ld_l2(NEG + base + k);
-                uint64_t cand = fwd & ~((fwd << 1) | carry) & ~l;
+                if (l) { LAB[base + k] = 0; NEG[base + k] = 0; }
+                uint64_t cand = check ? (fwd & ~((fwd << 1) | carry) & ~l) : 0ull;
                 while (cand) {
                     const int b = __ffsll((long long)cand) - 1;
                     cand &= cand - 1;
@@ -587,12 +593,10 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
             }
         }
     }
+    __threadfence();
     __syncthreads();
     STAMP();
     const bool complex = (s_flags & FL_COMPLEX) != 0;
-    if (summarised && !force_literal) clear_labels(tid, LAB, NEG, prow, s_rowmask, s_rows, nrows);
-    __threadfence();
-    __syncthreads();
 
     if (complex) {
         // ---------------- F: literal scanner (one wavefront), exact for nested components

@@ -44,11 +44,14 @@ __device__ __forceinline__ double seq_sum_terms(int n, int lane, WaveLds& L, F t
     double s = 0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
-        if (i < n) L.terms[lane] = term(i);
-        __builtin_amdgcn_wave_barrier();
+        const double t = i < n ? term(i) : 0.0;
         const int m = n - base < 64 ? n - base : 64;
-        for (int j = 0; j < m; j++) s += L.terms[j];
-        __builtin_amdgcn_wave_barrier();
+        if (m == 64) {
+#pragma unroll
+            for (int j = 0; j < 64; j++) s += lane_get(t, j); // in point order: lane j holds point base+j
+        } else {
+            for (int j = 0; j < m; j++) s += lane_get(t, j);
+        }
     }
     return s;
 }
@@ -69,10 +72,13 @@ __device__ __forceinline__ double seq_sum_products(int n, int lane, WaveLds& L, 
         __builtin_amdgcn_wave_barrier();
         const int m = n - base < 64 ? n - base : 64;
         if (lane < ns) {
-            if (lb >= 0)
+            if (lb >= 0) {
+#pragma unroll 8
                 for (int j = 0; j < m; j++) acc += L.rows[j][la] * L.rows[j][lb];
-            else
+            } else {
+#pragma unroll 8
                 for (int j = 0; j < m; j++) acc += L.rows[j][la] * konst;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
