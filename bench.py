@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 plain stream, 1 stress stream")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 (binary only) side measurements")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="contexts/streams the steps are double-buffered over (1 = strictly serial steps)")
     args = ap.parse_args()
 
     import torch
@@ -66,20 +68,31 @@ def main():
     n = args.frames
     host = synth.batch(rank * n, n, W, H, CAMP_BLUE, args.variant, threads=min(16, os.cpu_count() or 1))
     frames = torch.from_numpy(host).to(dev)                      # resident in HBM before any timing
-    ctx = Context(device=local_rank, max_frames=n, max_width=W, max_height=H)
-    ctx.bind_device_frames(frames.data_ptr(), n, H, W, keepalive=frames)
+    # Steps are double-buffered over `--streams` contexts (own work buffers, own HIP stream, same resident
+    # frames): while the sparse stages of step i (contours, fits, pairing: latency-bound, a few waves per CU) run,
+    # the HBM-bound pixel kernel of step i+1 streams -- what a continuous camera feed would do.
+    ns = max(1, args.streams)
+    ctxs = [Context(device=local_rank, max_frames=n, max_width=W, max_height=H) for _ in range(ns)]
+    for c in ctxs:
+        c.bind_device_frames(frames.data_ptr(), n, H, W, keepalive=frames)
+    ctx = ctxs[0]
     params = default_params()                                     # main.cpp:172-176: BLUE, lb 80, close, ...
     cap = n * 16
     head, _ = rdist.record_layout(n, cap)
-    rec = rdist.new_record(n, cap, dev)
-    stream = torch.cuda.Stream(device=dev)
-    sh = stream.cuda_stream
+    recs_buf = [rdist.new_record(n, cap, dev) for _ in range(ns)]
+    # alternate stream priorities: HIP maps streams of different priority to different hardware queues, which is
+    # what lets kernels of two steps actually run concurrently
+    streams = [torch.cuda.Stream(device=dev, priority=-(k % 2)) for k in range(ns)]
+    stream, sh, rec = streams[0], streams[0].cuda_stream, recs_buf[0]
+    step_no = [0]
 
     def step():
-        with torch.cuda.stream(stream):
-            ctx.run(params, STAGE_ALL, sh)
-            ctx.compact_armours_into(rec.data_ptr() + head, cap, rec.data_ptr(), sh)
-            return rdist.gather_records(rec) if world > 1 else [rec]
+        k = step_no[0] % ns
+        step_no[0] += 1
+        with torch.cuda.stream(streams[k]):
+            ctxs[k].run(params, STAGE_ALL, streams[k].cuda_stream)
+            ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
+            return rdist.gather_records(recs_buf[k]) if world > 1 else [recs_buf[k]]
 
     def barrier():
         if world > 1:
@@ -137,6 +150,7 @@ def main():
         "config": {"workload": "C3: batch=%d/GPU 1280x1024 BGR, blue lb=80, close3x3 + findContours + lightblob fit + armour "
                                "pairing%s" % (n, " + RCCL gather of armour lists (C4)" if world > 1 else ""),
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
+                   "double_buffered_steps": ns,
                    "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad},
         "path_hbm_frac": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
         "stage_ms": {"binary": round(float(stage[0]), 4), "contours": round(float(stage[1]), 4),

@@ -86,15 +86,22 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     uint64_t* T = smem;
     uint64_t* D = smem + (size_t)(SR + 4) * ww;
 
-    // XCD-aware mapping: blocks b, b+8, b+16.. share an XCD -> give them consecutive strips
-    int b = blockIdx.x;
-    const int nb8 = n_blocks & ~7;
-    int L = (b < nb8) ? (b & 7) * (nb8 >> 3) + (b >> 3) : b;
+    // Persistent workgroups: the grid is sized to a fixed number of workgroups per CU (leaving wave slots for the
+    // sparse kernels of the previous batch that run on another stream) and every workgroup loops over strips.
+    // XCD-aware order: workgroups b, b+8, b+16.. share an XCD; XCD x owns the contiguous strip range
+    // [x*n/8, (x+1)*n/8) and its workgroups sweep it together, so neighbouring strips (which share halo rows)
+    // are in flight on the same L2 at the same time.
+    const int tid = threadIdx.x;
+    const int wq = ww * 4; // 16-pixel groups per row
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, jn = gridDim.x >> 3; // gridDim.x is a multiple of 8
+    const int per_xcd = (n_blocks + 7) >> 3;
+    for (int j = j0; j < per_xcd; j += jn) {
+    const int L = xcd * per_xcd + j;
+    if (L >= n_blocks) break;
     const int f = L / strips, strip = L - f * strips;
     const int y0 = strip * SR;
     const uint8_t* frame = frames + (int64_t)f * frame_pitch;
-    const int tid = threadIdx.x;
-    const int wq = ww * 4; // 16-pixel groups per row
+    __syncthreads(); // the LDS planes of the previous strip are free
 
     // ---------------- phase 1: load + threshold -> T
     if (FAST && LOADV == 1) {
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
             if (q >= wq) { q -= wq; s++; }
         }
     }
+    } // strip loop
 }
 
 template <int CA, int CB>
@@ -262,8 +270,20 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
                       ((uintptr_t)b.frames % 16 == 0);
     static const int forced = getenv("RMCV_K1_LOADV") ? atoi(getenv("RMCV_K1_LOADV")) : -1; // dev knob for A/B runs
     const bool coalesced = fast && g.stride == 3 * g.w && forced != 0;
-#define RMCV_K1_LAUNCH(F, V, LDS)                                                                                          \
-    hipLaunchKernelGGL((k_binary<CA, CB, F, V>), dim3(n_blocks), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, \
+    // persistent grid: RMCV_K1_BPC workgroups per CU (default 6 of the 8 that would fit: 24 of 32 wave slots)
+    static const int bpc = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 6;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    int grid = n_cu * (bpc > 0 ? bpc : 6);
+    if (grid > ((n_blocks + 7) & ~7)) grid = (n_blocks + 7) & ~7;
+    grid = (grid + 7) & ~7;
+#define RMCV_K1_LAUNCH(F, V, LDS)                                                                                       \
+    hipLaunchKernelGGL((k_binary<CA, CB, F, V>), dim3(grid), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, \
                        g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks)
     if (coalesced) RMCV_K1_LAUNCH(true, 1, planes + 4 * 3072);
     else if (fast) RMCV_K1_LAUNCH(true, 0, planes);
