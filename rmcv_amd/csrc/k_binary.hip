@@ -78,7 +78,7 @@ template <int CA, int CB, bool FAST, int LOADV>
 __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride,
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
-                                                 int64_t plane_pitch, int strips, int n_blocks)
+                                                 int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask)
 {
     extern __shared__ uint64_t smem[];
     const int halo = morph; // NONE 0, DILATE 1, CLOSE 2
@@ -222,6 +222,12 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
         }
     }
 
+    // ---------------- row masks for the contour stage: bit k = word k of the row is non-zero
+    if (ww <= 32 && tid < SR && y0 + tid < h) {
+        uint32_t m = 0;
+        for (int k = 0; k < ww; k++) m |= (uint32_t)(R[(tid + halo) * ww + k] != 0) << k;
+        rowmask[(int64_t)f * h + y0 + tid] = m;
+    }
     // ---------------- phase 4: expand to bytes + bit plane
     {
         const int items = SR * wq;
@@ -284,7 +290,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     grid = (grid + 7) & ~7;
 #define RMCV_K1_LAUNCH(F, V, LDS)                                                                                       \
     hipLaunchKernelGGL((k_binary<CA, CB, F, V>), dim3(grid), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, \
-                       g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks)
+                       g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask)
     if (coalesced) RMCV_K1_LAUNCH(true, 1, planes + 4 * 3072);
     else if (fast) RMCV_K1_LAUNCH(true, 0, planes);
     else RMCV_K1_LAUNCH(false, 0, planes);
@@ -302,7 +308,7 @@ hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound
 
 // binary (0 / non-zero bytes) -> padded bit plane; used when a caller hands in its own binary image
 __global__ void k_pack_bits(const uint8_t* __restrict__ binary, int w, int h, int ww, uint64_t* __restrict__ bits, int prow,
-                            int64_t plane_pitch)
+                            int64_t plane_pitch, uint32_t* __restrict__ rowmask)
 {
     const int f = blockIdx.y;
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
@@ -315,13 +321,16 @@ __global__ void k_pack_bits(const uint8_t* __restrict__ binary, int w, int h, in
         if (x < w && row[x]) word |= 1ull << bqt;
     }
     bits[(int64_t)f * plane_pitch + (int64_t)(y + 1) * prow + 1 + k] = word;
+    if (word && k < 32) atomicOr(&rowmask[(int64_t)f * h + y], 1u << k); // caller zeroes the masks first
 }
 
 hipError_t launch_pack_bits(const Geom& g, const Bufs& b, hipStream_t s)
 {
     const int items = g.h * g.ww;
+    hipError_t e = hipMemsetAsync(b.rowmask, 0, (size_t)g.n_frames * g.h * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pack_bits, dim3((items + 255) / 256, g.n_frames), dim3(256), 0, s, b.binary, g.w, g.h, g.ww, b.bits,
-                       g.prow, g.plane_pitch);
+                       g.prow, g.plane_pitch, b.rowmask);
     return hipGetLastError();
 }
 

@@ -327,9 +327,18 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane)
     return inc - v;
 }
 
-// all lanes replay their 32 recorded steps: points -> out[0..n), labels -> LAB/NEG (n <= CODE_CAP)
-__device__ void replay_emit(int n, int x0, int y0, int lane, uint64_t c0, uint64_t c1, rmcv_point* out, uint64_t* LAB,
-                            uint64_t* NEG, int prow)
+// Sparse label store of the fast path: one LDS slot per NON-EMPTY word of F (labels only exist where F is set).
+// slot(y, k) = rowbase[y] + popcount(rowmask[y] & ((1 << k) - 1)).
+struct LabelStore {
+    const uint32_t* rowmask;
+    const uint16_t* rowbase;
+    unsigned long long* lab;
+    unsigned long long* neg;
+    __device__ __forceinline__ int slot(int y, int k) const { return rowbase[y] + __popc(rowmask[y] & ((1u << k) - 1u)); }
+};
+
+// all lanes replay their 32 recorded steps: points -> out[0..n), labels -> the LDS label store (n <= CODE_CAP)
+__device__ void replay_emit(int n, int x0, int y0, int lane, uint64_t c0, uint64_t c1, rmcv_point* out, const LabelStore& LS)
 {
     int cnt = n - 32 * lane;
     cnt = cnt < 0 ? 0 : (cnt > 32 ? 32 : cnt);
@@ -340,19 +349,20 @@ __device__ void replay_emit(int n, int x0, int y0, int lane, uint64_t c0, uint64
         dy += dir_dy(sdir);
     }
     int x = x0 + wave_excl_scan_i32(dx, lane), y = y0 + wave_excl_scan_i32(dy, lane);
-    int64_t pidx = -1; // pending label word
-    uint64_t plab = 0, pneg = 0;
+    int pslot = -1, py = -1, pk = -1; // pending label word
+    unsigned long long plab = 0, pneg = 0;
     for (int j = 0; j < cnt; j++) {
         const uint32_t code = (uint32_t)((j < 16 ? c0 >> (4 * j) : c1 >> (4 * (j - 16)))) & 15u;
         rmcv_point p;
         p.x = x;
         p.y = y;
         out[32 * lane + j] = p;
-        const int64_t idx = (int64_t)(y + 1) * prow + 1 + (x >> 6);
-        if (idx != pidx) {
-            if (plab) atomicOr((unsigned long long*)(LAB + pidx), (unsigned long long)plab);
-            if (pneg) atomicOr((unsigned long long*)(NEG + pidx), (unsigned long long)pneg);
-            pidx = idx;
+        if (y != py || (x >> 6) != pk) {
+            if (plab) atomicOr(LS.lab + pslot, plab);
+            if (pneg) atomicOr(LS.neg + pslot, pneg);
+            py = y;
+            pk = x >> 6;
+            pslot = LS.slot(y, pk);
             plab = 0;
             pneg = 0;
         }
@@ -361,55 +371,49 @@ __device__ void replay_emit(int n, int x0, int y0, int lane, uint64_t c0, uint64
         x += dir_dx((int)(code & 7u));
         y += dir_dy((int)(code & 7u));
     }
-    if (plab) atomicOr((unsigned long long*)(LAB + pidx), (unsigned long long)plab);
-    if (pneg) atomicOr((unsigned long long*)(NEG + pidx), (unsigned long long)pneg);
+    if (plab) atomicOr(LS.lab + pslot, plab);
+    if (pneg) atomicOr(LS.neg + pslot, pneg);
 }
 
-// ---- k_contours: one workgroup (4 wavefronts) per frame ---------------------------------------------------
-//  T  every thread scans rows for LOCAL TOPS (run starts whose run touches nothing in the row above): the
-//     raster-first pixel of every 8-connected component is one of them
-//  S  wavefronts pull tops from a queue and trace them speculatively; a trace whose raster-smallest pixel is its
-//     own start is the outer border of a component seen from its first pixel -> kept, traced again to store
-//     points + labels.  Traces are independent, so all components of a frame are followed concurrently.
+// ---- k_contours: one workgroup (8 wavefronts) per frame ---------------------------------------------------
+//  T  every thread scans non-empty rows for LOCAL TOPS (run starts whose run touches nothing in the row above):
+//     the raster-first pixel of every 8-connected component is one of them
+//  S  wavefronts pull tops from a queue and walk them; a walk that meets no raster-earlier pixel started at the
+//     first pixel of a component and followed its outer border -> kept, replayed into points + labels.
+//     Walks are independent, so all components of a frame are followed concurrently.
 //  V  verification of OpenCV's RETR_EXTERNAL bookkeeping on the merged labels: every kept start must have been
 //     accepted (nearest labelled pixel to its left negative or absent) and every other unlabelled run start
 //     rejected.  True for frames without nested components; then discovery order = raster order of the starts.
-//  F  otherwise the frame is redone by the literal scanner (exact for every input).
-// LAB/NEG are zero between launches: whoever set labels clears them (labels only exist where F is set).
-static constexpr int CAND_CAP = 4096;
-static constexpr int KEPT_CAP = 2048;
-static constexpr int CT_THREADS = 512; // 8 wavefronts: the bars of a frame are traced concurrently
-static constexpr int CT_MAXH = 2048;   // rows covered by the LDS row summary (taller/wider frames take the literal path)
+//  F  otherwise the frame is redone by the literal scanner (exact for every input) on the global LAB/NEG planes,
+//     which are zero between launches (the literal path clears what it set).
+// Non-empty rows/words come from the row masks k_binary writes next to the bit plane (bit k of rowmask[y] = word k
+// of row y is non-zero; a superset is fine).
+static constexpr int CAND_CAP = 2048;
+static constexpr int KEPT_CAP = 1024;
+static constexpr int SLOT_CAP = 2048;  // non-empty words of a frame the LDS label store can hold
+static constexpr int CT_THREADS = 512; // 8 wavefronts: the bars of a frame are walked concurrently
+static constexpr int CT_MAXH = 2048;   // rows covered by the LDS row tables (taller/wider frames take the literal path)
 
-// labels only exist where F is set: clear LAB/NEG on the non-empty words of the non-empty rows
-__device__ void clear_labels(int tid, uint64_t* LAB, uint64_t* NEG, int prow, const uint32_t* rowmask, const uint16_t* rows,
-                             int nrows)
-{
-    for (int r = tid; r < nrows; r += CT_THREADS) {
-        const int y = rows[r];
-        const int64_t base = (int64_t)(y + 1) * prow + 1;
-        uint32_t m = rowmask[y];
-        while (m) {
-            const int k = __ffs((int)m) - 1;
-            m &= m - 1;
-            LAB[base + k] = 0;
-            NEG[base + k] = 0;
-        }
-    }
-}
+struct ContoursLds {
+    unsigned long long lab[SLOT_CAP], neg[SLOT_CAP];
+    uint32_t rowmask[CT_MAXH];
+    uint32_t cand[CAND_CAP];
+    uint32_t kkey[KEPT_CAP];
+    int32_t koff[KEPT_CAP], klen[KEPT_CAP];
+    uint16_t rows[CT_MAXH], rowbase[CT_MAXH];
+    int scan[CT_THREADS];
+    uint8_t lut[4096];
+    int ncand, next, nkept, cursor, flags, nrows, nslots, lit[3];
+};
 
-__global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restrict__ bits, uint64_t* lab, uint64_t* neg, int w, int h,
-                                                 int ww, int prow, int64_t plane_pitch, rmcv_point* points, int32_t* cont_start,
-                                                 int32_t* cont_len, int32_t* n_contours, int32_t* n_points, int32_t* status,
-                                                 int max_contours, int max_points, int force_literal)
+__global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restrict__ bits, const uint32_t* __restrict__ rowmasks,
+                                                        int rm_pitch, uint64_t* lab, uint64_t* neg, int w, int h, int ww, int prow,
+                                                        int64_t plane_pitch, rmcv_point* points, int32_t* cont_start,
+                                                        int32_t* cont_len, int32_t* n_contours, int32_t* n_points,
+                                                        int32_t* status, int max_contours, int max_points, int force_literal)
 {
-    __shared__ uint32_t s_cand[CAND_CAP];
-    __shared__ uint32_t s_kkey[KEPT_CAP];
-    __shared__ int32_t s_koff[KEPT_CAP], s_klen[KEPT_CAP];
-    __shared__ uint8_t s_lut[4096];         // border-following step table (lut_build)
-    __shared__ uint32_t s_rowmask[CT_MAXH]; // bit k: word k of the row is non-zero
-    __shared__ uint16_t s_rows[CT_MAXH];    // the non-empty rows (any order)
-    __shared__ int s_ncand, s_next, s_nkept, s_cursor, s_flags, s_nrows, s_lit[3];
+    extern __shared__ unsigned long long smem_raw[];
+    ContoursLds& S = *reinterpret_cast<ContoursLds*>(smem_raw);
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t* F = bits + (int64_t)f * plane_pitch;
     const uint32_t* F32 = reinterpret_cast<const uint32_t*>(F);
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
     rmcv_point* pts = points + (int64_t)f * max_points;
     int32_t* cs = cont_start + (int64_t)f * max_contours;
     int32_t* cl = cont_len + (int64_t)f * max_contours;
-    enum { FL_COMPLEX = 1, FL_OVF_POINTS = 2, FL_OVF_CONTOURS = 4 };
+    enum { FL_COMPLEX = 1 };
 #ifdef RMCV_PROFILE
     long long t_[8]; int ti_ = 0;
 #define STAMP() do { __syncthreads(); t_[ti_++] = wall_clock64(); } while (0)
@@ -428,44 +432,60 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
     STAMP();
     const bool summarised = (h <= CT_MAXH && ww <= 32);
     if (tid == 0) {
-        s_ncand = 0; s_next = 0; s_nkept = 0; s_cursor = 0; s_nrows = 0;
-        s_flags = (force_literal || !summarised) ? FL_COMPLEX : 0;
+        S.ncand = 0; S.next = 0; S.nkept = 0; S.cursor = 0; S.nrows = 0; S.nslots = 0;
+        S.flags = (force_literal || !summarised) ? FL_COMPLEX : 0;
     }
-    if (summarised)
-        for (int y = tid; y < h; y += CT_THREADS) s_rowmask[y] = 0;
-    lut_build(s_lut, tid, CT_THREADS);
-    __syncthreads();
-    // ---------------- row summary: one coalesced, fully pipelined sweep over the bit plane
+    lut_build(S.lut, tid, CT_THREADS);
+    // ---------------- row tables: masks from k_binary, slot bases by a workgroup prefix sum, list of non-empty rows
     if (summarised) {
-        const int total = h * ww;
-        for (int i0 = tid; i0 < total; i0 += 4 * CT_THREADS) {
-            uint64_t v[4];
-            int yy[4], kk[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = i0 + u * CT_THREADS;
-                yy[u] = i / ww;
-                kk[u] = i - yy[u] * ww;
-                v[u] = i < total ? F[(int64_t)(yy[u] + 1) * prow + 1 + kk[u]] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (v[u]) atomicOr(&s_rowmask[yy[u]], 1u << kk[u]);
+        const int per = (h + CT_THREADS - 1) / CT_THREADS; // consecutive rows per thread
+        int cnt = 0;
+        for (int u = 0; u < per; u++) {
+            const int y = tid * per + u;
+            const uint32_t m = y < h ? rowmasks[(int64_t)f * rm_pitch + y] : 0u;
+            if (y < h) S.rowmask[y] = m;
+            cnt += __popc(m);
         }
+        S.scan[tid] = cnt;
         __syncthreads();
-        for (int y = tid; y < h; y += CT_THREADS)
-            if (s_rowmask[y]) s_rows[atomicAdd(&s_nrows, 1)] = (uint16_t)y;
-        __syncthreads();
+        for (int d = 1; d < CT_THREADS; d <<= 1) { // Hillis-Steele inclusive scan
+            const int v = tid >= d ? S.scan[tid - d] : 0;
+            __syncthreads();
+            S.scan[tid] += v;
+            __syncthreads();
+        }
+        int base = S.scan[tid] - cnt;
+        for (int u = 0; u < per; u++) {
+            const int y = tid * per + u;
+            if (y < h) {
+                const uint32_t m = S.rowmask[y];
+                S.rowbase[y] = (uint16_t)(base < 65535 ? base : 65535);
+                base += __popc(m);
+                if (m) S.rows[atomicAdd(&S.nrows, 1)] = (uint16_t)y;
+            }
+        }
+        if (tid == CT_THREADS - 1) {
+            S.nslots = S.scan[tid];
+            if (S.scan[tid] > SLOT_CAP) S.flags |= FL_COMPLEX;
+        }
     }
-    const int nrows = s_nrows;
+    __syncthreads();
+    const int nrows = S.nrows;
+    if (!(S.flags & FL_COMPLEX))
+        for (int i = tid; i < S.nslots; i += CT_THREADS) { S.lab[i] = 0; S.neg[i] = 0; }
+    LabelStore LS;
+    LS.rowmask = S.rowmask;
+    LS.rowbase = S.rowbase;
+    LS.lab = S.lab;
+    LS.neg = S.neg;
     STAMP();
 
     // ---------------- T: local tops
-    if (!(s_flags & FL_COMPLEX))
+    if (!(S.flags & FL_COMPLEX))
         for (int r = tid; r < nrows; r += CT_THREADS) {
-            const int y = s_rows[r];
+            const int y = S.rows[r];
             const int64_t base = (int64_t)(y + 1) * prow + 1, up = base - prow;
-            const uint32_t occ = s_rowmask[y], occ_up = y > 0 ? s_rowmask[y - 1] : 0u;
+            const uint32_t occ = S.rowmask[y], occ_up = y > 0 ? S.rowmask[y - 1] : 0u;
             bool in_run = false, touched = false;
             int run_x = 0;
             for (int k = 0; k < ww; k++) {
@@ -484,8 +504,8 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
                     touched |= (touch & mask) != 0;
                     if (lead == 64) continue;
                     if (!touched) {
-                        const int i = atomicAdd(&s_ncand, 1);
-                        if (i < CAND_CAP) s_cand[i] = ((uint32_t)y << 16) | (uint32_t)run_x;
+                        const int i = atomicAdd(&S.ncand, 1);
+                        if (i < CAND_CAP) S.cand[i] = ((uint32_t)y << 16) | (uint32_t)run_x;
                     }
                     in_run = false;
                     rem = fwd & ~mask;
@@ -498,151 +518,146 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
                     const bool tch = (touch & mask) != 0;
                     if (st + len == 64) { in_run = true; touched = tch; run_x = k * 64 + st; break; }
                     if (!tch) {
-                        const int i = atomicAdd(&s_ncand, 1);
-                        if (i < CAND_CAP) s_cand[i] = ((uint32_t)y << 16) | (uint32_t)(k * 64 + st);
+                        const int i = atomicAdd(&S.ncand, 1);
+                        if (i < CAND_CAP) S.cand[i] = ((uint32_t)y << 16) | (uint32_t)(k * 64 + st);
                     }
                     rem &= ~mask;
                 }
             }
             if (in_run && !touched) {
-                const int i = atomicAdd(&s_ncand, 1);
-                if (i < CAND_CAP) s_cand[i] = ((uint32_t)y << 16) | (uint32_t)run_x;
+                const int i = atomicAdd(&S.ncand, 1);
+                if (i < CAND_CAP) S.cand[i] = ((uint32_t)y << 16) | (uint32_t)run_x;
             }
         }
     __syncthreads();
     STAMP();
-    const int ncand = s_ncand;
-    if (ncand > CAND_CAP && tid == 0) s_flags |= FL_COMPLEX;
+    const int ncand = S.ncand;
+    if (ncand > CAND_CAP && tid == 0) S.flags |= FL_COMPLEX;
     __syncthreads();
 
-    // ---------------- S: speculative traces, one wavefront per candidate
-    if (!(s_flags & FL_COMPLEX)) {
+    // ---------------- S: speculative walks, one wavefront per candidate
+    if (!(S.flags & FL_COMPLEX)) {
         WWin W;
         for (;;) {
             // every lane issues the LDS atomic (lanes != 0 add 0), so the loop control stays wave-uniform
-            const int i = __builtin_amdgcn_readfirstlane(atomicAdd(&s_next, lane == 0 ? 1 : 0));
+            const int i = __builtin_amdgcn_readfirstlane(atomicAdd(&S.next, lane == 0 ? 1 : 0));
             if (i >= ncand) break;
-            const uint32_t key0 = s_cand[i];
+            const uint32_t key0 = S.cand[i];
             const int x0 = (int)(key0 & 0xFFFFu), y0 = (int)(key0 >> 16);
             int state = 0;
             uint64_t c0 = 0, c1 = 0;
             wwin_load(W, F32, prow, h, x0, y0, lane);
-            const int len = walk_record(W, F32, prow, h, x0, y0, lane, s_lut, &state, &c0, &c1);
+            const int len = walk_record(W, F32, prow, h, x0, y0, lane, S.lut, &state, &c0, &c1);
             if (state == 2) continue; // not the first pixel of its component (or a hole border)
-            const int off = __builtin_amdgcn_readfirstlane(atomicAdd(&s_cursor, lane == 0 ? len : 0));
-            const int slot = __builtin_amdgcn_readfirstlane(atomicAdd(&s_nkept, lane == 0 ? 1 : 0));
+            const int off = __builtin_amdgcn_readfirstlane(atomicAdd(&S.cursor, lane == 0 ? len : 0));
+            const int slot = __builtin_amdgcn_readfirstlane(atomicAdd(&S.nkept, lane == 0 ? 1 : 0));
             if (slot >= KEPT_CAP || slot >= max_contours || off + len > max_points || len > CODE_CAP) {
                 // capacity, or a contour longer than the code registers (> 2048 points): the literal scanner
                 // redoes the frame and reports an overflow exactly
-                atomicOr(&s_flags, FL_COMPLEX);
+                atomicOr(&S.flags, FL_COMPLEX);
                 continue;
             }
-            replay_emit(len, x0, y0, lane, c0, c1, pts + off, LAB, NEG, prow);
-            s_kkey[slot] = key0; // same value from every lane
-            s_koff[slot] = off;
-            s_klen[slot] = len;
+            replay_emit(len, x0, y0, lane, c0, c1, pts + off, LS);
+            S.kkey[slot] = key0; // same value from every lane
+            S.koff[slot] = off;
+            S.klen[slot] = len;
         }
     }
-    __threadfence();
     __syncthreads();
     STAMP();
 
-    // ---------------- V: verification against the merged labels
-    const int nkept = s_nkept;
-    if (!(s_flags & FL_COMPLEX)) {
+    // ---------------- V: verification against the merged labels (all in LDS)
+    const int nkept = S.nkept;
+    if (!(S.flags & FL_COMPLEX)) {
         // V1: every kept start was acceptable: nearest labelled pixel to its left is negative, or there is none
         for (int e = tid; e < nkept; e += CT_THREADS) {
-            const uint32_t key = s_kkey[e];
+            const uint32_t key = S.kkey[e];
             const int x0 = (int)(key & 0xFFFFu), y0 = (int)(key >> 16);
-            const int64_t base = (int64_t)(y0 + 1) * prow + 1;
+            const uint32_t occ = S.rowmask[y0];
             int k = x0 >> 6;
-            uint64_t l = ld_l2(LAB + base + k) & ((1ull << (x0 & 63)) - 1);
-            while (!l && k > 0) { k--; l = ld_l2(LAB + base + k); }
+            unsigned long long l = S.lab[LS.slot(y0, k)] & ((1ull << (x0 & 63)) - 1);
+            uint32_t left = occ & ((1u << k) - 1u);
+            while (!l && left) {
+                k = 31 - __clz((int)left);
+                left &= ~(1u << k);
+                l = S.lab[LS.slot(y0, k)];
+            }
             if (l) {
                 const int top = 63 - __clzll((long long)l);
-                if (!((ld_l2(NEG + base + k) >> top) & 1ull)) atomicOr(&s_flags, FL_COMPLEX);
+                if (!((S.neg[LS.slot(y0, k)] >> top) & 1ull)) atomicOr(&S.flags, FL_COMPLEX);
             }
         }
-    }
-    __syncthreads();
-    if (summarised && !force_literal) {
-        // V2: every unlabelled run start would have been rejected.  The labels of a row are cleared right after
-        // they were read (LAB/NEG are zero between launches; nobody else reads this row's labels any more).
-        const bool check = !(s_flags & FL_COMPLEX);
+        // V2: every unlabelled run start would have been rejected
         for (int r = tid; r < nrows; r += CT_THREADS) {
-            const int y = s_rows[r];
+            const int y = S.rows[r];
             const int64_t base = (int64_t)(y + 1) * prow + 1;
-            const uint32_t occ = s_rowmask[y];
+            const uint32_t occ = S.rowmask[y];
+            int slot = S.rowbase[y];
             uint64_t carry = 0;
             bool last_pos = false;
             for (int k = 0; k < ww; k++) {
                 if (!((occ >> k) & 1u)) { carry = 0; continue; }
                 const uint64_t fwd = F[base + k];
-                const uint64_t l = ld_l2(LAB + base + k), ng = ld_l2(NEG + base + k);
-                if (l) { LAB[base + k] = 0; NEG[base + k] = 0; }
-                uint64_t cand = check ? (fwd & ~((fwd << 1) | carry) & ~l) : 0ull;
+                const unsigned long long l = S.lab[slot], ng = S.neg[slot];
+                slot++;
+                uint64_t cand = fwd & ~((fwd << 1) | carry) & ~l;
                 while (cand) {
                     const int b = __ffsll((long long)cand) - 1;
                     cand &= cand - 1;
                     const uint64_t below = l & ((1ull << b) - 1);
                     const bool pos = below ? !((ng >> (63 - __clzll((long long)below))) & 1ull) : last_pos;
-                    if (!pos) atomicOr(&s_flags, FL_COMPLEX);
+                    if (!pos) atomicOr(&S.flags, FL_COMPLEX);
                 }
                 if (l) last_pos = !((ng >> (63 - __clzll((long long)l))) & 1ull);
                 carry = fwd >> 63;
             }
         }
     }
-    __threadfence();
     __syncthreads();
     STAMP();
-    const bool complex = (s_flags & FL_COMPLEX) != 0;
+    const bool complex = (S.flags & FL_COMPLEX) != 0;
 
     if (complex) {
         // ---------------- F: literal scanner (one wavefront), exact for nested components
         if (wave == 0) {
             int nc, np, st;
             literal_frame(lane, F, LAB, NEG, h, ww, prow, pts, cs, cl, max_contours, max_points,
-                          summarised ? s_rowmask : nullptr, &nc, &np, &st);
-            if (lane == 0) { s_lit[0] = nc; s_lit[1] = np; s_lit[2] = st; }
+                          summarised ? S.rowmask : nullptr, &nc, &np, &st);
+            if (lane == 0) { S.lit[0] = nc; S.lit[1] = np; S.lit[2] = st; }
         }
         __threadfence();
         __syncthreads();
-        if (summarised) {
-            clear_labels(tid, LAB, NEG, prow, s_rowmask, s_rows, nrows);
-        } else { // no summary: sweep every word
-            for (int y = tid; y < h; y += CT_THREADS) {
-                const int64_t base = (int64_t)(y + 1) * prow + 1;
-                for (int k = 0; k < ww; k++)
-                    if (F[base + k]) { LAB[base + k] = 0; NEG[base + k] = 0; }
-            }
+        // the literal scanner labels in the global planes: clear what it set (labels only exist where F is set)
+        for (int y = tid; y < h; y += CT_THREADS) {
+            const int64_t base = (int64_t)(y + 1) * prow + 1;
+            const uint32_t occ = summarised ? S.rowmask[y] : ~0u;
+            for (int k = 0; k < ww; k++)
+                if ((k >= 32 || ((occ >> k) & 1u)) && F[base + k]) { LAB[base + k] = 0; NEG[base + k] = 0; }
         }
         if (tid == 0) {
-            n_contours[f] = s_lit[0];
-            n_points[f] = s_lit[1];
-            status[f] = s_lit[2] | RMCV_FRAME_SLOW_PATH;
+            n_contours[f] = S.lit[0];
+            n_points[f] = S.lit[1];
+            status[f] = S.lit[2] | RMCV_FRAME_SLOW_PATH;
         }
         return;
     }
-
     STAMP();
 #ifdef RMCV_PROFILE
     if (tid == 0 && (f == 0 || f == 100))
-        printf("[f%d] rows=%d cand=%d kept=%d pts=%d | summary %.1f T %.1f S %.1f V %.1f clear %.1f us\n", f, nrows, ncand, nkept,
-               s_cursor, (t_[1] - t_[0]) / 100.0, (t_[2] - t_[1]) / 100.0, (t_[3] - t_[2]) / 100.0, (t_[4] - t_[3]) / 100.0,
-               (t_[5] - t_[4]) / 100.0);
+        printf("[f%d] rows=%d slots=%d cand=%d kept=%d pts=%d | tables %.1f T %.1f S %.1f V %.1f us\n", f, nrows, S.nslots, ncand,
+               nkept, S.cursor, (t_[1] - t_[0]) / 100.0, (t_[2] - t_[1]) / 100.0, (t_[3] - t_[2]) / 100.0, (t_[4] - t_[3]) / 100.0);
 #endif
     // discovery order = raster order of the starts: rank the kept entries by key
     for (int e = tid; e < nkept; e += CT_THREADS) {
-        const uint32_t key = s_kkey[e];
+        const uint32_t key = S.kkey[e];
         int rank = 0;
-        for (int j = 0; j < nkept; j++) rank += s_kkey[j] < key;
-        cs[rank] = s_koff[e];
-        cl[rank] = s_klen[e];
+        for (int j = 0; j < nkept; j++) rank += S.kkey[j] < key;
+        cs[rank] = S.koff[e];
+        cl[rank] = S.klen[e];
     }
     if (tid == 0) {
         n_contours[f] = nkept;
-        n_points[f] = s_cursor;
+        n_points[f] = S.cursor;
         status[f] = 0;
     }
 }
@@ -650,9 +665,16 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)
 {
     static const int force_literal = getenv("RMCV_CONTOURS_LITERAL") ? atoi(getenv("RMCV_CONTOURS_LITERAL")) : 0; // dev/test knob
-    hipLaunchKernelGGL(k_contours, dim3(g.n_frames), dim3(CT_THREADS), 0, s, b.bits, b.lab, b.neg, g.w, g.h, g.ww, g.prow, g.plane_pitch,
-                       b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status, lim.max_contours, lim.max_points,
-                       force_literal);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(ContoursLds));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_contours, dim3(g.n_frames), dim3(CT_THREADS), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg,
+                       g.w, g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points,
+                       b.status, lim.max_contours, lim.max_points, force_literal);
     return hipGetLastError();
 }
 

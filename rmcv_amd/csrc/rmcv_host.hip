@@ -134,6 +134,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     Bufs& b = c->bufs;
     if (e == hipSuccess) e = dalloc(c, &b.binary, F * d.max_width * d.max_height);
     if (e == hipSuccess) e = dalloc(c, &b.bits, F * plane);
+    if (e == hipSuccess) e = dalloc(c, &b.rowmask, F * d.max_height);
     if (e == hipSuccess) e = dalloc(c, &b.lab, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.neg, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.points, F * d.max_points);
