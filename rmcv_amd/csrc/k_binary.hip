@@ -27,6 +27,9 @@ namespace rmcv {
 #ifndef RMCV_SR
 #define RMCV_SR 32
 #endif
+#ifndef RMCV_K1_UNROLL
+#define RMCV_K1_UNROLL 4
+#endif
 static constexpr int SR = RMCV_SR; // strip rows per workgroup
 
 // streaming hints (dev knobs): frames are read once, `binary` is written once
@@ -56,19 +59,38 @@ __device__ __forceinline__ uint32_t expand4(uint32_t nib)
     return (((nib & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
 }
 
+// 16 pixels (48 bytes in 12 dwords) -> 16-bit mask of (a - b >= lb), two pixels per packed-16 operation:
+//   v_perm_b32 gathers byte a of pixels p, p+1 into the two halves of a dword (same for b),
+//   t = (A + (0x8000 - lb)) - B per half: bit 15 of a half is set  <=>  a - b - lb >= 0   (|a - b - lb| < 2^15),
+// the flags of the 8 pairs are collected as two 8-bit fields and bit-interleaved once at the end.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 template <int CA, int CB>
 __device__ __forceinline__ uint32_t thresh16(const uint32_t d[12], int lb)
 {
-    uint32_t m = 0;
+    const uint32_t kk = (uint32_t)(0x8000 - lb) & 0xFFFFu;
+    const uint32_t K = kk | (kk << 16);
+    uint32_t acc = 0; // bit i: pixel 2i, bit 16+i: pixel 2i+1
 #pragma unroll
-    for (int p = 0; p < 16; p++) {
-        const int ia = 3 * p + CA, ib = 3 * p + CB;
-        int a = (int)((d[ia >> 2] >> ((ia & 3) * 8)) & 0xFFu);
-        int b = (int)((d[ib >> 2] >> ((ib & 3) * 8)) & 0xFFu);
-        m |= (uint32_t)(a - b >= lb) << p;
+    for (int j = 0; j < 8; j++) {
+        const int ia = 6 * j + CA, ib = 6 * j + CB; // byte offsets of pixel 2j; pixel 2j+1 is 3 bytes further
+        // v_perm_b32(S0, S1, sel): selector 0..3 = bytes of S1, 4..7 = bytes of S0, 0x0c = zero
+        const uint32_t sa = (uint32_t)(ia & 3) | (0x0cu << 8) | ((uint32_t)((ia & 3) + 3) << 16) | (0x0cu << 24);
+        const uint32_t sb = (uint32_t)(ib & 3) | (0x0cu << 8) | ((uint32_t)((ib & 3) + 3) << 16) | (0x0cu << 24);
+        const uint32_t A = __builtin_amdgcn_perm(d[(ia >> 2) + 1 < 12 ? (ia >> 2) + 1 : 11], d[ia >> 2], sa);
+        const uint32_t B = __builtin_amdgcn_perm(d[(ib >> 2) + 1 < 12 ? (ib >> 2) + 1 : 11], d[ib >> 2], sb);
+        u16x2 t = __builtin_bit_cast(u16x2, A) + __builtin_bit_cast(u16x2, K);
+        t = t - __builtin_bit_cast(u16x2, B);
+        acc |= ((__builtin_bit_cast(uint32_t, t) >> 15) & 0x00010001u) << j;
     }
-    return m;
+    // interleave the two 8-bit fields: pixel 2i -> bit 2i, pixel 2i+1 -> bit 2i+1
+    acc = (acc | (acc << 4)) & 0x0F0F0F0Fu;
+    acc = (acc | (acc << 2)) & 0x33333333u;
+    acc = (acc | (acc << 1)) & 0x55555555u;
+    return (acc & 0xFFFFu) | ((acc >> 16) << 1);
 }
+
+// n / d for n < 2^16 with a precomputed reciprocal r = ceil(2^32 / d) (exact in that range); d == 1 gives r == 0
+__device__ __forceinline__ int div_r(int n, uint32_t r) { return r ? (int)__umulhi((uint32_t)n, r) : n; }
 
 // lb is pre-clamped on the host to [1, 256]: lb <= 0 means "everything passes" (lb = -1 flag).
 // LOADV (FAST only): 0 = each lane loads its own 48 contiguous bytes (lane stride 48 B);
@@ -93,6 +115,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     // are in flight on the same L2 at the same time.
     const int tid = threadIdx.x;
     const int wq = ww * 4; // 16-pixel groups per row
+    const uint32_t r_wq = (uint32_t)((0x100000000ull + wq - 1) / wq), r_ww = (uint32_t)((0x100000000ull + ww - 1) / ww);
     const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, jn = gridDim.x >> 3; // gridDim.x is a multiple of 8
     const int per_xcd = (n_blocks + 7) >> 3;
     for (int j = j0; j < per_xcd; j += jn) {
@@ -137,6 +160,49 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
             q += dq;
             if (q >= wq) { q -= wq; rr++; }
         }
+    } else if (FAST) {
+        // U items per thread per iteration: all 3*U loads are issued before the first threshold (memory-level
+        // parallelism per wave), then the items are reduced to bit masks and merged into LDS words
+        constexpr int U = RMCV_K1_UNROLL;
+        const int items = srh * wq;
+        for (int it0 = tid; it0 < items; it0 += 256 * U) {
+            uint4 v[U][3];
+            int rr_[U], q_[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int it = it0 + 256 * u;
+                rr_[u] = div_r(it, r_wq);
+                q_[u] = it - rr_[u] * wq;
+                const int y = y0 - halo + rr_[u];
+                ok[u] = it < items && y >= 0 && y < h;
+#ifdef RMCV_K1_NOLOAD
+                if (ok[u] && lb > 1000) {
+#else
+                if (ok[u]) {
+#endif
+                    const uint4* src = reinterpret_cast<const uint4*>(frame + (int64_t)y * stride + q_[u] * 48);
+                    v[u][0] = ld_stream(src);
+                    v[u][1] = ld_stream(src + 1);
+                    v[u][2] = ld_stream(src + 2);
+                } else {
+                    v[u][0] = v[u][1] = v[u][2] = make_uint4(0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t d[12] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w, v[u][1].x, v[u][1].y,
+                                        v[u][1].z, v[u][1].w, v[u][2].x, v[u][2].y, v[u][2].z, v[u][2].w};
+                uint32_t m = 0;
+                if (ok[u]) m = all_pass ? 0xFFFFu : thresh16<CA, CB>(d, lb);
+                const int q = q_[u];
+                // merge the 4 lanes of a word (lanes are word-aligned: wq % 4 == 0, 256 % 4 == 0)
+                uint32_t x = m << (16 * (q & 1));
+                x |= __shfl_xor(x, 1);
+                const uint32_t o = __shfl_xor(x, 2);
+                if (it0 + 256 * u < items && (q & 3) == 0) T[rr_[u] * ww + (q >> 2)] = ((uint64_t)o << 32) | x;
+            }
+        }
     } else {
         const int items = srh * wq;
         int rr = tid / wq, q = tid - rr * wq;
@@ -145,19 +211,12 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
             const int y = y0 - halo + rr;
             uint32_t m = 0;
             if (y >= 0 && y < h) {
-                if (FAST) {
-                    const uint4* src = reinterpret_cast<const uint4*>(frame + (int64_t)y * stride + q * 48);
-                    uint4 v0 = ld_stream(src), v1 = ld_stream(src + 1), v2 = ld_stream(src + 2);
-                    uint32_t d[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-                    m = all_pass ? 0xFFFFu : thresh16<CA, CB>(d, lb);
-                } else {
-                    const uint8_t* row = frame + (int64_t)y * stride;
-                    for (int p = 0; p < 16; p++) {
-                        int x = q * 16 + p;
-                        if (x < w) {
-                            int a = row[3 * x + CA], bb = row[3 * x + CB];
-                            m |= (uint32_t)(all_pass || (a - bb >= lb)) << p;
-                        }
+                const uint8_t* row = frame + (int64_t)y * stride;
+                for (int p = 0; p < 16; p++) {
+                    int x = q * 16 + p;
+                    if (x < w) {
+                        int a = row[3 * x + CA], bb = row[3 * x + CB];
+                        m |= (uint32_t)(all_pass || (a - bb >= lb)) << p;
                     }
                 }
             }
@@ -180,7 +239,8 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
         // ---------------- phase 2: dilate -> D (rows 1 .. srh-2)
         const int items = (srh - 2) * ww;
         for (int it = tid; it < items; it += 256) {
-            const int rr = 1 + it / ww, k = it % ww;
+            const int r_ = div_r(it, r_ww);
+            const int rr = 1 + r_, k = it - r_ * ww;
             const int y = y0 - halo + rr;
             uint64_t d;
             if (y < 0 || y >= h) {
@@ -206,7 +266,8 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
             // ---------------- phase 3: erode -> T (rows 2 .. srh-3 = the strip)
             const int items3 = SR * ww;
             for (int it = tid; it < items3; it += 256) {
-                const int rr = 2 + it / ww, k = it % ww;
+                const int r_ = div_r(it, r_ww);
+                const int rr = 2 + r_, k = it - r_ * ww;
                 const uint64_t* d0 = D + (rr - 1) * ww;
                 const uint64_t* d1 = D + rr * ww;
                 const uint64_t* d2 = D + (rr + 1) * ww;
@@ -246,6 +307,9 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
                     o.y = expand4(m >> 4);
                     o.z = expand4(m >> 8);
                     o.w = expand4(m >> 12);
+#ifdef RMCV_K1_NOSTORE
+                    if (lb > 1000)
+#endif
                     st_stream(reinterpret_cast<uint4*>(bin + (int64_t)y * w + q * 16), o);
                 } else {
                     for (int p = 0; p < 16; p++) {
@@ -275,7 +339,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     const bool fast = (g.w % 64 == 0) && (g.stride % 16 == 0) && (g.frame_pitch % 16 == 0) &&
                       ((uintptr_t)b.frames % 16 == 0);
     static const int forced = getenv("RMCV_K1_LOADV") ? atoi(getenv("RMCV_K1_LOADV")) : -1; // dev knob for A/B runs
-    const bool coalesced = fast && g.stride == 3 * g.w && forced != 0;
+    const bool coalesced = fast && g.stride == 3 * g.w && forced == 1; // A/B on MI355X: no faster than per-lane 48 B loads
     // persistent grid: RMCV_K1_BPC workgroups per CU (default 6 of the 8 that would fit: 24 of 32 wave slots)
     static const int bpc = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 6;
     static int n_cu = 0;
