@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 plain stream, 1 stress stream")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 (binary only) side measurements")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="contexts/streams the steps are double-buffered over (1 = strictly serial steps)")
     args = ap.parse_args()
 
