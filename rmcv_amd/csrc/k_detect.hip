@@ -2,8 +2,8 @@
 // rm::filter_armours (/root/reference/src/objdetect.cpp:114-166) on the device.
 //
 // k_fit:     one wavefront per contour (findContours order): size/area gate, ellipse fit, ratio/tilt tests.
-// k_blob_compact: one wavefront per frame appends the positives / negatives IN ORDER (ballot + prefix
-//            popcount) and builds the rm::lightblob PODs.
+// k_pairs:   one wavefront per frame appends the positives / negatives IN ORDER (ballot + prefix popcount),
+//            builds the rm::lightblob PODs and runs the pair loop of filter_armours.
 // k_armours: one wavefront per frame; for each i the lanes test 64 partners j > i at once and append the
 //            accepted pairs in (i, j) lexicographic order, again by ballot + prefix popcount.
 #include "device_fit.h"
@@ -229,6 +229,27 @@ __device__ int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n, long 
     return 1;
 }
 
+__device__ int blob_compact_frame(int f, int lane, const int32_t* slot_kind, const rmcv_rrect* slot_ell, int n, int max_contours,
+                                  int enemy, rmcv_lightblob* blobs, int32_t* blob_src, rmcv_rrect* ellipses, int32_t* neg_idx,
+                                  int32_t* n_blobs, int32_t* n_neg, int32_t* status, int max_blobs);
+__device__ void armours_frame(int f, int lane, const rmcv_lightblob* blobs, int n, int max_blobs, float angle_diff_max,
+                              float shear_max, float length_ratio_max, int enemy, rmcv_armour* armours, int32_t* n_armours,
+                              int32_t* status, int max_armours);
+
+struct FitTail { // what k_pairs needs to finish filter_lightblobs and run filter_armours
+    rmcv_lightblob* blobs;
+    int32_t* blob_src;
+    rmcv_rrect* ellipses;
+    int32_t* neg_idx;
+    int32_t* n_blobs;
+    int32_t* n_neg;
+    int32_t* status;
+    rmcv_armour* armours;
+    int32_t* n_armours;
+    int max_blobs, max_armours, enemy, do_pairs;
+    float angle_diff_max, shear_max, length_ratio_max;
+};
+
 // kinds: 0 skipped, 1 positive, 2 negative.  grid (frames, FIT_CHUNKS), 4 wavefronts per block, one contour each.
 static constexpr int FIT_CHUNKS = 8;
 __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ points, const int32_t* __restrict__ cont_start,
@@ -291,16 +312,12 @@ __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ poin
     }
 }
 
-// ordered compaction of the per-contour results into the reference's `positive` / `negative` lists
-__global__ __launch_bounds__(64) void k_blob_compact(const int32_t* __restrict__ slot_kind, const rmcv_rrect* __restrict__ slot_ell,
-                                                    const int32_t* __restrict__ n_contours, int max_contours, int enemy,
-                                                    rmcv_lightblob* __restrict__ blobs, int32_t* __restrict__ blob_src,
-                                                    rmcv_rrect* __restrict__ ellipses, int32_t* __restrict__ neg_idx,
-                                                    int32_t* __restrict__ n_blobs, int32_t* __restrict__ n_neg,
-                                                    int32_t* __restrict__ status, int max_blobs)
+// ordered compaction of the per-contour results of frame f into the reference's `positive` / `negative` lists
+// (one wavefront); returns the number of positives
+__device__ int blob_compact_frame(int f, int lane, const int32_t* slot_kind, const rmcv_rrect* slot_ell, int n, int max_contours,
+                                  int enemy, rmcv_lightblob* blobs, int32_t* blob_src, rmcv_rrect* ellipses, int32_t* neg_idx,
+                                  int32_t* n_blobs, int32_t* n_neg, int32_t* status, int max_blobs)
 {
-    const int f = blockIdx.x, lane = threadIdx.x;
-    const int n = n_contours[f];
     rmcv_lightblob* ob = blobs + (int64_t)f * max_blobs;
     int32_t* osrc = blob_src + (int64_t)f * max_blobs;
     rmcv_rrect* oell = ellipses + (int64_t)f * max_blobs;
@@ -324,14 +341,15 @@ __global__ __launch_bounds__(64) void k_blob_compact(const int32_t* __restrict__
         np += __popcll(mp);
         nn += __popcll(mn_);
     }
+    if (np > max_blobs) {
+        if (lane == 0) atomicOr(&status[f], RMCV_FRAME_OVF_BLOBS);
+        np = max_blobs;
+    }
     if (lane == 0) {
-        if (np > max_blobs) {
-            atomicOr(&status[f], RMCV_FRAME_OVF_BLOBS);
-            np = max_blobs;
-        }
         n_blobs[f] = np;
         n_neg[f] = nn;
     }
+    return np;
 }
 
 __device__ __forceinline__ bool pair_ok(const rmcv_lightblob& a, const rmcv_lightblob& b, float angle_diff_max,
@@ -355,13 +373,11 @@ __device__ __forceinline__ bool pair_ok(const rmcv_lightblob& a, const rmcv_ligh
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_armours(const rmcv_lightblob* __restrict__ blobs, const int32_t* __restrict__ n_blobs,
-                                               int max_blobs, float angle_diff_max, float shear_max,
-                                               float length_ratio_max, int enemy, rmcv_armour* __restrict__ armours,
-                                               int32_t* __restrict__ n_armours, int32_t* __restrict__ status, int max_armours)
+// rm::filter_armours for frame f (one wavefront, n = number of light blobs)
+__device__ void armours_frame(int f, int lane, const rmcv_lightblob* blobs, int n, int max_blobs, float angle_diff_max,
+                              float shear_max, float length_ratio_max, int enemy, rmcv_armour* armours, int32_t* n_armours,
+                              int32_t* status, int max_armours)
 {
-    const int f = blockIdx.x, lane = threadIdx.x;
-    const int n = n_blobs[f];
     const rmcv_lightblob* lb = blobs + (int64_t)f * max_blobs;
     rmcv_armour* out = armours + (int64_t)f * max_armours;
     int na = 0;
@@ -396,6 +412,32 @@ __global__ __launch_bounds__(64) void k_armours(const rmcv_lightblob* __restrict
             na = max_armours;
         }
         n_armours[f] = na;
+    }
+}
+
+// stand-alone pairing (the stage-wise rmcv_filter_armours entry point, or RMCV_STAGE_ARMOURS without RMCV_STAGE_BLOBS)
+__global__ __launch_bounds__(64) void k_armours(const rmcv_lightblob* __restrict__ blobs, const int32_t* __restrict__ n_blobs,
+                                               int max_blobs, float angle_diff_max, float shear_max,
+                                               float length_ratio_max, int enemy, rmcv_armour* __restrict__ armours,
+                                               int32_t* __restrict__ n_armours, int32_t* __restrict__ status, int max_armours)
+{
+    armours_frame(blockIdx.x, threadIdx.x, blobs, n_blobs[blockIdx.x], max_blobs, angle_diff_max, shear_max, length_ratio_max, enemy,
+                  armours, n_armours, status, max_armours);
+}
+
+// the tail of filter_lightblobs (ordered compaction) and filter_armours (pair loop) of one frame in one launch:
+// one wavefront per frame.  (Kept out of k_fit on purpose: folded into k_fit's last-arriving workgroup it cost
+// 26 VGPRs, one wave of occupancy and +0.13 ms on MI355X.)
+__global__ __launch_bounds__(64) void k_pairs(const int32_t* __restrict__ slot_kind, const rmcv_rrect* __restrict__ slot_ell,
+                                             const int32_t* __restrict__ n_contours, int max_contours, FitTail T)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int np = blob_compact_frame(f, lane, slot_kind, slot_ell, n_contours[f], max_contours, T.enemy, T.blobs, T.blob_src,
+                                      T.ellipses, T.neg_idx, T.n_blobs, T.n_neg, T.status, T.max_blobs);
+    if (T.do_pairs) {
+        __threadfence(); // the pair loop re-reads, across lanes, the blobs this wave just wrote
+        armours_frame(f, lane, T.blobs, np, T.max_blobs, T.angle_diff_max, T.shear_max, T.length_ratio_max, T.enemy, T.armours,
+                      T.n_armours, T.status, T.max_armours);
     }
 }
 
@@ -445,16 +487,43 @@ hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& li
     return hipGetLastError();
 }
 
-hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s)
+static hipError_t launch_fit(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s)
 {
     hipLaunchKernelGGL(k_fit, dim3(g.n_frames, FIT_CHUNKS), dim3(256), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
                        lim.max_contours, lim.max_points, p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi, b.slot_kind,
                        b.slot_ell);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_blob_compact, dim3(g.n_frames), dim3(64), 0, s, b.slot_kind, b.slot_ell, b.n_contours, lim.max_contours,
-                       p.camp, b.blobs, b.blob_src, b.ellipses, b.neg_idx, b.n_blobs, b.n_neg, b.status, lim.max_blobs);
+    FitTail T;
+    T.blobs = b.blobs;
+    T.blob_src = b.blob_src;
+    T.ellipses = b.ellipses;
+    T.neg_idx = b.neg_idx;
+    T.n_blobs = b.n_blobs;
+    T.n_neg = b.n_neg;
+    T.status = b.status;
+    T.armours = b.armours;
+    T.n_armours = b.n_armours;
+    T.max_blobs = lim.max_blobs;
+    T.max_armours = lim.max_armours;
+    T.enemy = p.camp;
+    T.do_pairs = pairs ? 1 : 0;
+    T.angle_diff_max = p.angle_diff_max;
+    T.shear_max = p.shear_max;
+    T.length_ratio_max = p.length_ratio_max;
+    hipLaunchKernelGGL(k_pairs, dim3(g.n_frames), dim3(64), 0, s, b.slot_kind, b.slot_ell, b.n_contours, lim.max_contours, T);
     return hipGetLastError();
+}
+
+hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s)
+{
+    return launch_fit(g, b, lim, p, false, s);
+}
+
+// filter_lightblobs + filter_armours: k_fit, then one k_pairs launch for both tails
+hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s)
+{
+    return launch_fit(g, b, lim, p, true, s);
 }
 
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s)

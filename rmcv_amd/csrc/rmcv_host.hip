@@ -207,14 +207,17 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     const Bufs& b = c->bufs;
     int k = 0;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
-    HIPCHK(c, hipMemsetAsync(b.status, 0, (size_t)g.n_frames * 4, s), "memset status");
+    // k_contours writes every frame's status word; without that stage the word is cleared here
+    if (!(stages & RMCV_STAGE_CONTOURS)) HIPCHK(c, hipMemsetAsync(b.status, 0, (size_t)g.n_frames * 4, s), "memset status");
     if (stages & RMCV_STAGE_BINARY) HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, s), "k_binary");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
-    if (stages & RMCV_STAGE_BLOBS) HIPCHK(c, launch_blobs(g, b, c->lim, *p, s), "k_blobs");
+    const bool fused = (stages & RMCV_STAGE_BLOBS) && (stages & RMCV_STAGE_ARMOURS); // one launch for both
+    if (fused) HIPCHK(c, launch_blobs_armours(g, b, c->lim, *p, s), "k_fit");
+    else if (stages & RMCV_STAGE_BLOBS) HIPCHK(c, launch_blobs(g, b, c->lim, *p, s), "k_fit");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
-    if (stages & RMCV_STAGE_ARMOURS) HIPCHK(c, launch_armours(g, b, c->lim, *p, s), "k_armours");
+    if (!fused && (stages & RMCV_STAGE_ARMOURS)) HIPCHK(c, launch_armours(g, b, c->lim, *p, s), "k_armours");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     c->last_stream = s;
     return RMCV_OK;

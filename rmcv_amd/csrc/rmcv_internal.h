@@ -59,6 +59,7 @@ hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
+hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
                                   int32_t* d_frame_offs, hipStream_t s);
 // stage-wise helpers: binary (host-supplied 0/255 image) -> bit plane
