@@ -61,7 +61,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the detection path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -92,10 +93,10 @@ def main():
         with torch.cuda.stream(streams[k]):
             ctxs[k].run(params, STAGE_ALL, streams[k].cuda_stream)
             ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
-            return rdist.gather_records(recs_buf[k]) if world > 1 else [recs_buf[k]]
+            return rdist.gather_records(recs_buf[k]) if use_dist else [recs_buf[k]]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -107,7 +108,7 @@ def main():
         recs = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -194,7 +195,7 @@ def main():
                                "armours": tot}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

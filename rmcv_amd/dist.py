@@ -50,7 +50,7 @@ def fill_record(rec, n_local, cap, frame_offs, armours_u8):
 
 def gather_records(rec, group=None, dst=0):
     """the one collective of the path; returns the list of records on dst, None elsewhere"""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return [rec]
     rank = dist.get_rank(group)
     recs = [torch.empty_like(rec) for _ in range(dist.get_world_size(group))] if rank == dst else None
