@@ -1,0 +1,34 @@
+// TEST-ONLY stand-in for the handful of OpenCV types include/rmcv_shim.hpp touches, so that the shim can be
+// compiled and run in an image without OpenCV.  It is NOT used to build any reference source and is not part of
+// the product; with real OpenCV installed the shim compiles against the real headers instead.
+#pragma once
+#include <cstddef>
+#include <cstdlib>
+#include <stdexcept>
+#include <vector>
+#define CV_8UC1 0
+#define CV_8UC3 16
+#define CV_Assert(x) do { if (!(x)) throw std::runtime_error("CV_Assert: " #x); } while (0)
+namespace cv {
+typedef unsigned char uchar;
+struct Point { int x, y; Point(int x_ = 0, int y_ = 0) : x(x_), y(y_) {} };
+struct Point2f { float x, y; Point2f(float x_ = 0, float y_ = 0) : x(x_), y(y_) {} };
+struct Size2f { float width, height; Size2f(float w = 0, float h = 0) : width(w), height(h) {} };
+struct Rect2f { float x, y, width, height; Rect2f(float x_ = 0, float y_ = 0, float w = 0, float h = 0) : x(x_), y(y_), width(w), height(h) {} };
+struct RotatedRect {
+    Point2f center; Size2f size; float angle;
+    RotatedRect(Point2f c = Point2f(), Size2f s = Size2f(), float a = 0) : center(c), size(s), angle(a) {}
+};
+struct Mat {
+    int rows = 0, cols = 0, type_ = 0; size_t step = 0; uchar* data = nullptr;
+    std::vector<uchar> own;
+    Mat() {}
+    Mat(int r, int c, int t) : rows(r), cols(c), type_(t) { step = (size_t)c * (t == CV_8UC3 ? 3 : 1); own.resize(step * r); data = own.data(); }
+    Mat(int r, int c, int t, void* d) : rows(r), cols(c), type_(t), data((uchar*)d) { step = (size_t)c * (t == CV_8UC3 ? 3 : 1); }
+    Mat(const Mat& o) : rows(o.rows), cols(o.cols), type_(o.type_), step(o.step), data(o.data), own(o.own) { if (!own.empty()) data = own.data(); }
+    Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; type_ = o.type_; step = o.step; own = o.own; data = own.empty() ? o.data : own.data(); return *this; }
+    int type() const { return type_; }
+};
+struct _InputArray { const Mat* m; _InputArray(const Mat& mm) : m(&mm) {} Mat getMat() const { return *m; } };
+typedef const _InputArray& InputArray;
+} // namespace cv

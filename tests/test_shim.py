@@ -1,0 +1,41 @@
+"""include/rmcv_shim.hpp -- the reference's rm:: signatures over the C-ABI -- compiled as C++17 and run end to end.
+OpenCV is absent from this image, so the shim is compiled against tests/cv_mock (a test-only stand-in for the few
+cv:: types it touches; no reference source is built)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.join(ROOT, "tests")
+LIBDIR = os.path.join(ROOT, "rmcv_amd", "lib")
+
+
+def build(tmp):
+    exe = os.path.join(tmp, "shim_main")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(HERE, "cv_mock"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(HERE, "shim_main.cpp"), "-o", exe, "-L", LIBDIR, "-lrmcv_hip", "-Wl,-rpath," + LIBDIR,
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+def test_shim_compiles(tmp_path):
+    assert os.path.exists(build(str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_shim_matches_oracle(tmp_path, oracle):
+    from rmcv_amd import synth
+    exe = build(str(tmp_path))
+    for index in (0, 5):
+        out = subprocess.run([exe, str(index)], check=True, capture_output=True, text=True, timeout=120).stdout.strip().splitlines()
+        ref = oracle.detect_frame(synth.frame(index))
+        head = dict(zip(out[0].split()[0::2], map(int, out[0].split()[1::2])))
+        assert head["contours"] == len(ref["offs"]) - 1 and head["points"] == len(ref["pts"])
+        assert head["binary_on"] == int(np.count_nonzero(ref["binary"])) and head["positive"] == len(ref["blobs"])
+        assert head["armours"] == len(ref["armours"])
+        got = [[float.fromhex(t) for t in line.split()[1:]] for line in out[1:]]
+        exp = [[float(v) for v in a["vertices"].reshape(-1)] for a in ref["armours"]]
+        assert got == exp
