@@ -26,9 +26,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H = 1280, 1024
 FRAMES = 256
-BYTES_PER_FRAME = 4 * W * H          # 3 B/px BGR read + 1 B/px binary written
+WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200)}   # BASELINE.json configs[2] (the metric's config) and configs[4]
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 
@@ -41,15 +40,19 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 plain stream, 1 stress stream")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 (binary only) side measurements")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
+                    help="c3: 1280x1024 full path (the metric's config); c5: 1920x1200 full path + SVM digit classify on the icons")
     ap.add_argument("--streams", type=int, default=3,
                     help="contexts/streams the steps are double-buffered over (1 = strictly serial steps)")
     args = ap.parse_args()
 
+    W, H = WORKLOADS[args.workload]
+    BYTES_PER_FRAME = 4 * W * H      # 3 B/px BGR read + 1 B/px binary written
     import torch
     import torch.distributed as dist
 
-    from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_BINARY, Context, default_params,
-                          synth)
+    from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_BINARY, STAGE_IDENTITY, Context,
+                          default_params, synth)
     from rmcv_amd import dist as rdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,8 +77,12 @@ def main():
     # the HBM-bound pixel kernel of step i+1 streams -- what a continuous camera feed would do.
     ns = max(1, args.streams)
     ctxs = [Context(device=local_rank, max_frames=n, max_width=W, max_height=H) for _ in range(ns)]
+    stages = STAGE_ALL | (STAGE_IDENTITY if args.workload == "c5" else 0)
+    svm = synth.svm_weights() if args.workload == "c5" else None   # svm.xml is not in the reference: seeded stand-in weights
     for c in ctxs:
         c.bind_device_frames(frames.data_ptr(), n, H, W, keepalive=frames)
+        if svm:
+            c.svm_load(*svm)
     ctx = ctxs[0]
     params = default_params()                                     # main.cpp:172-176: BLUE, lb 80, close, ...
     cap = n * 16
@@ -91,7 +98,7 @@ def main():
         k = step_no[0] % ns
         step_no[0] += 1
         with torch.cuda.stream(streams[k]):
-            ctxs[k].run(params, STAGE_ALL, streams[k].cuda_stream)
+            ctxs[k].run(params, stages, streams[k].cuda_stream)
             ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
             return rdist.gather_records(recs_buf[k]) if use_dist else [recs_buf[k]]
 
@@ -129,7 +136,7 @@ def main():
     stage = np.zeros(5)
     reps = max(5, min(args.steps, 20))
     for _ in range(reps):
-        stage += np.asarray(ctx.run_timed(params, STAGE_ALL, sh))
+        stage += np.asarray(ctx.run_timed(params, stages, sh))
     stage /= reps
     k1_ms = float(stage[0])
     achieved = n * BYTES_PER_FRAME / (k1_ms * 1e-3) / 1e9
@@ -145,11 +152,13 @@ def main():
             traffic = None
 
     out = {
-        "metric": "frames/sec (1280x1024 BGR) armour detect", "value": round(value, 1), "unit": "frames/s",
+        "metric": "frames/sec (%dx%d BGR) armour detect" % (W, H), "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "C3: batch=%d/GPU 1280x1024 BGR, blue lb=80, close3x3 + findContours + lightblob fit + armour "
-                               "pairing%s" % (n, " + RCCL gather of armour lists (C4)" if world > 1 else ""),
+        "config": {"workload": "%s: batch=%d/GPU %dx%d BGR, blue lb=80, close3x3 + findContours + lightblob fit + armour "
+                               "pairing%s%s" % (args.workload.upper(), n, W, H,
+                                                " + icon rectification + 7-class linear SVM (synthetic weights)" if svm else "",
+                                                " + RCCL gather of armour lists (C4)" if world > 1 else ""),
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
                    "double_buffered_steps": ns,
                    "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad},
@@ -187,7 +196,10 @@ def main():
         t0 = time.perf_counter()
         tot = 0
         for f in range(m):
-            tot += len(O.detect_frame(host[f], p)["armours"])
+            arm_f = O.detect_frame(host[f], p)["armours"]
+            if svm:
+                O.classify_armours(host[f], arm_f, svm)
+            tot += len(arm_f)
         dc = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(m / dc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": "first %d frames of the same batch, oracle/ full path, 1 thread (the reference "

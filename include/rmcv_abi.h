@@ -97,6 +97,8 @@ typedef struct {            /* capacities of one context; 0 = default */
 #define RMCV_STAGE_BLOBS 4    /* filter_lightblobs                   src/objdetect.cpp:55-87  */
 #define RMCV_STAGE_ARMOURS 8  /* filter_armours                      src/objdetect.cpp:114-166 */
 #define RMCV_STAGE_ALL 15
+#define RMCV_STAGE_IDENTITY 16 /* affine_correction + flatten + svm->predict per armour (BASELINE config 5),
+                                 src/imgproc.cpp:9-35, src/core.cpp:202-216, executable/main.cpp:180-181; needs rmcv_svm_load */
 
 /* per-frame status bits reported by rmcv_batch_counts */
 #define RMCV_FRAME_OVF_CONTOURS 1
@@ -171,6 +173,20 @@ int rmcv_batch_get_armours(rmcv_ctx* ctx, rmcv_armour* armours_out, int cap, int
  * d_armours[frame][per_frame_cap], d_counts[frame] */
 int rmcv_batch_device_views(rmcv_ctx* ctx, void** d_armours, void** d_counts, int32_t* per_frame_cap,
                             int32_t* n_frames);
+
+/* ---- icon classifier: the "next" row of the path (executable/main.cpp:178-181) ------------------------ */
+#define RMCV_SVM_FEATURES 1200 /* 20 x 20 x BGR, executable/main.cpp:180 ({20, 20}), core.cpp:202-216 */
+/* linear one-vs-one C_SVC as cv::ml::SVM keeps it after training (executable/svm/optimizer.cpp:16-19): one weight
+ * vector + rho per class pair (i<j, row-major), class labels in training order.  n_class <= 8. */
+int rmcv_svm_load(rmcv_ctx* ctx, const float* weights /* [n_class*(n_class-1)/2][1200] */, const double* rho,
+                  const int32_t* labels, int n_class);
+/* single frame: identity_out[i] = predict(flatten(affine_correction(frame, armours[i].icon, {20,20})));
+ * armours[i].icon is clamped to the frame in place, exactly as the reference does.  icons_out (n*1200 B) may be NULL. */
+int rmcv_classify_armours(rmcv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, rmcv_armour* armours, int n,
+                          int32_t* identity_out, uint8_t* icons_out);
+/* batch: identities in the order of rmcv_batch_get_armours (after a run that included RMCV_STAGE_IDENTITY) */
+int rmcv_batch_get_identities(rmcv_ctx* ctx, int32_t* identity_out, int cap, int32_t* n_total);
+int rmcv_batch_get_icons(rmcv_ctx* ctx, int frame, uint8_t* icons_out, int cap_armours, int32_t* n_armours);
 
 /* device-side, frame-major compaction into caller-provided HBM (e.g. torch tensors): d_armours_out has room
  * for `cap` armours, d_frame_offs for n_frames+1 int32 (last entry = total, which may exceed cap: then only the

@@ -1214,3 +1214,239 @@ out:
     if (!blobs) free(lbp);
     return rc;
 }
+
+/* ================================================================================================
+ * SURVEY 8f-1 / BASELINE config 5: icon rectification + SVM digit classifier
+ * ================================================================================================ */
+
+/* [OCV] cvRound / saturate_cast<int>(double): round half to even */
+static int cv_round(double v) { return (int)lrint(v); }
+static int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+
+/* [OCV] cv::solve(A, b, x, DECOMP_LU) for a 6x6 system in double: LU with partial pivoting (hal::LU64f) */
+static int lu_solve6(double A[6][6], double b[6])
+{
+    const int m = 6;
+    for (int i = 0; i < m; i++) {
+        int k = i;
+        for (int j = i + 1; j < m; j++)
+            if (fabs(A[j][i]) > fabs(A[k][i])) k = j;
+        if (fabs(A[k][i]) < DBL_EPSILON * 100) return 0;
+        if (k != i) {
+            for (int j = i; j < m; j++) { double t = A[i][j]; A[i][j] = A[k][j]; A[k][j] = t; }
+            double t = b[i]; b[i] = b[k]; b[k] = t;
+        }
+        double d = -1 / A[i][i];
+        for (int j = i + 1; j < m; j++) {
+            double alpha = A[j][i] * d;
+            for (int kk = i + 1; kk < m; kk++) A[j][kk] += alpha * A[i][kk];
+            b[j] += alpha * b[i];
+        }
+    }
+    for (int i = m - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < m; k++) s -= A[i][k] * b[k];
+        b[i] = s / A[i][i];
+    }
+    return 1;
+}
+
+/* [OCV] cv::getAffineTransform(src[3], dst[3]) -> 2x3 double */
+static int get_affine_transform(const float src[3][2], const float dst[3][2], double M[6])
+{
+    double a[6][6], b[6];
+    memset(a, 0, sizeof(a));
+    for (int i = 0; i < 3; i++) {
+        a[2 * i][0] = a[2 * i + 1][3] = src[i][0];
+        a[2 * i][1] = a[2 * i + 1][4] = src[i][1];
+        a[2 * i][2] = a[2 * i + 1][5] = 1;
+        b[2 * i] = dst[i][0];
+        b[2 * i + 1] = dst[i][1];
+    }
+    if (!lu_solve6(a, b)) { memset(M, 0, 6 * sizeof(double)); return 0; }
+    memcpy(M, b, 6 * sizeof(double));
+    return 1;
+}
+
+/* [OCV] cv::warpAffine(src ROI, dst, M, dsize = src size, INTER_LINEAR, BORDER_CONSTANT 0) for CV_8UC3:
+ * the matrix is inverted, source coordinates are computed in 1/1024 px fixed point and quantised to 1/32 px
+ * (INTER_BITS = 5), the four taps are blended with 15-bit weights (32 - fx)(32 - fy)*32 ... and rounded. */
+static void warp_affine_roi(const uint8_t* src, int sw, int sh, int sstride, const double Min[6], uint8_t* dst /* sw*sh*3 */)
+{
+    double M[6];
+    memcpy(M, Min, sizeof(M));
+    {
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1. / D : 0;
+        double A11 = M[4] * D, A22 = M[0] * D;
+        M[0] = A11; M[1] *= -D;
+        M[3] *= -D; M[4] = A22;
+        double b1 = -M[0] * M[2] - M[1] * M[5];
+        double b2 = -M[3] * M[2] - M[4] * M[5];
+        M[2] = b1; M[5] = b2;
+    }
+    const int AB_BITS = 10, AB_SCALE = 1 << 10, INTER_BITS = 5, TAB = 32;
+    const int round_delta = AB_SCALE / TAB / 2;
+    for (int y = 0; y < sh; y++) {
+        const int X0 = cv_round((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+        const int Y0 = cv_round((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+        for (int x = 0; x < sw; x++) {
+            const int adelta = cv_round(M[0] * x * AB_SCALE), bdelta = cv_round(M[3] * x * AB_SCALE);
+            const int X = (X0 + adelta) >> (AB_BITS - INTER_BITS), Y = (Y0 + bdelta) >> (AB_BITS - INTER_BITS);
+            int sx = X >> INTER_BITS, sy = Y >> INTER_BITS;
+            if (sx > 32767) sx = 32767; if (sx < -32768) sx = -32768; /* saturate_cast<short> */
+            if (sy > 32767) sy = 32767; if (sy < -32768) sy = -32768;
+            const int fx = X & (TAB - 1), fy = Y & (TAB - 1);
+            int w00 = (TAB - fx) * (TAB - fy) * 32, w01 = fx * (TAB - fy) * 32, w10 = (TAB - fx) * fy * 32, w11 = fx * fy * 32;
+            if (w00 > 32767) { w00 = 32767; w11 += 1; } /* saturate_cast<short>(32768) and the table's sum correction */
+            uint8_t* d = dst + ((size_t)y * sw + x) * 3;
+            for (int c = 0; c < 3; c++) {
+                int v00 = 0, v01 = 0, v10 = 0, v11 = 0; /* BORDER_CONSTANT, value 0, outside the ROI */
+                if (sy >= 0 && sy < sh) {
+                    if (sx >= 0 && sx < sw) v00 = src[(size_t)sy * sstride + 3 * sx + c];
+                    if (sx + 1 >= 0 && sx + 1 < sw) v01 = src[(size_t)sy * sstride + 3 * (sx + 1) + c];
+                }
+                if (sy + 1 >= 0 && sy + 1 < sh) {
+                    if (sx >= 0 && sx < sw) v10 = src[(size_t)(sy + 1) * sstride + 3 * sx + c];
+                    if (sx + 1 >= 0 && sx + 1 < sw) v11 = src[(size_t)(sy + 1) * sstride + 3 * (sx + 1) + c];
+                }
+                int v = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+                d[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+    }
+}
+
+/* [OCV] cv::resize(src, dst, 20x20, INTER_LINEAR) for CV_8UC3: 11-bit fixed-point coefficients; an exact 2:1
+ * decimation is done as INTER_AREA (2x2 box, rounded) */
+static void resize_linear_20(const uint8_t* src, int sw, int sh, uint8_t* dst /* 20*20*3 */)
+{
+    const int dw = ORC_ICON_SIDE, dh = ORC_ICON_SIDE;
+    if (sw == 2 * dw && sh == 2 * dh) {
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < 3; c++) {
+                    const uint8_t* s0 = src + ((size_t)(2 * y) * sw + 2 * x) * 3 + c;
+                    const uint8_t* s1 = s0 + (size_t)sw * 3;
+                    dst[(y * dw + x) * 3 + c] = (uint8_t)((s0[0] + s0[3] + s1[0] + s1[3] + 2) >> 2);
+                }
+        return;
+    }
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int xofs[ORC_ICON_SIDE], yofs[ORC_ICON_SIDE];
+    short ia[ORC_ICON_SIDE][2], ib[ORC_ICON_SIDE][2];
+    int xmax = dw;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor_f(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= sw) {
+            if (dx < xmax) xmax = dx;
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        }
+        xofs[dx] = sx;
+        ia[dx][0] = (short)cv_round((1.f - fx) * 2048);
+        ia[dx][1] = (short)cv_round(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor_f(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ib[dy][0] = (short)cv_round((1.f - fy) * 2048);
+        ib[dy][1] = (short)cv_round(fy * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        int sy0 = yofs[dy], sy1 = yofs[dy] + 1;
+        if (sy0 < 0) sy0 = 0; if (sy0 > sh - 1) sy0 = sh - 1; /* clip(sy + k, 0, ssize.height) */
+        if (sy1 < 0) sy1 = 0; if (sy1 > sh - 1) sy1 = sh - 1;
+        for (int dx = 0; dx < dw; dx++)
+            for (int c = 0; c < 3; c++) {
+                int r0, r1;
+                const int sx = xofs[dx];
+                if (dx < xmax) {
+                    r0 = src[((size_t)sy0 * sw + sx) * 3 + c] * ia[dx][0] + src[((size_t)sy0 * sw + sx + 1) * 3 + c] * ia[dx][1];
+                    r1 = src[((size_t)sy1 * sw + sx) * 3 + c] * ia[dx][0] + src[((size_t)sy1 * sw + sx + 1) * 3 + c] * ia[dx][1];
+                } else {
+                    r0 = src[((size_t)sy0 * sw + sx) * 3 + c] * 2048;
+                    r1 = src[((size_t)sy1 * sw + sx) * 3 + c] * 2048;
+                }
+                const int v = (((ib[dy][0] * (r0 >> 4)) >> 16) + ((ib[dy][1] * (r1 >> 4)) >> 16) + 2) >> 2;
+                dst[(dy * dw + dx) * 3 + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+    }
+}
+
+int orc_affine_correction(const uint8_t* bgr, int w, int h, int stride, float icon[4][2], uint8_t* out)
+{
+    /* imgproc.cpp:11-15 */
+    for (int i = 0; i < 4; i++) {
+        float vx = icon[i][0] < (float)w - 1 ? icon[i][0] : (float)w - 1; /* std::min(v, cols - 1) */
+        icon[i][0] = 0.0f > vx ? 0.0f : vx;                               /* std::max(0, .) */
+        float vy = icon[i][1] < (float)h - 1 ? icon[i][1] : (float)h - 1;
+        icon[i][1] = 0.0f > vy ? 0.0f : vy;
+    }
+    /* :17 boundingRect(vector<Point>(vertices)): Point2f -> Point rounds (cvRound); int points: inclusive box */
+    int minx = 0, maxx = 0, miny = 0, maxy = 0;
+    for (int i = 0; i < 4; i++) {
+        const int px = cv_round(icon[i][0]), py = cv_round(icon[i][1]);
+        if (i == 0 || px < minx) minx = px;
+        if (i == 0 || px > maxx) maxx = px;
+        if (i == 0 || py < miny) miny = py;
+        if (i == 0 || py > maxy) maxy = py;
+    }
+    const int bx = minx, by = miny, bw = maxx - minx + 1, bh = maxy - miny + 1;
+    memset(out, 0, ORC_SVM_FEATURES);
+    if (bw <= 0 || bh <= 0 || bx < 0 || by < 0 || bx + bw > w || by + bh > h) return 1;
+    /* :18-27 */
+    const float srcPts[3][2] = {{icon[1][0] - (float)bx, icon[1][1] - (float)by},
+                                {icon[2][0] - (float)bx, icon[2][1] - (float)by},
+                                {icon[0][0] - (float)bx, icon[0][1] - (float)by}};
+    const float dstPts[3][2] = {{0, 0}, {(float)bw, 0}, {0, (float)bh}};
+    double M[6];
+    get_affine_transform(srcPts, dstPts, M); /* :28 */
+    /* :30-32 warpAffine(source(box), calibration, warp, Size()) -> same size as the ROI; resize to 20x20 */
+    uint8_t* tmp = (uint8_t*)malloc((size_t)bw * bh * 3);
+    if (!tmp) return 1;
+    warp_affine_roi(bgr + (size_t)by * stride + 3 * (size_t)bx, bw, bh, stride, M, tmp);
+    resize_linear_20(tmp, bw, bh, out);
+    free(tmp);
+    return 0;
+}
+
+int orc_svm_predict(const float* x, int n_feat, const float* weights, const double* rho, const int32_t* labels, int n_class)
+{
+    /* [OCV] SVMImpl::predict for C_SVC, LINEAR kernel after optimize_linear_svm: every decision function is one
+     * weight vector; kernel value = float dot accumulated four products at a time into a double */
+    int vote[16] = {0};
+    int dfi = 0;
+    for (int i = 0; i < n_class; i++)
+        for (int j = i + 1; j < n_class; j++, dfi++) {
+            const float* wv = weights + (size_t)dfi * n_feat;
+            double s = 0;
+            int k = 0;
+            for (; k <= n_feat - 4; k += 4) s += wv[k] * x[k] + wv[k + 1] * x[k + 1] + wv[k + 2] * x[k + 2] + wv[k + 3] * x[k + 3];
+            for (; k < n_feat; k++) s += wv[k] * x[k];
+            const float kval = (float)(s * 1.0 + 0.0);
+            const double sum = -rho[dfi] + 1.0 * kval;
+            vote[sum > 0 ? i : j]++;
+        }
+    int best = 0;
+    for (int i = 1; i < n_class; i++)
+        if (vote[i] > vote[best]) best = i;
+    return labels[best];
+}
+
+void orc_classify_armours(const uint8_t* bgr, int w, int h, int stride, orc_armour* armours, int n, const float* weights,
+                          const double* rho, const int32_t* labels, int n_class, int32_t* identity, uint8_t* icons)
+{
+    uint8_t icon[ORC_SVM_FEATURES];
+    float feat[ORC_SVM_FEATURES];
+    for (int i = 0; i < n; i++) {
+        orc_affine_correction(bgr, w, h, stride, armours[i].icon, icon); /* main.cpp:180 */
+        for (int k = 0; k < ORC_SVM_FEATURES; k++) feat[k] = (float)icon[k]; /* flatten_image: reshape(1,1), CV_32FC1 */
+        identity[i] = orc_svm_predict(feat, ORC_SVM_FEATURES, weights, rho, labels, n_class); /* main.cpp:181 */
+        if (icons) memcpy(icons + (size_t)i * ORC_SVM_FEATURES, icon, ORC_SVM_FEATURES);
+    }
+}

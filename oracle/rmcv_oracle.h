@@ -105,6 +105,27 @@ int orc_detect_frame(const uint8_t* bgr, int w, int h, int stride, const orc_par
                      orc_lightblob* blobs, int cap_blobs, int32_t* n_blobs, orc_armour* armours, int cap_armours,
                      int32_t* n_armours);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * "Next" row SURVEY 8f-1 / BASELINE config 5: icon ROI rectification + linear SVM digit classifier,
+ *   rm::affine_correction            /root/reference/src/imgproc.cpp:9-35
+ *   rm::utils::flatten_image         /root/reference/src/core.cpp:202-216
+ *   svm->predict                     /root/reference/executable/main.cpp:180-181
+ *   model shape                      /root/reference/executable/svm/optimizer.cpp:9,16-19  (7-class linear C_SVC)
+ * [OCV] pieces (cvRound, boundingRect on int points, getAffineTransform's LU solve, warpAffine's and resize's 8-bit
+ * fixed-point bilinear, the one-vs-one vote) restate OpenCV 4.8 as recalled -- parity unpinned like the rest. */
+#define ORC_ICON_SIDE 20
+#define ORC_SVM_FEATURES (ORC_ICON_SIDE * ORC_ICON_SIDE * 3)
+
+/* icon: the armour's 4 icon vertices, clamped IN PLACE to the frame like the reference does (imgproc.cpp:11-15).
+ * out: 20x20 BGR u8.  Returns 0, or 1 when the ROI is degenerate (then out is zero-filled). */
+int orc_affine_correction(const uint8_t* bgr, int w, int h, int stride, float icon[4][2], uint8_t* out);
+/* 7-class one-vs-one linear C_SVC: weights[n_df][n_feat] (n_df = n_class*(n_class-1)/2), rho[n_df], labels[n_class] */
+int orc_svm_predict(const float* features, int n_feat, const float* weights, const double* rho, const int32_t* labels, int n_class);
+/* main.cpp:178-181 for every armour of a frame: identity[i] = predict(flatten(affine_correction(icon))) */
+void orc_classify_armours(const uint8_t* bgr, int w, int h, int stride, orc_armour* armours, int n, const float* weights,
+                          const double* rho, const int32_t* labels, int n_class, int32_t* identity, uint8_t* icons /* n*1200 or NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,8 @@ assert POINT.itemsize == 8 and LIGHTBLOB.itemsize == 56 and ARMOUR.itemsize == 8
 OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 CAMP_RED, CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL = 0, 1, 2, -1
 MORPH_NONE, MORPH_DILATE, MORPH_CLOSE = 0, 1, 2
-STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL = 1, 2, 4, 8, 15
+STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY = 1, 2, 4, 8, 15, 16
+SVM_FEATURES = 1200
 FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_SLOW_PATH = 1, 2, 4, 8, 16
 
 EXPORTS = [
@@ -31,6 +32,7 @@ EXPORTS = [
     "rmcv_batch_upload", "rmcv_batch_set_device_frames", "rmcv_batch_run", "rmcv_batch_sync", "rmcv_batch_run_timed",
     "rmcv_batch_counts", "rmcv_batch_get_binary", "rmcv_batch_get_contours", "rmcv_batch_get_blobs",
     "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_batch_compact_armours", "rmcv_synth_frame", "rmcv_synth_checksum",
+    "rmcv_svm_load", "rmcv_classify_armours", "rmcv_batch_get_identities", "rmcv_batch_get_icons",
 ]
 
 

@@ -187,6 +187,42 @@ class Context:
         self._chk(lib().rmcv_batch_compact_armours(self._h, C.c_void_p(d_armours_ptr), int(cap), C.c_void_p(d_frame_offs_ptr),
                                                    C.c_void_p(stream or 0)))
 
+    # ---------------------------------------------------------------- icon classifier (BASELINE config 5)
+    def svm_load(self, weights, rho, labels):
+        """linear one-vs-one C_SVC: weights [n_df, 1200] f32, rho [n_df] f64, labels [n_class] i32"""
+        weights = np.ascontiguousarray(weights, np.float32)
+        rho = np.ascontiguousarray(rho, np.float64)
+        labels = np.ascontiguousarray(labels, np.int32)
+        n_class = len(labels)
+        assert weights.shape == (n_class * (n_class - 1) // 2, abi.SVM_FEATURES) and len(rho) == weights.shape[0]
+        self._chk(lib().rmcv_svm_load(self._h, ptr(weights), ptr(rho), ptr(labels), n_class))
+
+    def classify_armours(self, image, armours):
+        """main.cpp:178-181 for one frame -> (identity int32[n], armours with clamped icon, icons uint8[n,20,20,3])"""
+        image = np.ascontiguousarray(image, np.uint8)
+        h, w, _ = image.shape
+        arm = np.ascontiguousarray(armours, ARMOUR).copy()
+        n = len(arm)
+        ident = np.empty(max(n, 1), np.int32)
+        icons = np.empty((max(n, 1), 20, 20, 3), np.uint8)
+        self._chk(lib().rmcv_classify_armours(self._h, ptr(image), w, h, 3 * w, ptr(arm), n, ptr(ident), ptr(icons)))
+        return ident[:n].copy(), arm, icons[:n].copy()
+
+    def identities(self):
+        n = self.shape[0]
+        cap = n * self.limits.max_armours
+        out = np.empty(cap, np.int32)
+        tot = C.c_int32(0)
+        self._chk(lib().rmcv_batch_get_identities(self._h, ptr(out), cap, C.byref(tot)))
+        return out[:tot.value].copy()
+
+    def icons(self, frame):
+        cap = self.limits.max_armours
+        out = np.empty((cap, 20, 20, 3), np.uint8)
+        na = C.c_int32(0)
+        self._chk(lib().rmcv_batch_get_icons(self._h, int(frame), ptr(out), cap, C.byref(na)))
+        return out[:na.value].copy()
+
     def detect_batch(self, frames, params=None):
         """the whole path of executable/main.cpp:172-176 on a batch of host frames"""
         self.upload(frames)

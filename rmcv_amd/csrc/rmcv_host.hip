@@ -218,6 +218,10 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     else if (stages & RMCV_STAGE_BLOBS) HIPCHK(c, launch_blobs(g, b, c->lim, *p, s), "k_fit");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     if (!fused && (stages & RMCV_STAGE_ARMOURS)) HIPCHK(c, launch_armours(g, b, c->lim, *p, s), "k_armours");
+    if (stages & RMCV_STAGE_IDENTITY) {
+        if (!b.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
+        HIPCHK(c, launch_classify(g, b, c->lim, s), "k_classify");
+    }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     c->last_stream = s;
     return RMCV_OK;
@@ -228,7 +232,7 @@ static int check_params(rmcv_ctx* c, const rmcv_params* p, int stages)
     if (!c) return RMCV_ERR_BAD_ARG;
     if (!p) return fail(c, RMCV_ERR_BAD_ARG, "null params");
     if (p->morph < RMCV_MORPH_NONE || p->morph > RMCV_MORPH_CLOSE) return fail(c, RMCV_ERR_BAD_ARG, "bad morph");
-    if (stages <= 0 || stages > RMCV_STAGE_ALL) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
+    if (stages <= 0 || stages > (RMCV_STAGE_ALL | RMCV_STAGE_IDENTITY)) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
     if (c->geom.n_frames <= 0 || !c->bufs.frames) {
         if (stages & RMCV_STAGE_BINARY) return fail(c, RMCV_ERR_BAD_ARG, "no frames bound");
     }
@@ -439,6 +443,82 @@ int rmcv_batch_compact_armours(rmcv_ctx* c, void* d_armours_out, int cap, void* 
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     HIPCHK(c, launch_compact_armours(c->geom, c->bufs, c->lim, (rmcv_armour*)d_armours_out, cap, (int32_t*)d_frame_offs, s), "k_compact_armours");
     c->last_stream = s;
+    return RMCV_OK;
+}
+
+int rmcv_svm_load(rmcv_ctx* c, const float* weights, const double* rho, const int32_t* labels, int n_class)
+{
+    if (!c || !weights || !rho || !labels || n_class < 2 || n_class > 8) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    const int n_df = n_class * (n_class - 1) / 2;
+    Bufs& b = c->bufs;
+    if (!b.svm_w) {
+        hipError_t e = dalloc(c, &b.svm_w, (size_t)28 * RMCV_SVM_FEATURES);
+        if (e == hipSuccess) e = dalloc(c, &b.svm_rho, 28);
+        if (e == hipSuccess) e = dalloc(c, &b.svm_labels, 8);
+        if (e == hipSuccess) e = dalloc(c, &b.identity, (size_t)c->lim.max_frames * c->lim.max_armours);
+        if (e == hipSuccess) e = dalloc(c, &b.icons, (size_t)c->lim.max_frames * c->lim.max_armours * RMCV_SVM_FEATURES);
+        if (e != hipSuccess) { b.svm_w = nullptr; return fail(c, RMCV_ERR_NOMEM, "svm buffers", e); }
+    }
+    HIPCHK(c, hipMemcpy(b.svm_w, weights, (size_t)n_df * RMCV_SVM_FEATURES * sizeof(float), hipMemcpyHostToDevice), "H2D svm");
+    HIPCHK(c, hipMemcpy(b.svm_rho, rho, (size_t)n_df * sizeof(double), hipMemcpyHostToDevice), "H2D svm");
+    HIPCHK(c, hipMemcpy(b.svm_labels, labels, (size_t)n_class * sizeof(int32_t), hipMemcpyHostToDevice), "H2D svm");
+    b.svm_classes = n_class;
+    return RMCV_OK;
+}
+
+int rmcv_batch_get_identities(rmcv_ctx* c, int32_t* identity_out, int cap, int32_t* n_total)
+{
+    if (!c || !c->bufs.identity) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    const int nf = c->geom.n_frames;
+    std::vector<int32_t> cnt(nf), all((size_t)nf * c->lim.max_armours);
+    HIPCHK(c, hipMemcpy(cnt.data(), c->bufs.n_armours, (size_t)nf * 4, hipMemcpyDeviceToHost), "D2H");
+    HIPCHK(c, hipMemcpy(all.data(), c->bufs.identity, all.size() * 4, hipMemcpyDeviceToHost), "D2H identity");
+    int64_t total = 0;
+    for (int f = 0; f < nf; f++) total += cnt[f];
+    if (n_total) *n_total = (int32_t)total;
+    if (total > cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    int64_t o = 0;
+    for (int f = 0; f < nf; f++)
+        for (int a = 0; a < cnt[f]; a++) identity_out[o++] = all[(size_t)f * c->lim.max_armours + a];
+    return RMCV_OK;
+}
+
+int rmcv_batch_get_icons(rmcv_ctx* c, int frame, uint8_t* icons_out, int cap_armours, int32_t* n_armours)
+{
+    if (!c || !c->bufs.icons || !icons_out || frame < 0 || frame >= c->geom.n_frames) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    int32_t na = 0;
+    HIPCHK(c, hipMemcpy(&na, c->bufs.n_armours + frame, 4, hipMemcpyDeviceToHost), "D2H");
+    if (n_armours) *n_armours = na;
+    if (na > cap_armours) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    if (na)
+        HIPCHK(c, hipMemcpy(icons_out, c->bufs.icons + (size_t)frame * c->lim.max_armours * RMCV_SVM_FEATURES,
+                            (size_t)na * RMCV_SVM_FEATURES, hipMemcpyDeviceToHost), "D2H icons");
+    return RMCV_OK;
+}
+
+int rmcv_classify_armours(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride, rmcv_armour* armours, int n,
+                          int32_t* identity_out, uint8_t* icons_out)
+{
+    if (!c || !bgr || (n > 0 && (!armours || !identity_out)) || n < 0) return RMCV_ERR_BAD_ARG;
+    if (!c->bufs.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "rmcv_svm_load first");
+    if (n > c->lim.max_armours) return fail(c, RMCV_ERR_CAPACITY, "too many armours for this context");
+    int rc = rmcv_batch_upload(c, bgr, 1, w, h, stride, (int64_t)stride * h);
+    if (rc) return rc;
+    if (n == 0) return RMCV_OK;
+    HIPCHK(c, hipMemcpy(c->bufs.armours, armours, (size_t)n * sizeof(rmcv_armour), hipMemcpyHostToDevice), "H2D armours");
+    HIPCHK(c, hipMemcpy(c->bufs.n_armours, &n, 4, hipMemcpyHostToDevice), "H2D");
+    HIPCHK(c, launch_classify(c->geom, c->bufs, c->lim, c->stream), "k_classify");
+    HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+    HIPCHK(c, hipMemcpy(armours, c->bufs.armours, (size_t)n * sizeof(rmcv_armour), hipMemcpyDeviceToHost), "D2H armours");
+    HIPCHK(c, hipMemcpy(identity_out, c->bufs.identity, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H identity");
+    if (icons_out) HIPCHK(c, hipMemcpy(icons_out, c->bufs.icons, (size_t)n * RMCV_SVM_FEATURES, hipMemcpyDeviceToHost), "D2H icons");
     return RMCV_OK;
 }
 

@@ -52,6 +52,13 @@ struct Bufs {
     rmcv_armour* armours;  // [frame][max_armours]
     int32_t* n_armours;    // [frame]
     int32_t* status;       // [frame] RMCV_FRAME_* bits
+    // icon classifier (BASELINE config 5); allocated by rmcv_svm_load
+    float* svm_w;          // [n_df][1200]
+    double* svm_rho;       // [n_df]
+    int32_t* svm_labels;   // [n_class]
+    int svm_classes;
+    int32_t* identity;     // [frame][max_armours]
+    uint8_t* icons;        // [frame][max_armours][1200]  rectified 20x20 BGR icons
 };
 
 // kernel launchers (each enqueues on `s` and returns the launch error)
@@ -62,6 +69,7 @@ hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const
 hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
                                   int32_t* d_frame_offs, hipStream_t s);
+hipError_t launch_classify(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 // stage-wise helpers: binary (host-supplied 0/255 image) -> bit plane
 hipError_t launch_pack_bits(const Geom& g, const Bufs& b, hipStream_t s);
 // contours in findContours order as CSR (for download); d_offs has max_contours+1 entries per frame

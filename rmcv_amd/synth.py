@@ -29,3 +29,14 @@ def checksum(img):
     h, w, _ = img.shape
     img = np.ascontiguousarray(img)
     return int(lib().rmcv_synth_checksum(ptr(img), w, h, 3 * w))
+
+
+def svm_weights(seed=20241008, n_class=7):
+    """stand-in for the reference's svm.xml, which is not in its repository (.gitignore:40-43): seeded weights with
+    the trained model's shape (executable/svm/optimizer.cpp:9,16-19 -- 7 classes, linear C_SVC, 20*20*3 features):
+    (weights f32 [21, 1200], rho f64 [21], labels i32 [7])"""
+    rng = np.random.default_rng(seed)
+    n_df = n_class * (n_class - 1) // 2
+    w = (rng.standard_normal((n_df, 1200)) * 1e-3).astype(np.float32)
+    rho = (rng.standard_normal(n_df) * 0.05).astype(np.float64)
+    return w, rho, np.arange(n_class, dtype=np.int32)

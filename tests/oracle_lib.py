@@ -183,3 +183,26 @@ def detect_frame(bgr, p=None, cap_pts=1 << 18, cap_contours=1 << 14, cap_blobs=4
     o = offs[:nc.value + 1].copy()
     return dict(binary=binary, pts=pts[:o[-1] if nc.value else 0].copy(), offs=o, blobs=blobs[:nb.value].copy(),
                 armours=arm[:na.value].copy())
+
+
+def affine_correction(bgr, icon):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    ic = np.ascontiguousarray(icon, np.float32).copy()
+    out = np.zeros((20, 20, 3), np.uint8)
+    rc = lib().orc_affine_correction(_p(bgr), w, h, 3 * w, _p(ic), _p(out))
+    return out, ic, rc
+
+
+def classify_armours(bgr, armours, svm):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    arm = np.ascontiguousarray(armours, ARMOUR).copy()
+    n = len(arm)
+    wts, rho, labels = svm
+    ident = np.zeros(max(n, 1), np.int32)
+    icons = np.zeros((max(n, 1), 20, 20, 3), np.uint8)
+    lib().orc_classify_armours(_p(bgr), w, h, 3 * w, _p(arm), n, _p(np.ascontiguousarray(wts, np.float32)),
+                               _p(np.ascontiguousarray(rho, np.float64)), _p(np.ascontiguousarray(labels, np.int32)),
+                               len(labels), _p(ident), _p(icons))
+    return ident[:n].copy(), arm, icons[:n].copy()
