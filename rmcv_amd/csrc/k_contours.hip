@@ -296,16 +296,44 @@ __device__ int walk_record(WWin& W, const uint32_t* F32, int prow, int h, int x0
                        d = (uint32_t)(rl64(W.fw, ly + 1) >> sh) & 7u;
         const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lut[(s_back << 9) | (u << 6) | (m << 3) | d]);
         if ((((uint32_t)y << 16) | (uint32_t)x) < key0) { *state = 2; break; }
-        { // record the step in the lane that owns it -- branch-free (selects, no EXEC change in the hot loop)
-            const uint64_t code = (uint64_t)(e & 15u) << ((n & 15) * 4);
-            const bool mine = (lane == (n >> 5)) && (n < CODE_CAP);
-            c0 |= (mine && !(n & 16)) ? code : 0ull;
-            c1 |= (mine && (n & 16)) ? code : 0ull;
+        // ---- straight vertical runs in one go.  In the steady states "came from the north, go on south" and "came from
+        // the south, go on north" every further pixel of the column is judged with the SAME back direction, so whether
+        // it repeats this very step is a function of its own 3x3 neighbourhood: all 64 window rows evaluate the table
+        // at once (rows above/below via lane shuffles), a ballot gives the length of the run, and its steps are
+        // recorded together.  (Bars are mostly vertical edges: this removes most of the sequential steps.)
+        int extra = 0;
+        const int sdir = (int)(e & 7u);
+        if ((sdir == 6 && s_back == 2) || (sdir == 2 && s_back == 6 && x != x0)) {
+            const uint64_t up = __shfl_up(W.fw, 1), dn = __shfl_down(W.fw, 1);
+            const uint32_t ur = (uint32_t)(up >> sh) & 7u, mr = (uint32_t)(W.fw >> sh) & 7u, dr = (uint32_t)(dn >> sh) & 7u;
+            const bool same = lane >= 1 && lane <= 62 && (uint32_t)lut[(s_back << 9) | (ur << 6) | (mr << 3) | dr] == e;
+            const uint64_t okm = __ballot(same);
+            if (sdir == 6) { // rows below the current one
+                const uint64_t t = ly < 63 ? okm >> (ly + 1) : 0ull;
+                extra = (~t) ? __ffsll((long long)~t) - 1 : 64;
+            } else {         // rows above
+                const uint64_t t = ly > 0 ? okm << (64 - ly) : 0ull;
+                extra = (~t) ? __clzll((long long)~t) : 64;
+                // the raster-smallest pixel of the run is its top end
+                if (extra > 0 && ((((uint32_t)(y - extra)) << 16) | (uint32_t)x) < key0) { *state = 2; break; }
+            }
         }
-        n++;
-        const int cx = x, cy = y;
+        { // record the step(s) in the lanes that own them -- branch-free (selects, no EXEC change in the hot loop)
+            const int a = n - 32 * lane, b = n + extra + 1 - 32 * lane; // this lane owns steps [0,32) of [a,b)
+            const int lo = a < 0 ? 0 : a, hi = b > 32 ? 32 : b;
+            const bool any = lo < hi && n + extra < CODE_CAP;
+            const uint64_t pat = 0x1111111111111111ull * (uint64_t)(e & 15u);
+            // nibble ranges [lo,hi) split over the two 16-step registers
+            const int l0 = lo < 16 ? lo : 16, h0 = hi < 16 ? hi : 16, l1 = lo > 16 ? lo - 16 : 0, h1 = hi > 16 ? hi - 16 : 0;
+            const uint64_t m0 = (h0 >= 16 ? ~0ull : ((1ull << (4 * h0)) - 1)) & ~((1ull << (4 * l0)) - 1);
+            const uint64_t m1 = (h1 >= 16 ? ~0ull : ((1ull << (4 * h1)) - 1)) & ~((1ull << (4 * l1)) - 1);
+            c0 |= (any && l0 < h0) ? (pat & m0) : 0ull;
+            c1 |= (any && l1 < h1) ? (pat & m1) : 0ull;
+        }
+        n += 1 + extra;
+        const int cx = x, cy = y + extra * ((int)((e >> 6) & 3u) - 1);
         x += (int)((e >> 4) & 3u) - 1;
-        y += (int)((e >> 6) & 3u) - 1;
+        y += (1 + extra) * ((int)((e >> 6) & 3u) - 1);
         if (x == x0 && y == y0 && cx == x1 && cy == y1) break; // i4 == i0 && i3 == i1
         if (n >= (1 << 22)) break;                             // cannot happen on a consistent plane
         const int wx = x - W.xb, wy = y - W.wy0;
@@ -337,14 +365,26 @@ struct LabelStore {
     __device__ __forceinline__ int slot(int y, int k) const { return rowbase[y] + __popc(rowmask[y] & ((1u << k) - 1u)); }
 };
 
-// all lanes replay their 32 recorded steps: points -> out[0..n), labels -> the LDS label store (n <= CODE_CAP)
+// all lanes replay the recorded steps: points -> out[0..n), labels -> the LDS label store (n <= CODE_CAP).
+// The codes sit 32 per lane (lane n>>5); the replay spreads them over all 64 lanes, spl = 1, 2, 4 .. 32 consecutive
+// steps per lane (each lane fetches its owner's code registers with a shuffle), so a 150-point contour costs 4
+// dependent LDS round trips per lane instead of 32.
 __device__ void replay_emit(int n, int x0, int y0, int lane, uint64_t c0, uint64_t c1, rmcv_point* out, const LabelStore& LS)
 {
-    int cnt = n - 32 * lane;
-    cnt = cnt < 0 ? 0 : (cnt > 32 ? 32 : cnt);
+    int spl = 1;
+    while (spl * 64 < n) spl <<= 1; // <= 32 because n <= CODE_CAP
+    const int first = lane * spl;
+    int cnt = n - first;
+    cnt = cnt < 0 ? 0 : (cnt > spl ? spl : cnt);
+    const int owner = (first >> 5) & 63, sub = first & 31;
+    const uint64_t o0 = __shfl(c0, owner), o1 = __shfl(c1, owner);
+    // the lane's codes, 4 bits each, starting at bit 0 (sub is a multiple of spl, so the run never straddles c0/c1
+    // unless spl == 32, where sub == 0)
+    const uint64_t lo = sub < 16 ? (o0 >> (4 * sub)) : (o1 >> (4 * (sub - 16)));
+    const uint64_t hi = o1; // only used when spl == 32 (steps 16..31)
     int dx = 0, dy = 0;
     for (int j = 0; j < cnt; j++) {
-        const int sdir = (int)(((j < 16 ? c0 >> (4 * j) : c1 >> (4 * (j - 16)))) & 7u);
+        const int sdir = (int)((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16))) & 7u);
         dx += dir_dx(sdir);
         dy += dir_dy(sdir);
     }
@@ -352,11 +392,11 @@ __device__ void replay_emit(int n, int x0, int y0, int lane, uint64_t c0, uint64
     int pslot = -1, py = -1, pk = -1; // pending label word
     unsigned long long plab = 0, pneg = 0;
     for (int j = 0; j < cnt; j++) {
-        const uint32_t code = (uint32_t)((j < 16 ? c0 >> (4 * j) : c1 >> (4 * (j - 16)))) & 15u;
+        const uint32_t code = (uint32_t)(j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16))) & 15u;
         rmcv_point p;
         p.x = x;
         p.y = y;
-        out[32 * lane + j] = p;
+        out[first + j] = p;
         if (y != py || (x >> 6) != pk) {
             if (plab) atomicOr(LS.lab + pslot, plab);
             if (pneg) atomicOr(LS.neg + pslot, pneg);
@@ -404,6 +444,7 @@ struct ContoursLds {
     int scan[CT_THREADS];
     uint8_t lut[4096];
     int ncand, next, nkept, cursor, flags, nrows, nslots, lit[3];
+    int dummy[64]; // per-lane sinks: lanes != 0 add 0 here so that a wave-wide atomic does not serialise on one word
 };
 
 __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restrict__ bits, const uint32_t* __restrict__ rowmasks,
@@ -540,17 +581,27 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
         WWin W;
         for (;;) {
             // every lane issues the LDS atomic (lanes != 0 add 0), so the loop control stays wave-uniform
-            const int i = __builtin_amdgcn_readfirstlane(atomicAdd(&S.next, lane == 0 ? 1 : 0));
+            const int i = __builtin_amdgcn_readfirstlane(atomicAdd(lane == 0 ? &S.next : &S.dummy[lane], lane == 0 ? 1 : 0));
             if (i >= ncand) break;
             const uint32_t key0 = S.cand[i];
             const int x0 = (int)(key0 & 0xFFFFu), y0 = (int)(key0 >> 16);
             int state = 0;
             uint64_t c0 = 0, c1 = 0;
+#ifdef RMCV_PROFILE
+            const long long tp0 = wall_clock64();
+#endif
             wwin_load(W, F32, prow, h, x0, y0, lane);
+#ifdef RMCV_PROFILE
+            const long long tp1 = wall_clock64();
+#endif
             const int len = walk_record(W, F32, prow, h, x0, y0, lane, S.lut, &state, &c0, &c1);
+#ifdef RMCV_PROFILE
+            const long long tp2 = wall_clock64();
+            if (f == 0 && lane == 0 && state == 2) printf("[cand f0 w%d i%d] aborted len=%d load %.1f walk %.1f us\n", wave, i, len, (tp1 - tp0) / 100.0, (tp2 - tp1) / 100.0);
+#endif
             if (state == 2) continue; // not the first pixel of its component (or a hole border)
-            const int off = __builtin_amdgcn_readfirstlane(atomicAdd(&S.cursor, lane == 0 ? len : 0));
-            const int slot = __builtin_amdgcn_readfirstlane(atomicAdd(&S.nkept, lane == 0 ? 1 : 0));
+            const int off = __builtin_amdgcn_readfirstlane(atomicAdd(lane == 0 ? &S.cursor : &S.dummy[lane], lane == 0 ? len : 0));
+            const int slot = __builtin_amdgcn_readfirstlane(atomicAdd(lane == 0 ? &S.nkept : &S.dummy[lane], lane == 0 ? 1 : 0));
             if (slot >= KEPT_CAP || slot >= max_contours || off + len > max_points || len > CODE_CAP) {
                 // capacity, or a contour longer than the code registers (> 2048 points): the literal scanner
                 // redoes the frame and reports an overflow exactly
@@ -558,6 +609,9 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
                 continue;
             }
             replay_emit(len, x0, y0, lane, c0, c1, pts + off, LS);
+#ifdef RMCV_PROFILE
+            if (f == 0 && lane == 0) printf("[cand f0 w%d i%d] len=%d load %.1f walk %.1f replay %.1f us (t=%.1f)\n", wave, i, len, (tp1 - tp0) / 100.0, (tp2 - tp1) / 100.0, (wall_clock64() - tp2) / 100.0, (tp0 - t_[2]) / 100.0);
+#endif
             S.kkey[slot] = key0; // same value from every lane
             S.koff[slot] = off;
             S.klen[slot] = len;
