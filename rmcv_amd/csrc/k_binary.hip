@@ -172,8 +172,12 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int it = it0 + 256 * u;
-                rr_[u] = div_r(it, r_wq);
-                q_[u] = it - rr_[u] * wq;
+                const int rq = div_r(it, r_wq);
+                q_[u] = it - rq * wq;
+                // neighbouring strips share halo rows: odd strips sweep top->bottom, even strips bottom->top, so a
+                // shared row is requested by both workgroups at about the same time and one of them hits in L2
+                rr_[u] = (L & 1) ? rq : srh - 1 - rq;
+                if (it >= items) rr_[u] = 0;
                 const int y = y0 - halo + rr_[u];
                 ok[u] = it < items && y >= 0 && y < h;
 #ifdef RMCV_K1_NOLOAD
@@ -340,8 +344,9 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
                       ((uintptr_t)b.frames % 16 == 0);
     static const int forced = getenv("RMCV_K1_LOADV") ? atoi(getenv("RMCV_K1_LOADV")) : -1; // dev knob for A/B runs
     const bool coalesced = fast && g.stride == 3 * g.w && forced == 1; // A/B on MI355X: no faster than per-lane 48 B loads
-    // persistent grid: RMCV_K1_BPC workgroups per CU (default 6 of the 8 that would fit: 24 of 32 wave slots)
-    static const int bpc = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 6;
+    // persistent grid: RMCV_K1_BPC workgroups per CU.  Measured on MI355X: the kernel alone runs equally fast with 4..8
+    // workgroups per CU (0.282-0.285 ms); 4 leaves half of the wave slots to the sparse kernels of the previous batch.
+    static const int bpc = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 4;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -349,7 +354,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
-    int grid = n_cu * (bpc > 0 ? bpc : 6);
+    int grid = n_cu * (bpc > 0 ? bpc : 4);
     if (grid > ((n_blocks + 7) & ~7)) grid = (n_blocks + 7) & ~7;
     grid = (grid + 7) & ~7;
 #define RMCV_K1_LAUNCH(F, V, LDS)                                                                                       \
