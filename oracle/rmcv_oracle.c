@@ -53,38 +53,43 @@ void orc_default_params(orc_params* p)
 
 /* ------------------------------------------------- imgproc.cpp:52-69 (pixel part) */
 
-/* [OCV] cv::dilate, 3x3 rect, anchor centre, BORDER_CONSTANT with the default
- * morphology border value: out-of-image samples never win the max. */
-void orc_dilate3x3(const uint8_t* in, uint8_t* out, int w, int h)
+/* [OCV] cv::dilate / cv::erode, 3x3 rect, anchor centre, BORDER_CONSTANT with the default morphology border
+ * value: out-of-image samples never win (they are simply left out of the max / min).  A 3x3 box max (min) is
+ * separable: rows first, then columns -- same result as the 9-tap form, three passes fewer. */
+static void morph3x3(const uint8_t* in, uint8_t* out, int w, int h, int is_max)
 {
-    for (int y = 0; y < h; y++)
+    uint8_t* tmp = (uint8_t*)malloc((size_t)w * h);
+    if (!tmp) return;
+    for (int y = 0; y < h; y++) {
+        const uint8_t* r = in + (size_t)y * w;
+        uint8_t* t = tmp + (size_t)y * w;
         for (int x = 0; x < w; x++) {
-            uint8_t m = 0;
-            for (int dy = -1; dy <= 1; dy++)
-                for (int dx = -1; dx <= 1; dx++) {
-                    int yy = y + dy, xx = x + dx;
-                    if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
-                    if (in[(size_t)yy * w + xx] > m) m = in[(size_t)yy * w + xx];
-                }
-            out[(size_t)y * w + x] = m;
+            uint8_t m = r[x];
+            if (x > 0) m = is_max ? (r[x - 1] > m ? r[x - 1] : m) : (r[x - 1] < m ? r[x - 1] : m);
+            if (x + 1 < w) m = is_max ? (r[x + 1] > m ? r[x + 1] : m) : (r[x + 1] < m ? r[x + 1] : m);
+            t[x] = m;
         }
+    }
+    for (int y = 0; y < h; y++) {
+        const uint8_t* t1 = tmp + (size_t)y * w;
+        const uint8_t* t0 = y > 0 ? t1 - w : t1;
+        const uint8_t* t2 = y + 1 < h ? t1 + w : t1;
+        uint8_t* o = out + (size_t)y * w;
+        if (is_max)
+            for (int x = 0; x < w; x++) {
+                uint8_t m = t0[x] > t1[x] ? t0[x] : t1[x];
+                o[x] = t2[x] > m ? t2[x] : m;
+            }
+        else
+            for (int x = 0; x < w; x++) {
+                uint8_t m = t0[x] < t1[x] ? t0[x] : t1[x];
+                o[x] = t2[x] < m ? t2[x] : m;
+            }
+    }
+    free(tmp);
 }
-
-/* [OCV] cv::erode, same conventions: out-of-image samples never win the min. */
-void orc_erode3x3(const uint8_t* in, uint8_t* out, int w, int h)
-{
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) {
-            uint8_t m = 255;
-            for (int dy = -1; dy <= 1; dy++)
-                for (int dx = -1; dx <= 1; dx++) {
-                    int yy = y + dy, xx = x + dx;
-                    if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
-                    if (in[(size_t)yy * w + xx] < m) m = in[(size_t)yy * w + xx];
-                }
-            out[(size_t)y * w + x] = m;
-        }
-}
+void orc_dilate3x3(const uint8_t* in, uint8_t* out, int w, int h) { morph3x3(in, out, w, h, 1); }
+void orc_erode3x3(const uint8_t* in, uint8_t* out, int w, int h) { morph3x3(in, out, w, h, 0); }
 
 int orc_extract_binary(const uint8_t* bgr, int w, int h, int stride, int camp, int lower_bound, int morph,
                        uint8_t* binary)
