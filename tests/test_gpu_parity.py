@@ -238,3 +238,49 @@ def test_full_size_batch_properties(oracle):
         assert arm[offs[f]:offs[f + 1]].tobytes() == ref.tobytes(), f
     assert offs[-1] > n
     big.close()
+
+
+# ---------------------------------------------------------------- limits of the fast contour path -> literal scanner
+def _check_contours(c, canvas, oracle):
+    img = np.zeros(canvas.shape + (3,), np.uint8)
+    img[..., 0] = canvas
+    pts, offs, binary = c.extract_color_csr(img, CAMP_BLUE, 80, MORPH_NONE)
+    rp, ro = oracle.find_contours(canvas)
+    assert np.array_equal(binary, canvas) and np.array_equal(offs, ro) and np.array_equal(pts, rp)
+    return len(ro) - 1, len(rp)
+
+
+def test_contours_beyond_fast_path_limits(oracle):
+    from rmcv_amd import Context
+    c = Context(device=0, max_frames=1, max_width=2304, max_height=2200, max_contours=8192, max_points=1 << 18)
+    # (1) one contour longer than the 2048 step codes a wavefront records: a serpentine
+    a = np.zeros((400, 600), np.uint8)
+    for k in range(0, 380, 8):
+        a[k:k + 4, 10:590] = 255
+        a[k + 4:k + 8, (10 if (k // 8) % 2 else 586):(14 if (k // 8) % 2 else 590)] = 255
+    nc, npnt = _check_contours(c, a, oracle)
+    assert nc == 1 and npnt > 2048
+    # (2) a solid frame-filling rectangle: perimeter 2 * (1500 + 900)
+    b = np.zeros((1000, 1600), np.uint8)
+    b[50:950, 50:1550] = 255
+    assert _check_contours(c, b, oracle) == (1, 2 * (1500 + 900) - 4)
+    # (3) more local tops than the candidate queue holds (> 2048 components)
+    d = np.zeros((600, 800), np.uint8)
+    d[::8, ::10] = 255
+    nc, _ = _check_contours(c, d, oracle)
+    assert nc == 75 * 80
+    # (4) taller than the LDS row tables (> 2048 rows) and (5) wider than 32 words (> 2048 px)
+    e = np.zeros((2100, 300), np.uint8)
+    e[5:2090:40, 10:250] = 255
+    e[3:2095, 280] = 255
+    _check_contours(c, e, oracle)
+    g = np.zeros((120, 2300), np.uint8)
+    g[10:100:9, 5:2290] = 255
+    g[10:100, 2295] = 255
+    _check_contours(c, g, oracle)
+    # (6) more non-empty words than the LDS label store holds (> 2048): vertical stripes over 280 rows x 20 words
+    t = np.zeros((300, 1280), np.uint8)
+    t[10:290, ::8] = 255
+    nc, _ = _check_contours(c, t, oracle)
+    assert nc == 160
+    c.close()
