@@ -284,3 +284,31 @@ def test_contours_beyond_fast_path_limits(oracle):
     nc, _ = _check_contours(c, t, oracle)
     assert nc == 160
     c.close()
+
+
+def test_borrowed_device_frames_with_row_and_frame_padding(oracle):
+    """rmcv_batch_set_device_frames on HBM the caller owns (a torch tensor), with a row pitch and a frame pitch that are not
+    the packed 3*w / 3*w*h: the byte-wise loader of k_binary and the fast one must both honour them"""
+    import torch
+    from rmcv_amd import Context
+    dev = torch.device("cuda", 0)
+    for (h, w, stride, extra) in [(96, 200, 3 * 200 + 7, 5), (64, 128, 3 * 128 + 16, 64), (1024, 1280, 3 * 1280, 4096)]:
+        n = 3
+        frames = np.stack([synth.frame(20 + i, w, h) if w >= 64 and h >= 64 else None for i in range(n)])
+        pitch = stride * h + extra
+        buf = torch.zeros(n * pitch + 64, dtype=torch.uint8, device=dev)
+        host = np.zeros(n * pitch, np.uint8)
+        for f in range(n):
+            for y in range(h):
+                host[f * pitch + y * stride:f * pitch + y * stride + 3 * w] = frames[f, y].reshape(-1)
+        buf[:n * pitch] = torch.from_numpy(host).to(dev)
+        c = Context(device=0, max_frames=n, max_width=w, max_height=h)
+        c.bind_device_frames(buf.data_ptr(), n, h, w, stride=stride, frame_pitch=pitch, keepalive=buf)
+        c.run(default_params(), STAGE_ALL)
+        c.sync()
+        arm, offs = c.armours()
+        for f in range(n):
+            ref = oracle.detect_frame(frames[f])
+            assert np.array_equal(c.binary(f), ref["binary"]), (h, w, f)
+            assert arm[offs[f]:offs[f + 1]].tobytes() == ref["armours"].tobytes(), (h, w, f)
+        c.close()
