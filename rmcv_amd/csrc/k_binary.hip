@@ -100,7 +100,8 @@ template <int CA, int CB, bool FAST, int LOADV>
 __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride,
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
-                                                 int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask)
+                                                 int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
+                                                 int* __restrict__ strip_ctr)
 {
     extern __shared__ uint64_t smem[];
     const int halo = morph; // NONE 0, DILATE 1, CLOSE 2
@@ -116,15 +117,22 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     const int tid = threadIdx.x;
     const int wq = ww * 4; // 16-pixel groups per row
     const uint32_t r_wq = (uint32_t)((0x100000000ull + wq - 1) / wq), r_ww = (uint32_t)((0x100000000ull + ww - 1) / ww);
-    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, jn = gridDim.x >> 3; // gridDim.x is a multiple of 8
+    const int xcd = blockIdx.x & 7; // gridDim.x is a multiple of 8
     const int per_xcd = (n_blocks + 7) >> 3;
-    for (int j = j0; j < per_xcd; j += jn) {
+    __shared__ int s_next;
+    for (;;) {
+    // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
+    // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
+    __syncthreads(); // also: the LDS planes of the previous strip are free
+    if (tid == 0) s_next = atomicAdd(&strip_ctr[xcd], 1);
+    __syncthreads();
+    const int j = s_next;
+    if (j >= per_xcd) break;
     const int L = xcd * per_xcd + j;
     if (L >= n_blocks) break;
     const int f = L / strips, strip = L - f * strips;
     const int y0 = strip * SR;
     const uint8_t* frame = frames + (int64_t)f * frame_pitch;
-    __syncthreads(); // the LDS planes of the previous strip are free
 
     // ---------------- phase 1: load + threshold -> T
     if (FAST && LOADV == 1) {
@@ -357,9 +365,13 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     int grid = n_cu * (bpc > 0 ? bpc : 4);
     if (grid > ((n_blocks + 7) & ~7)) grid = (n_blocks + 7) & ~7;
     grid = (grid + 7) & ~7;
+    { // the per-XCD strip queues start at zero
+        hipError_t e = hipMemsetAsync(b.strip_ctr, 0, 8 * sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
 #define RMCV_K1_LAUNCH(F, V, LDS)                                                                                       \
     hipLaunchKernelGGL((k_binary<CA, CB, F, V>), dim3(grid), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, \
-                       g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask)
+                       g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr)
     if (coalesced) RMCV_K1_LAUNCH(true, 1, planes + 4 * 3072);
     else if (fast) RMCV_K1_LAUNCH(true, 0, planes);
     else RMCV_K1_LAUNCH(false, 0, planes);

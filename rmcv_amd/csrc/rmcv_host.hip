@@ -135,6 +135,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.binary, F * d.max_width * d.max_height);
     if (e == hipSuccess) e = dalloc(c, &b.bits, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.rowmask, F * d.max_height);
+    if (e == hipSuccess) e = dalloc(c, &b.strip_ctr, 8);
     if (e == hipSuccess) e = dalloc(c, &b.lab, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.neg, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.points, F * d.max_points);

@@ -8,6 +8,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+def pytest_sessionstart(session):
+    """torch bundles its own HIP runtime; when librmcv_hip.so (system ROCm) initialises the GPU first, a later
+    torch.cuda initialisation in the same process reports "No HIP GPUs".  Tests that hand torch tensors to the
+    library need both, so torch gets the device first (as bench.py does by construction)."""
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
