@@ -443,7 +443,7 @@ struct ContoursLds {
     uint16_t rows[CT_MAXH], rowbase[CT_MAXH];
     int scan[CT_THREADS];
     uint8_t lut[4096];
-    int ncand, next, nkept, cursor, flags, nrows, nslots, lit[3];
+    int ncand, next, nkept, cursor, flags, nrows, nslots, nelig, lit[3];
     int dummy[64]; // per-lane sinks: lanes != 0 add 0 here so that a wave-wide atomic does not serialise on one word
 };
 
@@ -451,7 +451,9 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
                                                         int rm_pitch, uint64_t* lab, uint64_t* neg, int w, int h, int ww, int prow,
                                                         int64_t plane_pitch, rmcv_point* points, int32_t* cont_start,
                                                         int32_t* cont_len, int32_t* n_contours, int32_t* n_points,
-                                                        int32_t* status, int max_contours, int max_points, int force_literal)
+                                                        int32_t* status, int max_contours, int max_points, int force_literal,
+                                                        int32_t* __restrict__ elig, int32_t* __restrict__ n_elig,
+                                                        int32_t* __restrict__ slot_kind)
 {
     extern __shared__ unsigned long long smem_raw[];
     ContoursLds& S = *reinterpret_cast<ContoursLds*>(smem_raw);
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
     STAMP();
     const bool summarised = (h <= CT_MAXH && ww <= 32);
     if (tid == 0) {
-        S.ncand = 0; S.next = 0; S.nkept = 0; S.cursor = 0; S.nrows = 0; S.nslots = 0;
+        S.ncand = 0; S.next = 0; S.nkept = 0; S.cursor = 0; S.nrows = 0; S.nslots = 0; S.nelig = 0;
         S.flags = (force_literal || !summarised) ? FL_COMPLEX : 0;
     }
     lut_build(S.lut, tid, CT_THREADS);
@@ -688,9 +690,19 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
             for (int k = 0; k < ww; k++)
                 if ((k >= 32 || ((occ >> k) & 1u)) && F[base + k]) { LAB[base + k] = 0; NEG[base + k] = 0; }
         }
+        { // work list of the fit stage: contours with at least 6 points (objdetect.cpp:64); the others are "skipped"
+            const int nc = S.lit[0];
+            int32_t* el = elig + (int64_t)f * max_contours;
+            for (int k = tid; k < nc; k += CT_THREADS) {
+                if (cl[k] >= 6) el[atomicAdd(&S.nelig, 1)] = k;
+                else slot_kind[(int64_t)f * max_contours + (nc - 1 - k)] = 0;
+            }
+        }
+        __syncthreads();
         if (tid == 0) {
             n_contours[f] = S.lit[0];
             n_points[f] = S.lit[1];
+            n_elig[f] = S.nelig;
             status[f] = S.lit[2] | RMCV_FRAME_SLOW_PATH;
         }
         return;
@@ -708,10 +720,15 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
         for (int j = 0; j < nkept; j++) rank += S.kkey[j] < key;
         cs[rank] = S.koff[e];
         cl[rank] = S.klen[e];
+        // work list of the fit stage: contours with at least 6 points (objdetect.cpp:64); the others are "skipped"
+        if (S.klen[e] >= 6) elig[(int64_t)f * max_contours + atomicAdd(&S.nelig, 1)] = rank;
+        else slot_kind[(int64_t)f * max_contours + (nkept - 1 - rank)] = 0;
     }
+    __syncthreads();
     if (tid == 0) {
         n_contours[f] = nkept;
         n_points[f] = S.cursor;
+        n_elig[f] = S.nelig;
         status[f] = 0;
     }
 }
@@ -728,7 +745,7 @@ hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipS
     }
     hipLaunchKernelGGL(k_contours, dim3(g.n_frames), dim3(CT_THREADS), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg,
                        g.w, g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points,
-                       b.status, lim.max_contours, lim.max_points, force_literal);
+                       b.status, lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind);
     return hipGetLastError();
 }
 

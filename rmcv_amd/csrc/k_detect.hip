@@ -251,12 +251,13 @@ struct FitTail { // what k_pairs needs to finish filter_lightblobs and run filte
 };
 
 // kinds: 0 skipped, 1 positive, 2 negative.  grid (frames, FIT_CHUNKS), 4 wavefronts per block, one contour each.
-static constexpr int FIT_CHUNKS = 8;
+static constexpr int FIT_CHUNKS = 4; // x 4 wavefronts = 16 contours of a frame at a time (a frame has ~10 with >= 6 points)
 __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ points, const int32_t* __restrict__ cont_start,
                                             const int32_t* __restrict__ cont_len, const int32_t* __restrict__ n_contours,
                                             int max_contours, int max_points, float tilt_max, float ratio_lo, float ratio_hi,
                                             double area_lo, double area_hi, int32_t* __restrict__ slot_kind,
-                                            rmcv_rrect* __restrict__ slot_ell)
+                                            rmcv_rrect* __restrict__ slot_ell, const int32_t* __restrict__ elig,
+                                            const int32_t* __restrict__ n_elig)
 {
     __shared__ WaveLds lds[4];
     const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -265,8 +266,12 @@ __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ poin
     const rmcv_point* pts = points + (int64_t)f * max_points;
     const int32_t* cs = cont_start + (int64_t)f * max_contours;
     const int32_t* cl = cont_len + (int64_t)f * max_contours;
-    for (int c = blockIdx.y * 4 + wave; c < n; c += 4 * gridDim.y) { // c in findContours order; discovery index n-1-c
-        const int k = n - 1 - c;
+    // the work list holds the discovery indices of the contours with >= 6 points (k_contours / load_contours wrote it
+    // and marked the others "skipped"), so wavefronts are only spent on contours that reach the fit
+    const int ne = n_elig[f];
+    for (int e = blockIdx.y * 4 + wave; e < ne; e += 4 * gridDim.y) {
+        const int k = elig[(int64_t)f * max_contours + e];
+        const int c = n - 1 - k; // findContours order
         const int start = cs[k], len = cl[k];
         int kind = 0;
         rmcv_rrect ell = {0, 0, 0, 0, 0};
@@ -491,7 +496,7 @@ static hipError_t launch_fit(const Geom& g, const Bufs& b, const Limits& lim, co
 {
     hipLaunchKernelGGL(k_fit, dim3(g.n_frames, FIT_CHUNKS), dim3(256), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
                        lim.max_contours, lim.max_points, p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi, b.slot_kind,
-                       b.slot_ell);
+                       b.slot_ell, b.elig, b.n_elig);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     FitTail T;

@@ -149,6 +149,8 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.blob_src, F * d.max_blobs);
     if (e == hipSuccess) e = dalloc(c, &b.ellipses, F * d.max_blobs);
     if (e == hipSuccess) e = dalloc(c, &b.neg_idx, F * d.max_contours);
+    if (e == hipSuccess) e = dalloc(c, &b.elig, F * d.max_contours);
+    if (e == hipSuccess) e = dalloc(c, &b.n_elig, F);
     if (e == hipSuccess) e = dalloc(c, &b.slot_kind, F * d.max_contours);
     if (e == hipSuccess) e = dalloc(c, &b.slot_ell, F * d.max_contours);
     if (e == hipSuccess) e = dalloc(c, &b.n_blobs, F);
@@ -552,12 +554,15 @@ static int load_contours(rmcv_ctx* c, const rmcv_point* pts, const int32_t* offs
     if (n < 0 || n > c->lim.max_contours) return fail(c, RMCV_ERR_CAPACITY, "too many contours for this context");
     const int total = n ? offs[n] : 0;
     if (total > c->lim.max_points) return fail(c, RMCV_ERR_CAPACITY, "too many points for this context");
-    std::vector<int32_t> cs(n > 0 ? n : 1), cl(n > 0 ? n : 1);
+    std::vector<int32_t> cs(n > 0 ? n : 1), cl(n > 0 ? n : 1), el;
     for (int i = 0; i < n; i++) {
         if (offs[i + 1] < offs[i]) return fail(c, RMCV_ERR_BAD_ARG, "offs not monotone");
         cs[n - 1 - i] = offs[i];
         cl[n - 1 - i] = offs[i + 1] - offs[i];
     }
+    for (int k = 0; k < n; k++)
+        if (cl[k] >= 6) el.push_back(k); // the fit stage's work list (what k_contours writes in the batch path)
+    const int32_t ne = (int32_t)el.size();
     if (c->geom.n_frames < 1) c->geom.n_frames = 1;
     const Bufs& b = c->bufs;
     int32_t z = 0;
@@ -568,6 +573,9 @@ static int load_contours(rmcv_ctx* c, const rmcv_point* pts, const int32_t* offs
     }
     HIPCHK(c, hipMemcpy(b.n_contours, &n, 4, hipMemcpyHostToDevice), "H2D");
     HIPCHK(c, hipMemcpy(b.n_points, &total, 4, hipMemcpyHostToDevice), "H2D");
+    if (n) HIPCHK(c, hipMemset(b.slot_kind, 0, (size_t)n * 4), "memset slot_kind");
+    if (ne) HIPCHK(c, hipMemcpy(b.elig, el.data(), (size_t)ne * 4, hipMemcpyHostToDevice), "H2D elig");
+    HIPCHK(c, hipMemcpy(b.n_elig, &ne, 4, hipMemcpyHostToDevice), "H2D");
     HIPCHK(c, hipMemcpy(b.status, &z, 4, hipMemcpyHostToDevice), "H2D");
     return RMCV_OK;
 }

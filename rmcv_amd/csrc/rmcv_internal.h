@@ -45,6 +45,8 @@ struct Bufs {
     rmcv_lightblob* blobs; // [frame][max_blobs]
     int32_t* blob_src;     // [frame][max_blobs]   contour index (findContours order)
     rmcv_rrect* ellipses;  // [frame][max_blobs]   the fitted ellipse of each positive
+    int32_t* elig;         // [frame][max_contours] discovery indices of the contours with >= 6 points (fit work list)
+    int32_t* n_elig;       // [frame]
     int32_t* slot_kind;    // [frame][max_contours] per contour: 0 skipped, 1 positive, 2 negative
     rmcv_rrect* slot_ell;  // [frame][max_contours] per contour: fitted ellipse
     int32_t* neg_idx;      // [frame][max_contours]
