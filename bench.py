@@ -93,7 +93,8 @@ def main():
     recs_buf = [rdist.new_record(n, cap, dev) for _ in range(ns)]
     # alternate stream priorities: HIP maps streams of different priority to different hardware queues, which is
     # what lets kernels of two steps actually run concurrently
-    streams = [torch.cuda.Stream(device=dev, priority=-(k % 2)) for k in range(ns)]
+    prios = [int(x) for x in os.environ.get("RMCV_BENCH_PRIOS", "").split(",") if x] or [0, -1]
+    streams = [torch.cuda.Stream(device=dev, priority=prios[k % len(prios)]) for k in range(ns)]
     stream, sh, rec = streams[0], streams[0].cuda_stream, recs_buf[0]
     step_no = [0]
     # software pipeline: stream A carries only k_binary (HBM-bound), stream B (higher priority) the sparse stages;

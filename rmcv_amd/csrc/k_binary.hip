@@ -352,9 +352,11 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
                       ((uintptr_t)b.frames % 16 == 0);
     static const int forced = getenv("RMCV_K1_LOADV") ? atoi(getenv("RMCV_K1_LOADV")) : -1; // dev knob for A/B runs
     const bool coalesced = fast && g.stride == 3 * g.w && forced == 1; // A/B on MI355X: no faster than per-lane 48 B loads
-    // persistent grid: RMCV_K1_BPC workgroups per CU.  Measured on MI355X: the kernel alone runs equally fast with 4..8
-    // workgroups per CU (0.282-0.285 ms); 4 leaves half of the wave slots to the sparse kernels of the previous batch.
-    static const int bpc = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 4;
+    // persistent grid: RMCV_K1_BPC workgroups per CU.  Measured on MI355X: the kernel alone runs equally fast with 2..8
+    // workgroups per CU (0.279-0.285 ms; 0.42 ms with 1).  2 (= 2 of the 8 wave slots of every SIMD) leaves room for the
+    // pixel kernel of the next batch AND the sparse kernels of the previous one on the same CU: with 3 batches in flight
+    // 803 k frames/s against 720 k with 4 per CU (tools/ab_streams.sh).
+    static const int bpc = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 2;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;

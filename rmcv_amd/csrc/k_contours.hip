@@ -428,9 +428,12 @@ __device__ void replay_emit(int n, int x0, int y0, int lane, uint64_t c0, uint64
 //     which are zero between launches (the literal path clears what it set).
 // Non-empty rows/words come from the row masks k_binary writes next to the bit plane (bit k of rowmask[y] = word k
 // of row y is non-zero; a superset is fine).
-static constexpr int CAND_CAP = 2048;
-static constexpr int KEPT_CAP = 1024;
-static constexpr int SLOT_CAP = 2048;  // non-empty words of a frame the LDS label store can hold
+// LDS budget: the workgroup shares its CU with the pixel kernels of the next two batches (2 x 2 x 11.5 KB) and with other
+// frames' workgroups, so the tables are sized for ~50 KB (3 per CU); measured +4-8 % on the 3-stream bench against 75 KB.
+// Frames beyond a capacity take the literal path (tests/test_gpu_parity.py covers each limit).
+static constexpr int CAND_CAP = 1024;
+static constexpr int KEPT_CAP = 512;
+static constexpr int SLOT_CAP = 1024;  // non-empty words of a frame the LDS label store can hold
 static constexpr int CT_THREADS = 512; // 8 wavefronts: the bars of a frame are walked concurrently
 static constexpr int CT_MAXH = 2048;   // rows covered by the LDS row tables (taller/wider frames take the literal path)
 
@@ -456,6 +459,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
                                                         int32_t* __restrict__ slot_kind)
 {
     extern __shared__ unsigned long long smem_raw[];
+    __builtin_amdgcn_s_setprio(3); // latency-bound: issue ahead of the streaming pixel kernel of the next batch sharing the CU
     ContoursLds& S = *reinterpret_cast<ContoursLds*>(smem_raw);
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t* F = bits + (int64_t)f * plane_pitch;

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ poin
                                             const int32_t* __restrict__ n_elig)
 {
     __shared__ WaveLds lds[4];
+    __builtin_amdgcn_s_setprio(3); // latency-bound: issue ahead of the streaming pixel kernel of the next batch sharing the CU
     const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     WaveLds& L = lds[wave];
     const int n = n_contours[f];
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(64) void k_pairs(const int32_t* __restrict__ slot_k
                                              const int32_t* __restrict__ n_contours, int max_contours, FitTail T)
 {
     const int f = blockIdx.x, lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
     const int np = blob_compact_frame(f, lane, slot_kind, slot_ell, n_contours[f], max_contours, T.enemy, T.blobs, T.blob_src,
                                       T.ellipses, T.neg_idx, T.n_blobs, T.n_neg, T.status, T.max_blobs);
     if (T.do_pairs) {

@@ -1,0 +1,11 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/ovl; rm -rf $out; mkdir -p $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/d -- python3 bench.py --steps 30 --warmup 3 --cpu-frames 0 --no-extras > $out/b.json 2> $out/err
+python3 - $out <<'PY'
+import csv, glob, sys
+out = sys.argv[1]
+f = glob.glob(out + "/d/**/*kernel_stats.csv", recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if "rmcv" in r["Name"]: print(r["Name"][:34].ljust(34), r["Calls"], round(float(r["AverageNs"])/1000,1), "us  min", round(float(r["MinNs"])/1000,1), "max", round(float(r["MaxNs"])/1000,1))
+PY
+tail -1 $out/b.json | cut -c1-200
