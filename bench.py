@@ -165,7 +165,20 @@ def main():
     for _ in range(reps):
         stage += np.asarray(ctx.run_timed(params, stages, sh))
     stage /= reps
-    k1_ms = float(stage[0])
+    # the dominant kernel on its own: R back-to-back launches of k_binary between two HIP events recorded on the launch
+    # stream, so the event/launch latency (~20 us, visible in stage_ms.binary) is amortised and the figure is the
+    # kernel's duration, the same quantity rocprofv3 --kernel-trace reports
+    R = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        ctx.run(params, STAGE_BINARY, sh)
+        e0.record(stream)
+        for _ in range(R):
+            ctx.run(params, STAGE_BINARY, sh)
+        e1.record(stream)
+    torch.cuda.synchronize()
+    k1_ms = e0.elapsed_time(e1) / R
     achieved = n * BYTES_PER_FRAME / (k1_ms * 1e-3) / 1e9
 
     traffic = None
@@ -195,7 +208,8 @@ def main():
                      "sum": round(float(stage[4]), 4)},
         "roofline": {"kernel": "k_binary", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME, "avg_launch_ms": round(k1_ms, 4)},
+                     "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME, "avg_launch_ms": round(k1_ms, 4),
+                     "launches_timed": R},
     }
 
     if not args.no_extras and rank == 0:

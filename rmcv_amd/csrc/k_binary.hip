@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
-                                                 int* __restrict__ strip_ctr)
+                                                 int* __restrict__ strip_ctr, uint32_t strip_base)
 {
     extern __shared__ uint64_t smem[];
     const int halo = morph; // NONE 0, DILATE 1, CLOSE 2
@@ -124,12 +124,15 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
     __syncthreads(); // also: the LDS planes of the previous strip are free
-    if (tid == 0) s_next = atomicAdd(&strip_ctr[xcd], 1);
+    // The queue heads run free (no reset between launches): every workgroup of a launch draws until its first index
+    // >= per_xcd, so one launch advances each head by exactly per_xcd + gridDim.x/8 and the host knows the value the
+    // next launch starts from (strip_base, modulo 2^32).
+    if (tid == 0) s_next = (int)((uint32_t)atomicAdd(&strip_ctr[xcd], 1) - strip_base);
     __syncthreads();
     const int j = s_next;
-    if (j >= per_xcd) break;
+    if ((uint32_t)j >= (uint32_t)per_xcd) break;
     const int L = xcd * per_xcd + j;
-    if (L >= n_blocks) break;
+    if (L >= n_blocks) continue; // tail of the last XCD's range: draw on, so that every head advances alike
     const int f = L / strips, strip = L - f * strips;
     const int y0 = strip * SR;
     const uint8_t* frame = frames + (int64_t)f * frame_pitch;
@@ -367,18 +370,17 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     int grid = n_cu * (bpc > 0 ? bpc : 4);
     if (grid > ((n_blocks + 7) & ~7)) grid = (n_blocks + 7) & ~7;
     grid = (grid + 7) & ~7;
-    { // the per-XCD strip queues start at zero
-        hipError_t e = hipMemsetAsync(b.strip_ctr, 0, 8 * sizeof(int), s);
-        if (e != hipSuccess) return e;
-    }
+    const uint32_t base = *b.strip_base; // launches of one context are stream-ordered
 #define RMCV_K1_LAUNCH(F, V, LDS)                                                                                       \
     hipLaunchKernelGGL((k_binary<CA, CB, F, V>), dim3(grid), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, \
-                       g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr)
+                       g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr, base)
     if (coalesced) RMCV_K1_LAUNCH(true, 1, planes + 4 * 3072);
     else if (fast) RMCV_K1_LAUNCH(true, 0, planes);
     else RMCV_K1_LAUNCH(false, 0, planes);
 #undef RMCV_K1_LAUNCH
-    return hipGetLastError();
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) *b.strip_base = base + (uint32_t)((n_blocks + 7) >> 3) + (uint32_t)(grid >> 3);
+    return e;
 }
 
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, hipStream_t s)

@@ -27,6 +27,7 @@ struct rmcv_ctx {
     int32_t* pack_offs = nullptr;
     hipStream_t last_stream = nullptr;
     int geom_w = -1, geom_h = -1; // geometry the planes were zeroed for
+    uint32_t k1_base = 0;         // see Bufs::strip_base
     char err[256] = {0};
     std::vector<void*> allocs;
 };
@@ -159,6 +160,8 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.n_armours, F);
     if (e == hipSuccess) e = dalloc(c, &b.status, F);
     if (e == hipSuccess) {
+        b.strip_base = &c->k1_base;
+        hipMemset(b.strip_ctr, 0, 8 * sizeof(int));
         hipMemset(b.n_contours, 0, F * 4);
         hipMemset(b.n_points, 0, F * 4);
         hipMemset(b.n_blobs, 0, F * 4);

@@ -31,7 +31,8 @@ struct Bufs {
     const uint8_t* frames; // BGR input (owned upload buffer or borrowed)
     uint8_t* binary;       // [frame][h][w]          0/255           (imgproc.cpp:74 returns it)
     uint64_t* bits;        // [frame] padded plane F (closed binary as bits)
-    int* strip_ctr;        // [8] per-XCD strip queue heads of k_binary
+    int* strip_ctr;        // [8] per-XCD strip queue heads of k_binary (free-running, never reset)
+    uint32_t* strip_base;  // HOST word owned by the context: value every queue head has when the next k_binary launch starts
     uint32_t* rowmask;     // [frame][h]  bit k: word k of row y of F is non-zero (rows are h apart; k_binary writes them)
     uint64_t* lab;         // [frame] padded plane: pixel was visited by a border trace
     uint64_t* neg;         // [frame] padded plane: ... and got the negative ("right exit") label
