@@ -27,7 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FRAMES = 256
-WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200)}   # BASELINE.json configs[2] (the metric's config) and configs[4]
+WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200),   # BASELINE.json configs[2] (the metric's config) and configs[4]
+             "legacy": (1280, 1024)}                     # FindLightBlobs (minAreaRect boxes, camp vote) in place of filter_lightblobs
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 
@@ -41,7 +42,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 (binary only) side measurements")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
-                    help="c3: 1280x1024 full path (the metric's config); c5: 1920x1200 full path + SVM digit classify on the icons")
+                    help="c3: 1280x1024 full path (the metric's config); c5: 1920x1200 full path + SVM digit classify on the icons; "
+                         "legacy: c3 with rm::FindLightBlobs(fitEllipse=false) as the blob stage")
     ap.add_argument("--streams", type=int, default=3,
                     help="contexts (buffer sets) the steps are pipelined over (1 = strictly serial steps)")
     ap.add_argument("--mode", choices=("pipeline", "alternate"), default="alternate",
@@ -54,8 +56,8 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_BINARY, STAGE_IDENTITY, Context,
-                          default_params, synth)
+    from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_ARMOURS, STAGE_BINARY, STAGE_BLOBS,
+                          STAGE_IDENTITY, Context, LegacyParams, default_params, synth)
     from rmcv_amd import dist as rdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,6 +90,13 @@ def main():
             c.svm_load(*svm)
     ctx = ctxs[0]
     params = default_params()                                     # main.cpp:172-176: BLUE, lb 80, close, ...
+    legacy = LegacyParams(1.5, 80, 70, 10, 99999, 0) if args.workload == "legacy" else None
+
+    def run_path(c, st, hs):
+        if legacy is not None:
+            c.run_legacy(legacy, params, st, hs)
+        else:
+            c.run(params, st, hs)
     cap = n * 16
     head, _ = rdist.record_layout(n, cap)
     recs_buf = [rdist.new_record(n, cap, dev) for _ in range(ns)]
@@ -112,7 +121,7 @@ def main():
         step_no[0] += 1
         if not pipelined:
             with torch.cuda.stream(streams[k]):
-                ctxs[k].run(params, stages, streams[k].cuda_stream)
+                run_path(ctxs[k], stages, streams[k].cuda_stream)
                 ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
                 return rdist.gather_records(recs_buf[k]) if use_dist else [recs_buf[k]]
         with torch.cuda.stream(sA):
@@ -123,7 +132,7 @@ def main():
         sB = sBs[k % len(sBs)]
         with torch.cuda.stream(sB):
             sB.wait_event(ev_bin[k])
-            ctxs[k].run(params, sparse_stages, sB.cuda_stream)
+            run_path(ctxs[k], sparse_stages, sB.cuda_stream)
             ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), sB.cuda_stream)
             out = rdist.gather_records(recs_buf[k]) if use_dist else [recs_buf[k]]
             ev_done[k].record(sB)
@@ -165,6 +174,17 @@ def main():
     for _ in range(reps):
         stage += np.asarray(ctx.run_timed(params, stages, sh))
     stage /= reps
+    if legacy is not None:      # run_timed drives the current API; time the legacy blob stage (k_match + k_pairs) on its own
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(stream):
+            ctx.run_legacy(legacy, params, STAGE_ALL, sh)
+            ea.record(stream)
+            for _ in range(reps):
+                ctx.run_legacy(legacy, params, STAGE_BLOBS | STAGE_ARMOURS, sh)
+            eb.record(stream)
+        torch.cuda.synchronize()
+        stage[4] += ea.elapsed_time(eb) / reps - stage[2] - stage[3]
+        stage[2], stage[3] = ea.elapsed_time(eb) / reps, 0.0
     # the dominant kernel on its own: R back-to-back launches of k_binary between two HIP events recorded on the launch
     # stream, so the event/launch latency (~20 us, visible in stage_ms.binary) is amortised and the figure is the
     # kernel's duration, the same quantity rocprofv3 --kernel-trace reports
@@ -197,7 +217,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%s: batch=%d/GPU %dx%d BGR, blue lb=80, close3x3 + findContours + lightblob fit + armour "
                                "pairing%s%s" % (args.workload.upper(), n, W, H,
-                                                " + icon rectification + 7-class linear SVM (synthetic weights)" if svm else "",
+                                                (" + icon rectification + 7-class linear SVM (synthetic weights)" if svm else "") +
+                                                (" [legacy blob stage: FindLightBlobs, minAreaRect boxes, camp vote]" if legacy else ""),
                                                 " + RCCL gather of armour lists (C4)" if world > 1 else ""),
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
                    "double_buffered_steps": ns, "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
@@ -234,18 +255,40 @@ def main():
         O.set_math_mode(0)
         m = min(args.cpu_frames, n)
         p = O.default_params()
+
+        def cpu_frame(f):
+            r = O.detect_frame(host[f], p)
+            if legacy is not None:
+                lb = O.find_lightblobs(host[f], r["pts"], r["offs"], 1.5, 80, 70, 10, 99999, False)[0]
+                return O.filter_armours(lb, p)
+            if svm:
+                O.classify_armours(host[f], r["armours"], svm)
+            return r["armours"]
         t0 = time.perf_counter()
         tot = 0
         for f in range(m):
-            arm_f = O.detect_frame(host[f], p)["armours"]
-            if svm:
-                O.classify_armours(host[f], arm_f, svm)
+            arm_f = cpu_frame(f)
             tot += len(arm_f)
         dc = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(m / dc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": "first %d frames of the same batch, oracle/ full path, 1 thread (the reference "
                                          "runs detection on one process_thread)" % m,
                                "armours": tot}
+        # the same port with every host core, frames in parallel (the C calls release the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = min(cores, 16)          # the CPU share of a one-GPU box (the host shows all of its cores to every tenant)
+
+        def one(f):
+            return len(cpu_frame(f))
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            tot_all = sum(ex.map(one, range(n)))
+        dall = time.perf_counter() - t0
+        out["cpu_baseline_all_cores"] = {"value": round(n / dall, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+                                         "sample": "all %d frames of the batch, one frame per task, %d threads (capped at the 16-core share of a "
+                                                   "one-GPU box)" % (n, cores),
+                                         "armours": tot_all}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -106,6 +106,7 @@ typedef struct {            /* capacities of one context; 0 = default */
 #define RMCV_FRAME_OVF_BLOBS 4
 #define RMCV_FRAME_OVF_ARMOURS 8
 #define RMCV_FRAME_SLOW_PATH 16 /* informational: nested components, literal scan was used */
+#define RMCV_FRAME_HULL 32      /* legacy matcher: a contour exceeded the hull tables (dimensions > 4096) or is not a closed border */
 
 typedef struct rmcv_ctx rmcv_ctx;
 
@@ -192,6 +193,35 @@ int rmcv_batch_get_icons(rmcv_ctx* ctx, int frame, uint8_t* icons_out, int cap_a
  * for `cap` armours, d_frame_offs for n_frames+1 int32 (last entry = total, which may exceed cap: then only the
  * first `cap` were written).  Asynchronous on hip_stream.  This is the payload of the multi-GPU gather. */
 int rmcv_batch_compact_armours(rmcv_ctx* ctx, void* d_armours_out, int cap, void* d_frame_offs, void* hip_stream);
+
+/* ---- legacy per-contour matcher: the "next" row SURVEY 8f-2 (src/objdetect.cpp:9-53, 89-112) ---------- */
+typedef struct {            /* the float arguments of rm::MatchLightBlob / rm::FindLightBlobs, include/objdetect.h:22-37 */
+    float   min_ratio, max_ratio; /* aspect-ratio bounds (strict compares, src/objdetect.cpp:20)                */
+    float   tilt_angle;           /* maximal tilt, always judged on the fitted ellipse (src/objdetect.cpp:23-24) */
+    float   min_area, max_area;   /* contourArea bounds (strict compares, src/objdetect.cpp:12)                  */
+    int32_t fit_ellipse;          /* 1: box = cv::fitEllipseDirect, 0: box = cv::minAreaRect (src/objdetect.cpp:16) */
+} rmcv_legacy_params;
+
+/* cv::minAreaRect on one contour (the call of src/objdetect.cpp:16, :69): convex hull + rotating calipers.  pts must be
+ * a border as cv::findContours returns it (8-connected, closed: every column of its bounding box holds a point);
+ * anything else is RMCV_ERR_BAD_ARG. */
+int rmcv_min_area_rect(rmcv_ctx* ctx, const rmcv_point* pts, int n, rmcv_rrect* out);
+/* rm::MatchLightBlob (include/objdetect.h:22-23, src/objdetect.cpp:9-28): *matched = 1 and *box_out set when the
+ * contour passes every gate */
+int rmcv_match_lightblob(rmcv_ctx* ctx, const rmcv_point* pts, int n, const rmcv_legacy_params* lp, rmcv_rrect* box_out,
+                         int32_t* matched);
+/* rm::FindLightBlobs (include/objdetect.h:35-37, src/objdetect.cpp:30-53): every matching contour becomes a light blob
+ * whose camp is voted from the mean B/G/R of `bgr` over the contour's bounding rectangle.  blob_src / boxes_out nullable. */
+int rmcv_find_lightblobs(rmcv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, const rmcv_point* pts,
+                         const int32_t* offs, int n_contours, const rmcv_legacy_params* lp, rmcv_lightblob* blobs_out,
+                         int blobs_cap, int32_t* n_blobs, int32_t* blob_src, rmcv_rrect* boxes_out);
+/* rm::LightBlobOverlap (include/objdetect.h:62, src/objdetect.cpp:89-112).  Host-side predicate over caller memory (a few
+ * float compares, no device work).  right == n reads past the end in the reference (its bound check is off by one):
+ * that case is RMCV_ERR_BAD_ARG here. */
+int rmcv_lightblob_overlap(const rmcv_lightblob* blobs, int n, int left, int right, int32_t* overlap);
+/* batch: like rmcv_batch_run, but RMCV_STAGE_BLOBS runs FindLightBlobs with `lp` on every frame's contours (blobs of all
+ * camps, in findContours order); RMCV_STAGE_ARMOURS then pairs the blobs whose camp is p->camp. */
+int rmcv_batch_run_legacy(rmcv_ctx* ctx, const rmcv_params* p, const rmcv_legacy_params* lp, int stages, void* hip_stream);
 
 /* ---- synthetic stream: host generator, integer-only, bit-reproducible --- */
 int      rmcv_synth_frame(uint8_t* bgr, int w, int h, int stride, uint64_t frame_index, int camp, int variant);

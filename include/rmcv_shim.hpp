@@ -8,6 +8,7 @@
 // Usage: compile this header into ONE translation unit of librmcv in place of
 // those three bodies, after including the reference's own "core.h" (it supplies rm::camp, rm::range,
 // rm::contour, rm::lightblob, rm::armour and the cv:: types), and link librmcv_hip.so.
+// Also the legacy matcher rm::MatchLightBlob / rm::FindLightBlobs / rm::LightBlobOverlap (include/objdetect.h:22-37, 62).
 // The legacy names of the north star are aliased at the bottom (docs/core_8h_source.html:101,114).
 //
 // Every signature mentions cv:: types, so this header only compiles where OpenCV headers exist.
@@ -152,6 +153,55 @@ inline std::vector<armour> filter_armours(std::vector<lightblob>& lightblobs, co
         armours.push_back(a);
     }
     return armours;
+}
+
+// ---- legacy per-contour matcher (include/objdetect.h:22-37, 62; bodies src/objdetect.cpp:9-53, 89-112).  The default
+// argument `fitEllipse = true` lives on the reference's declarations.
+inline bool MatchLightBlob(const rm::contour& contour, float minRatio, float maxRatio, float tiltAngle, float minArea,
+                           float maxArea, cv::RotatedRect& lightBlobBox, bool fitEllipse)
+{
+    std::vector<rmcv_point> pts;
+    pts.reserve(contour.size());
+    for (const auto& p : contour) pts.push_back({p.x, p.y});
+    const rmcv_legacy_params lp = {minRatio, maxRatio, tiltAngle, minArea, maxArea, fitEllipse ? 1 : 0};
+    rmcv_rrect box{};
+    int32_t matched = 0;
+    hip_detail::check(rmcv_match_lightblob(hip_detail::ctx(), pts.data(), (int)pts.size(), &lp, &box, &matched));
+    if (!matched) return false;
+    lightBlobBox = cv::RotatedRect(cv::Point2f(box.cx, box.cy), cv::Size2f(box.w, box.h), box.angle);
+    return true;
+}
+
+inline void FindLightBlobs(std::vector<contour>& contours, std::vector<lightblob>& lightBlobs, float minRatio, float maxRatio,
+                           float tiltAngle, float minArea, float maxArea, const cv::Mat& source, bool fitEllipse)
+{
+    lightBlobs.clear();
+    if (source.channels() != 3) return; // src/objdetect.cpp:35
+    std::vector<rmcv_point> pts;
+    std::vector<int32_t> offs(contours.size() + 1, 0);
+    for (size_t i = 0; i < contours.size(); i++) {
+        for (const auto& p : contours[i]) pts.push_back({p.x, p.y});
+        offs[i + 1] = (int32_t)pts.size();
+    }
+    const rmcv_legacy_params lp = {minRatio, maxRatio, tiltAngle, minArea, maxArea, fitEllipse ? 1 : 0};
+    std::vector<rmcv_lightblob> blobs(contours.size() + 1);
+    int32_t nb = 0;
+    hip_detail::check(rmcv_find_lightblobs(hip_detail::ctx(), source.data, source.cols, source.rows, (int)source.step, pts.data(),
+                                           offs.data(), (int)contours.size(), &lp, blobs.data(), (int)blobs.size(), &nb, nullptr,
+                                           nullptr));
+    lightBlobs.reserve(nb);
+    for (int i = 0; i < nb; i++) lightBlobs.push_back(hip_detail::to_lightblob(blobs[i]));
+}
+
+inline bool LightBlobOverlap(const std::vector<rm::lightblob>& lightBlobs, int leftIndex, int rightIndex)
+{
+    std::vector<rmcv_lightblob> in;
+    in.reserve(lightBlobs.size());
+    for (const auto& b : lightBlobs) in.push_back(hip_detail::from_lightblob(b));
+    int32_t overlap = 0;
+    if (rmcv_lightblob_overlap(in.data(), (int)in.size(), leftIndex, rightIndex, &overlap) != RMCV_OK)
+        throw std::out_of_range("rm::LightBlobOverlap: rightIndex == lightBlobs.size() (the reference reads past the end here)");
+    return overlap != 0;
 }
 
 using LightBlob = lightblob; // pre-2024 API names used by the north star

@@ -126,6 +126,23 @@ int orc_svm_predict(const float* features, int n_feat, const float* weights, con
 void orc_classify_armours(const uint8_t* bgr, int w, int h, int stride, orc_armour* armours, int n, const float* weights,
                           const double* rho, const int32_t* labels, int n_class, int32_t* identity, uint8_t* icons /* n*1200 or NULL */);
 
+/* ------------------------------------------------------------------------------------------------
+ * "Next" row SURVEY 8f-2 (rmcv_oracle_legacy.c): the legacy per-contour matcher
+ *   rm::MatchLightBlob /root/reference/src/objdetect.cpp:9-28, rm::FindLightBlobs :30-53, rm::LightBlobOverlap :89-112
+ * with [OCV] cv::minAreaRect (convexHull + rotating calipers), boundingRect(int points), mean(ROI). */
+int  orc_convex_hull(const orc_point* pts, int n, int32_t* hull_idx);        /* clockwise=false; indices into pts */
+int  orc_convex_hull_pruned(const orc_point* pts, int n, int32_t* hull_idx); /* test cross-check of the kernel's column pruning */
+void orc_min_area_rect(const orc_point* pts, int n, orc_rrect* box);
+int  orc_match_lightblob(const orc_point* pts, int n, float min_ratio, float max_ratio, float tilt_angle, float min_area,
+                         float max_area, int fit_ellipse, orc_rrect* box_out); /* 1 = matched */
+void orc_bounding_rect(const orc_point* pts, int n, int32_t rect[4]);
+int  orc_camp_from_mean(const uint8_t* bgr, int stride, const int32_t rect[4]);
+int  orc_find_lightblobs(const uint8_t* bgr, int w, int h, int stride, const orc_point* pts, const int32_t* offs,
+                         int n_contours, float min_ratio, float max_ratio, float tilt_angle, float min_area, float max_area,
+                         int fit_ellipse, orc_lightblob* blobs, int cap_blobs, int32_t* n_blobs, int32_t* blob_src,
+                         orc_rrect* boxes /* optional, per blob */);
+int  orc_lightblob_overlap(const orc_lightblob* blobs, int n, int left, int right); /* 1/0; -1: right == n (UB in the reference) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ armour-detection hot path, behind the reference's own function names.
 """
 from .abi import (ARMOUR, CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL, CAMP_RED, LIGHTBLOB, MORPH_CLOSE, MORPH_DILATE,
                   MORPH_NONE, POINT, RRECT, STAGE_ALL, STAGE_ARMOURS, STAGE_BINARY, STAGE_BLOBS, STAGE_CONTOURS, STAGE_IDENTITY,
-                  SVM_FEATURES, Limits,
+                  SVM_FEATURES, LegacyParams, Limits,
                   Params, RmcvError, default_params)
 from .api import Context
 

@@ -33,6 +33,7 @@ EXPORTS = [
     "rmcv_batch_counts", "rmcv_batch_get_binary", "rmcv_batch_get_contours", "rmcv_batch_get_blobs",
     "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_batch_compact_armours", "rmcv_synth_frame", "rmcv_synth_checksum",
     "rmcv_svm_load", "rmcv_classify_armours", "rmcv_batch_get_identities", "rmcv_batch_get_icons",
+    "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
 ]
 
 
@@ -42,6 +43,12 @@ class Params(C.Structure):
                 ("ratio_lo", C.c_float), ("ratio_hi", C.c_float), ("area_lo", C.c_double), ("area_hi", C.c_double),
                 ("angle_diff_max", C.c_float), ("shear_max", C.c_float), ("length_ratio_max", C.c_float),
                 ("_pad", C.c_int32)]
+
+
+class LegacyParams(C.Structure):
+    """rmcv_legacy_params: the float arguments of rm::MatchLightBlob / rm::FindLightBlobs (include/objdetect.h:22-37)"""
+    _fields_ = [("min_ratio", C.c_float), ("max_ratio", C.c_float), ("tilt_angle", C.c_float), ("min_area", C.c_float),
+                ("max_area", C.c_float), ("fit_ellipse", C.c_int32)]
 
 
 class Limits(C.Structure):

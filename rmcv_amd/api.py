@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .abi import (ARMOUR, CAMP_BLUE, LIGHTBLOB, MORPH_CLOSE, POINT, RRECT, STAGE_ALL, Limits, Params, RmcvError,
+from .abi import (ARMOUR, CAMP_BLUE, LIGHTBLOB, MORPH_CLOSE, POINT, RRECT, STAGE_ALL, LegacyParams, Limits, Params, RmcvError,
                   default_params, lib, ptr)
 
 
@@ -104,6 +104,56 @@ class Context:
         out = np.zeros(1, RRECT)
         self._chk(lib().rmcv_fit_ellipse(self._h, ptr(pts), len(pts), ptr(out)))
         return out[0]
+
+    # ---------------------------------------------------------------- legacy matcher (src/objdetect.cpp:9-53, 89-112)
+    def min_area_rect(self, pts):
+        """cv::minAreaRect of one contour (stage-wise parity hook)"""
+        pts = np.ascontiguousarray(pts, POINT)
+        out = np.zeros(1, RRECT)
+        self._chk(lib().rmcv_min_area_rect(self._h, ptr(pts), len(pts), ptr(out)))
+        return out[0]
+
+    def match_lightblob(self, contour, min_ratio, max_ratio, tilt_angle, min_area, max_area, fit_ellipse=True):
+        """rm::MatchLightBlob: returns (matched, box)"""
+        pts = np.ascontiguousarray(contour, POINT)
+        lp = LegacyParams(min_ratio, max_ratio, tilt_angle, min_area, max_area, int(bool(fit_ellipse)))
+        out = np.zeros(1, RRECT)
+        m = C.c_int32(0)
+        self._chk(lib().rmcv_match_lightblob(self._h, ptr(pts), len(pts), C.byref(lp), ptr(out), C.byref(m)))
+        return bool(m.value), out[0]
+
+    def find_lightblobs(self, pts, offs, min_ratio, max_ratio, tilt_angle, min_area, max_area, source, fit_ellipse=True):
+        """rm::FindLightBlobs on CSR contours: returns (blobs, blob_src, boxes); camps are voted from `source` (h, w, 3 BGR)"""
+        source = np.ascontiguousarray(source, np.uint8)
+        h, w, ch = source.shape
+        assert ch == 3
+        pts = np.ascontiguousarray(pts, POINT)
+        offs = np.ascontiguousarray(offs, np.int32)
+        n = len(offs) - 1
+        lp = LegacyParams(min_ratio, max_ratio, tilt_angle, min_area, max_area, int(bool(fit_ellipse)))
+        cap = max(n, 1)
+        blobs, src, boxes = np.zeros(cap, LIGHTBLOB), np.zeros(cap, np.int32), np.zeros(cap, RRECT)
+        nb = C.c_int32(0)
+        self._chk(lib().rmcv_find_lightblobs(self._h, ptr(source), w, h, 3 * w, ptr(pts), ptr(offs), n, C.byref(lp), ptr(blobs), cap,
+                                             C.byref(nb), ptr(src), ptr(boxes)))
+        self.shape = (1, h, w)
+        return blobs[:nb.value].copy(), src[:nb.value].copy(), boxes[:nb.value].copy()
+
+    @staticmethod
+    def lightblob_overlap(blobs, left, right):
+        """rm::LightBlobOverlap; raises RmcvError for right == len(blobs), where the reference reads past the end"""
+        blobs = np.ascontiguousarray(blobs, LIGHTBLOB)
+        o = C.c_int32(0)
+        rc = lib().rmcv_lightblob_overlap(ptr(blobs), len(blobs), int(left), int(right), C.byref(o))
+        if rc:
+            raise RmcvError(rc, "rightIndex == size(): out of range in the reference")
+        return bool(o.value)
+
+    def run_legacy(self, legacy, params=None, stages=STAGE_ALL, stream=None):
+        """batch path with rm::FindLightBlobs (legacy: LegacyParams) in place of rm::filter_lightblobs"""
+        self._params = params or default_params()
+        self._legacy = legacy
+        self._chk(lib().rmcv_batch_run_legacy(self._h, C.byref(self._params), C.byref(legacy), int(stages), C.c_void_p(stream or 0)))
 
     # ---------------------------------------------------------------- batch
     def upload(self, frames):

@@ -7,6 +7,7 @@
 // k_armours: one wavefront per frame; for each i the lanes test 64 partners j > i at once and append the
 //            accepted pairs in (i, j) lexicographic order, again by ballot + prefix popcount.
 #include "device_fit.h"
+#include "device_hull.h"
 #include "rmcv_internal.h"
 
 namespace rmcv {
@@ -318,6 +319,102 @@ __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ poin
     }
 }
 
+
+// ---- legacy matcher: rm::MatchLightBlob + the camp vote of rm::FindLightBlobs ----------------------
+// One wavefront per contour of the frame's work list, one wavefront per workgroup (the hull tables take 16 B of LDS per
+// frame column).  mode 0: the matcher (objdetect.cpp:9-28, 43-51); mode 1: cv::minAreaRect alone, every gate open (the
+// stage-wise hook rmcv_min_area_rect).  Results go to the same per-contour slots k_fit uses, so k_pairs does the ordered
+// compaction; a matching contour's slot word is 1 | (camp + 2) << 4.
+struct MatchArgs {
+    float min_ratio, max_ratio, tilt_angle, min_area, max_area;
+    int fit_ellipse, mode, wcap;
+    const uint8_t* frames; // may be null: no camp vote (the blob gets CAMP_NEUTRAL)
+    int64_t frame_pitch;
+    int stride;
+};
+
+static constexpr int MATCH_CHUNKS = 16;
+__global__ __launch_bounds__(64) void k_match(const rmcv_point* __restrict__ points, const int32_t* __restrict__ cont_start,
+                                             const int32_t* __restrict__ cont_len, const int32_t* __restrict__ n_contours,
+                                             int max_contours, int max_points, MatchArgs A, int32_t* __restrict__ slot_kind,
+                                             rmcv_rrect* __restrict__ slot_ell, const int32_t* __restrict__ elig,
+                                             const int32_t* __restrict__ n_elig, int32_t* __restrict__ status)
+{
+    extern __shared__ unsigned long long match_smem[];
+    __builtin_amdgcn_s_setprio(3);
+    const int f = blockIdx.x, lane = threadIdx.x;
+    WaveLds& L = *reinterpret_cast<WaveLds*>(match_smem);
+    HullLds H;
+    hull_lds_carve(reinterpret_cast<unsigned char*>(match_smem) + sizeof(WaveLds), A.wcap, H);
+    const int n = n_contours[f];
+    const rmcv_point* pts = points + (int64_t)f * max_points;
+    const int32_t* cs = cont_start + (int64_t)f * max_contours;
+    const int32_t* cl = cont_len + (int64_t)f * max_contours;
+    const int ne = A.mode == 1 ? n : n_elig[f]; // the hook takes any contour, the matcher only those with >= 6 points
+    for (int e = blockIdx.y; e < ne; e += gridDim.y) {
+        const int k = A.mode == 1 ? e : elig[(int64_t)f * max_contours + e];
+        const int c = n - 1 - k; // findContours order
+        const int start = cs[k], len = cl[k];
+        int word = 0;
+        rmcv_rrect box = {0, 0, 0, 0, 0};
+        if (len >= 1 && start + len <= max_points && (A.mode == 1 || len >= 6)) { // objdetect.cpp:12
+            const rmcv_point* cp = pts + start;
+            double a00 = 0;
+            long long sx = 0, sy = 0;
+            int minx = INT_MAX, maxx = INT_MIN, miny = INT_MAX, maxy = INT_MIN;
+            for (int i = lane; i < len; i += 64) {
+                const rmcv_point p = cp[i], q = cp[i == 0 ? len - 1 : i - 1];
+                a00 += (double)(float)q.x * (float)p.y - (double)(float)q.y * (float)p.x;
+                sx += p.x;
+                sy += p.y;
+                minx = p.x < minx ? p.x : minx;
+                maxx = p.x > maxx ? p.x : maxx;
+                miny = p.y < miny ? p.y : miny;
+                maxy = p.y > maxy ? p.y : maxy;
+            }
+            a00 = wave_sum_f64(a00);
+            sx = wave_sum_i64(sx);
+            sy = wave_sum_i64(sy);
+            for (int d = 32; d >= 1; d >>= 1) {
+                const int a = __shfl_xor(minx, d), b = __shfl_xor(maxx, d), cc = __shfl_xor(miny, d), dd = __shfl_xor(maxy, d);
+                minx = a < minx ? a : minx;
+                maxx = b > maxx ? b : maxx;
+                miny = cc < miny ? cc : miny;
+                maxy = dd > maxy ? dd : maxy;
+            }
+            const int W = maxx - minx + 1, Hh = maxy - miny + 1; // cv::boundingRect on int points: inclusive box
+            const double area = dabs(a00 * 0.5);
+            int ovf = 0;
+            if (minx < 0 || miny < 0 || W > A.wcap || maxy >= HULL_MAX_DIM || len > (1 << 20)) ovf = 1;
+            if (A.mode == 1) {
+                if (!ovf) min_area_rect_wave(cp, len, minx, W, H, lane, &box, &ovf);
+                word = 1;
+            } else if (!(area < A.min_area || area > A.max_area)) { // :12
+                rmcv_rrect ellipse;
+                fit_ellipse_wave(cp, len, sx, sy, L, lane, &ellipse); // :15
+                if (A.fit_ellipse) box = ellipse;
+                else if (!ovf) min_area_rect_wave(cp, len, minx, W, H, lane, &box, &ovf); // :16
+                const float mx = box.w > box.h ? box.w : box.h, mn = box.w < box.h ? box.w : box.h;
+                const float ratio = mx / mn; // :19
+                bool ok = !(ratio > A.max_ratio || ratio < A.min_ratio);
+                const float angle = ellipse.angle > 90 ? ellipse.angle - 90 : ellipse.angle + 90; // :23
+                if (__builtin_fabsf(angle - 90) > A.tilt_angle) ok = false;                       // :24
+                if (ok) {
+                    int camp = RMCV_CAMP_NEUTRAL;
+                    if (A.frames) // :43-51
+                        camp = camp_from_mean_wave(A.frames + (int64_t)f * A.frame_pitch, A.stride, minx, miny, W, Hh, lane);
+                    word = 1 | ((camp + 2) << 4);
+                }
+            }
+            if (ovf && lane == 0 && (A.mode == 1 || !A.fit_ellipse)) atomicOr(&status[f], RMCV_FRAME_HULL);
+        }
+        if (lane == 0) {
+            slot_kind[(int64_t)f * max_contours + c] = word;
+            slot_ell[(int64_t)f * max_contours + c] = box;
+        }
+    }
+}
+
 // ordered compaction of the per-contour results of frame f into the reference's `positive` / `negative` lists
 // (one wavefront); returns the number of positives
 __device__ int blob_compact_frame(int f, int lane, const int32_t* slot_kind, const rmcv_rrect* slot_ell, int n, int max_contours,
@@ -331,13 +428,14 @@ __device__ int blob_compact_frame(int f, int lane, const int32_t* slot_kind, con
     int np = 0, nn = 0;
     for (int base = 0; base < n; base += 64) {
         const int c = base + lane;
-        const int kind = c < n ? slot_kind[(int64_t)f * max_contours + c] : 0;
+        const int word = c < n ? slot_kind[(int64_t)f * max_contours + c] : 0;
+        const int kind = word & 15, camp_code = word >> 4; // the legacy matcher votes a camp per contour (code = camp + 2)
         const uint64_t mp = __ballot(kind == 1), mn_ = __ballot(kind == 2);
         if (kind == 1) {
             const int o = np + lanes_below(mp, lane);
             if (o < max_blobs) {
                 const rmcv_rrect ell = slot_ell[(int64_t)f * max_contours + c];
-                make_lightblob(&ell, enemy, &ob[o]); // :83 -> core.cpp:9-19
+                make_lightblob(&ell, camp_code ? camp_code - 2 : enemy, &ob[o]); // :83 -> core.cpp:9-19
                 osrc[o] = c;
                 oell[o] = ell;
             }
@@ -494,13 +592,8 @@ hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& li
     return hipGetLastError();
 }
 
-static hipError_t launch_fit(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s)
+static hipError_t launch_pairs_tail(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fit, dim3(g.n_frames, FIT_CHUNKS), dim3(256), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
-                       lim.max_contours, lim.max_points, p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi, b.slot_kind,
-                       b.slot_ell, b.elig, b.n_elig);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
     FitTail T;
     T.blobs = b.blobs;
     T.blob_src = b.blob_src;
@@ -520,6 +613,46 @@ static hipError_t launch_fit(const Geom& g, const Bufs& b, const Limits& lim, co
     T.length_ratio_max = p.length_ratio_max;
     hipLaunchKernelGGL(k_pairs, dim3(g.n_frames), dim3(64), 0, s, b.slot_kind, b.slot_ell, b.n_contours, lim.max_contours, T);
     return hipGetLastError();
+}
+
+static hipError_t launch_fit(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fit, dim3(g.n_frames, FIT_CHUNKS), dim3(256), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
+                       lim.max_contours, lim.max_points, p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi, b.slot_kind,
+                       b.slot_ell, b.elig, b.n_elig);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_pairs_tail(g, b, lim, p, pairs, s);
+}
+
+// legacy matcher: k_match fills the per-contour slots, k_pairs compacts them (and pairs the blobs of camp p.camp)
+hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, const rmcv_legacy_params& lp,
+                        int mode, bool with_frames, bool pairs, hipStream_t s)
+{
+    MatchArgs A;
+    A.min_ratio = lp.min_ratio;
+    A.max_ratio = lp.max_ratio;
+    A.tilt_angle = lp.tilt_angle;
+    A.min_area = lp.min_area;
+    A.max_area = lp.max_area;
+    A.fit_ellipse = lp.fit_ellipse;
+    A.mode = mode;
+    A.wcap = lim.max_width < HULL_MAX_DIM ? lim.max_width : HULL_MAX_DIM;
+    A.frames = with_frames ? b.frames : nullptr;
+    A.frame_pitch = g.frame_pitch;
+    A.stride = g.stride;
+    const size_t lds = sizeof(WaveLds) + hull_lds_bytes(A.wcap);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_match, dim3(g.n_frames, MATCH_CHUNKS), dim3(64), lds, s, b.points, b.cont_start, b.cont_len, b.n_contours,
+                       lim.max_contours, lim.max_points, A, b.slot_kind, b.slot_ell, b.elig, b.n_elig, b.status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_pairs_tail(g, b, lim, p, pairs, s);
 }
 
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s)

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "rmcv_internal.h"
@@ -207,7 +208,8 @@ static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t
     return RMCV_OK;
 }
 
-static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t s, bool timed)
+static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t s, bool timed,
+                      const rmcv_legacy_params* lp = nullptr)
 {
     const Geom& g = c->geom;
     const Bufs& b = c->bufs;
@@ -220,7 +222,8 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     const bool fused = (stages & RMCV_STAGE_BLOBS) && (stages & RMCV_STAGE_ARMOURS); // one launch for both
-    if (fused) HIPCHK(c, launch_blobs_armours(g, b, c->lim, *p, s), "k_fit");
+    if (lp && (stages & RMCV_STAGE_BLOBS)) HIPCHK(c, launch_match(g, b, c->lim, *p, *lp, 0, b.frames != nullptr, fused, s), "k_match");
+    else if (fused) HIPCHK(c, launch_blobs_armours(g, b, c->lim, *p, s), "k_fit");
     else if (stages & RMCV_STAGE_BLOBS) HIPCHK(c, launch_blobs(g, b, c->lim, *p, s), "k_fit");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     if (!fused && (stages & RMCV_STAGE_ARMOURS)) HIPCHK(c, launch_armours(g, b, c->lim, *p, s), "k_armours");
@@ -296,6 +299,15 @@ int rmcv_batch_run(rmcv_ctx* c, const rmcv_params* p, int stages, void* hip_stre
     if (rc) return rc;
     hipSetDevice(c->device);
     return run_stages(c, p, stages, hip_stream ? (hipStream_t)hip_stream : c->stream, false);
+}
+
+int rmcv_batch_run_legacy(rmcv_ctx* c, const rmcv_params* p, const rmcv_legacy_params* lp, int stages, void* hip_stream)
+{
+    int rc = check_params(c, p, stages);
+    if (rc) return rc;
+    if (!lp) return fail(c, RMCV_ERR_BAD_ARG, "null legacy params");
+    hipSetDevice(c->device);
+    return run_stages(c, p, stages, hip_stream ? (hipStream_t)hip_stream : c->stream, false, lp);
 }
 
 int rmcv_batch_sync(rmcv_ctx* c)
@@ -669,6 +681,96 @@ int rmcv_fit_ellipse(rmcv_ctx* c, const rmcv_point* pts, int n, rmcv_rrect* out)
     HIPCHK(c, hipMemcpy(&nn, c->bufs.n_neg, 4, hipMemcpyDeviceToHost), "D2H");
     if (nb != 1) return fail(c, RMCV_ERR_BAD_ARG, n < 6 ? "contour has fewer than 6 points" : "ellipse fit produced NaN");
     HIPCHK(c, hipMemcpy(out, c->bufs.ellipses, sizeof(rmcv_rrect), hipMemcpyDeviceToHost), "D2H ellipse");
+    return RMCV_OK;
+}
+
+// ---- legacy per-contour matcher --------------------------------------------------------------------------
+static int match_one(rmcv_ctx* c, const rmcv_point* pts, int n, const rmcv_legacy_params& lp, int mode, rmcv_rrect* box, int32_t* matched)
+{
+    int32_t offs[2] = {0, n};
+    hipSetDevice(c->device);
+    int rc = load_contours(c, pts, offs, 1);
+    if (rc) return rc;
+    rmcv_params p;
+    rmcv_default_params(&p);
+    Geom g1 = c->geom;
+    g1.n_frames = 1;
+    HIPCHK(c, launch_match(g1, c->bufs, c->lim, p, lp, mode, false, false, c->stream), "k_match");
+    HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+    int32_t nb = 0, st = 0;
+    HIPCHK(c, hipMemcpy(&nb, c->bufs.n_blobs, 4, hipMemcpyDeviceToHost), "D2H");
+    HIPCHK(c, hipMemcpy(&st, c->bufs.status, 4, hipMemcpyDeviceToHost), "D2H");
+    if (st & RMCV_FRAME_HULL)
+        return fail(c, RMCV_ERR_BAD_ARG, "minAreaRect: not a closed border (a column of the bounding box is empty) or wider than the context's max_width");
+    *matched = nb == 1;
+    if (nb == 1) HIPCHK(c, hipMemcpy(box, c->bufs.ellipses, sizeof(rmcv_rrect), hipMemcpyDeviceToHost), "D2H box");
+    return RMCV_OK;
+}
+
+int rmcv_min_area_rect(rmcv_ctx* c, const rmcv_point* pts, int n, rmcv_rrect* out)
+{
+    if (!c || !pts || !out || n < 1) return RMCV_ERR_BAD_ARG;
+    rmcv_legacy_params lp = {0, 0, 0, 0, 0, 0};
+    int32_t m = 0;
+    int rc = match_one(c, pts, n, lp, 1, out, &m);
+    if (rc) return rc;
+    return m ? RMCV_OK : fail(c, RMCV_ERR_HIP, "minAreaRect produced no result");
+}
+
+int rmcv_match_lightblob(rmcv_ctx* c, const rmcv_point* pts, int n, const rmcv_legacy_params* lp, rmcv_rrect* box_out, int32_t* matched)
+{
+    if (!c || !lp || !box_out || !matched || n < 0 || (n > 0 && !pts)) return RMCV_ERR_BAD_ARG;
+    *matched = 0;
+    if (n < 6) return RMCV_OK; // src/objdetect.cpp:12
+    return match_one(c, pts, n, *lp, 0, box_out, matched);
+}
+
+int rmcv_find_lightblobs(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride, const rmcv_point* pts, const int32_t* offs,
+                         int n_contours, const rmcv_legacy_params* lp, rmcv_lightblob* blobs_out, int blobs_cap, int32_t* n_blobs,
+                         int32_t* blob_src, rmcv_rrect* boxes_out)
+{
+    if (!c || !bgr || !lp || (n_contours > 0 && (!pts || !offs))) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_upload(c, bgr, 1, w, h, stride, (int64_t)stride * h); // source.channels() == 3 is the ABI's only format
+    if (rc) return rc;
+    rc = load_contours(c, pts, offs, n_contours);
+    if (rc) return rc;
+    for (int i = 0; i < (n_contours ? offs[n_contours] : 0); i++)
+        if (pts[i].x < 0 || pts[i].x >= w || pts[i].y < 0 || pts[i].y >= h) return fail(c, RMCV_ERR_BAD_ARG, "contour point outside the frame");
+    rmcv_params p;
+    rmcv_default_params(&p);
+    HIPCHK(c, launch_match(c->geom, c->bufs, c->lim, p, *lp, 0, true, false, c->stream), "k_match");
+    c->last_stream = c->stream;
+    int32_t nb = 0;
+    rc = rmcv_batch_get_blobs(c, 0, blobs_out, blobs_cap, &nb, blob_src);
+    if (rc) return rc;
+    if (n_blobs) *n_blobs = nb;
+    int32_t st = 0;
+    HIPCHK(c, hipMemcpy(&st, c->bufs.status, 4, hipMemcpyDeviceToHost), "D2H");
+    if (st & RMCV_FRAME_HULL) return fail(c, RMCV_ERR_BAD_ARG, "minAreaRect: a contour is not a closed border or exceeds the hull tables");
+    if (boxes_out && nb) HIPCHK(c, hipMemcpy(boxes_out, c->bufs.ellipses, (size_t)nb * sizeof(rmcv_rrect), hipMemcpyDeviceToHost), "D2H boxes");
+    return RMCV_OK;
+}
+
+int rmcv_lightblob_overlap(const rmcv_lightblob* lb, int n, int left, int right, int32_t* overlap)
+{
+    if (!overlap || (n > 0 && !lb)) return RMCV_ERR_BAD_ARG;
+    *overlap = 0;
+    if (left < 0 || right > n || right - left < 2) return RMCV_OK; // src/objdetect.cpp:91
+    if (right == n) return RMCV_ERR_BAD_ARG;                       // the reference reads lightBlobs[size()] here
+    if (lb[left].target != lb[right].target) return RMCV_OK;       // :92
+    const float lower_y = std::min(std::min(lb[left].vertices[1][1], lb[left].vertices[2][1]),
+                                   std::min(lb[right].vertices[1][1], lb[right].vertices[2][1])); // :94-96
+    const float upper_y = std::max(std::max(lb[left].vertices[0][1], lb[left].vertices[3][1]),
+                                   std::max(lb[right].vertices[0][1], lb[right].vertices[3][1])); // :97-99
+    for (int i = left; i < right; i++) {
+        if (lb[i].target != lb[left].target) continue;
+        if (lb[i].center[0] > lb[left].center[0] && lb[i].center[0] < lb[right].center[0] && lb[i].center[1] > lower_y &&
+            lb[i].center[1] < upper_y) {
+            *overlap = 1;
+            return RMCV_OK;
+        }
+    }
     return RMCV_OK;
 }
 

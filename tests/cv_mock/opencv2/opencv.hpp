@@ -28,6 +28,7 @@ struct Mat {
     Mat(const Mat& o) : rows(o.rows), cols(o.cols), type_(o.type_), step(o.step), data(o.data), own(o.own) { if (!own.empty()) data = own.data(); }
     Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; type_ = o.type_; step = o.step; own = o.own; data = own.empty() ? o.data : own.data(); return *this; }
     int type() const { return type_; }
+    int channels() const { return type_ == CV_8UC3 ? 3 : 1; }
 };
 struct _InputArray { const Mat* m; _InputArray(const Mat& mm) : m(&mm) {} Mat getMat() const { return *m; } };
 typedef const _InputArray& InputArray;

@@ -206,3 +206,50 @@ def classify_armours(bgr, armours, svm):
                                _p(np.ascontiguousarray(rho, np.float64)), _p(np.ascontiguousarray(labels, np.int32)),
                                len(labels), _p(ident), _p(icons))
     return ident[:n].copy(), arm, icons[:n].copy()
+
+
+# ---------------------------------------------------------------- legacy matcher (oracle/rmcv_oracle_legacy.c)
+def convex_hull(pts, pruned=False):
+    pts = np.ascontiguousarray(pts, POINT)
+    out = np.zeros(max(4 * len(pts), 4), np.int32)
+    fn = lib().orc_convex_hull_pruned if pruned else lib().orc_convex_hull
+    n = fn(_p(pts), len(pts), _p(out))
+    return None if n < 0 else out[:n].copy()
+
+
+def min_area_rect(pts):
+    pts = np.ascontiguousarray(pts, POINT)
+    out = np.zeros(1, RRECT)
+    lib().orc_min_area_rect(_p(pts), len(pts), _p(out))
+    return out[0]
+
+
+def match_lightblob(pts, min_ratio, max_ratio, tilt_angle, min_area, max_area, fit_ellipse):
+    pts = np.ascontiguousarray(pts, POINT)
+    out = np.zeros(1, RRECT)
+    ok = lib().orc_match_lightblob(_p(pts), len(pts), C.c_float(min_ratio), C.c_float(max_ratio), C.c_float(tilt_angle),
+                                   C.c_float(min_area), C.c_float(max_area), int(fit_ellipse), _p(out))
+    return bool(ok), out[0]
+
+
+def find_lightblobs(bgr, pts, offs, min_ratio, max_ratio, tilt_angle, min_area, max_area, fit_ellipse):
+    """returns (blobs, blob_src, boxes)"""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    pts = np.ascontiguousarray(pts, POINT)
+    offs = np.ascontiguousarray(offs, np.int32)
+    n = len(offs) - 1
+    blobs = np.zeros(max(n, 1), LIGHTBLOB)
+    src = np.zeros(max(n, 1), np.int32)
+    boxes = np.zeros(max(n, 1), RRECT)
+    nb = C.c_int32(0)
+    rc = lib().orc_find_lightblobs(_p(bgr), w, h, 3 * w, _p(pts), _p(offs), n, C.c_float(min_ratio), C.c_float(max_ratio),
+                                   C.c_float(tilt_angle), C.c_float(min_area), C.c_float(max_area), int(fit_ellipse),
+                                   _p(blobs), len(blobs), C.byref(nb), _p(src), _p(boxes))
+    assert rc == 0, rc
+    return blobs[:nb.value].copy(), src[:nb.value].copy(), boxes[:nb.value].copy()
+
+
+def lightblob_overlap(blobs, left, right):
+    blobs = np.ascontiguousarray(blobs, LIGHTBLOB)
+    return lib().orc_lightblob_overlap(_p(blobs), len(blobs), int(left), int(right))

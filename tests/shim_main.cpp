@@ -54,6 +54,18 @@ int main(int argc, char** argv)
         for (int i = 0; i < 4; i++) std::printf(" %a %a", a.vertices[i].x, a.vertices[i].y);
         std::printf("\n");
     }
+    // the legacy matcher (include/objdetect.h:22-37, 62) through the same shim
+    std::vector<rm::lightblob> legacy;
+    rm::FindLightBlobs(contours, legacy, 1.5f, 80.0f, 70.0f, 10.0f, 99999.0f, frame, false);
+    std::printf("legacy %zu", legacy.size());
+    for (auto& b : legacy) std::printf(" %d %a %a", (int)b.target, b.size.width, b.size.height);
+    std::printf("\n");
+    size_t matched = 0;
+    cv::RotatedRect box;
+    for (auto& c : contours) matched += rm::MatchLightBlob(c, 1.5f, 80.0f, 70.0f, 10.0f, 99999.0f, box, true) ? 1 : 0;
+    int overlaps = 0;
+    for (int i = 0; i + 2 < (int)legacy.size(); i++) overlaps += rm::LightBlobOverlap(legacy, i, i + 2) ? 1 : 0;
+    std::printf("matched %zu overlaps %d\n", matched, overlaps);
     rm::LightBlob* alias_check = positive.empty() ? nullptr : &positive[0];
     (void)alias_check;
     return 0;

@@ -36,6 +36,20 @@ def test_shim_matches_oracle(tmp_path, oracle):
         assert head["contours"] == len(ref["offs"]) - 1 and head["points"] == len(ref["pts"])
         assert head["binary_on"] == int(np.count_nonzero(ref["binary"])) and head["positive"] == len(ref["blobs"])
         assert head["armours"] == len(ref["armours"])
-        got = [[float.fromhex(t) for t in line.split()[1:]] for line in out[1:]]
+        arm_lines = [l for l in out[1:] if l.startswith("armour")]
+        got = [[float.fromhex(t) for t in line.split()[1:]] for line in arm_lines]
         exp = [[float(v) for v in a["vertices"].reshape(-1)] for a in ref["armours"]]
         assert got == exp
+        # legacy matcher through the shim: FindLightBlobs(fitEllipse=false), MatchLightBlob(fitEllipse=true), LightBlobOverlap
+        frame = synth.frame(index)
+        lb, _, _ = oracle.find_lightblobs(frame, ref["pts"], ref["offs"], 1.5, 80, 70, 10, 99999, False)
+        leg = [l for l in out if l.startswith("legacy")][0].split()
+        assert int(leg[1]) == len(lb)
+        vals = leg[2:]
+        for i, b in enumerate(lb):
+            assert int(vals[3 * i]) == int(b["target"])
+            assert float.fromhex(vals[3 * i + 1]) == float(b["size"][0]) and float.fromhex(vals[3 * i + 2]) == float(b["size"][1])
+        tail = [l for l in out if l.startswith("matched")][0].split()
+        conts = [ref["pts"][ref["offs"][i]:ref["offs"][i + 1]] for i in range(len(ref["offs"]) - 1)]
+        assert int(tail[1]) == sum(oracle.match_lightblob(c, 1.5, 80, 70, 10, 99999, True)[0] for c in conts)
+        assert int(tail[3]) == sum(oracle.lightblob_overlap(lb, i, i + 2) == 1 for i in range(len(lb) - 2))
