@@ -90,7 +90,7 @@ def main():
             c.svm_load(*svm)
     ctx = ctxs[0]
     params = default_params()                                     # main.cpp:172-176: BLUE, lb 80, close, ...
-    legacy = LegacyParams(1.5, 80, 70, 10, 99999, 0) if args.workload == "legacy" else None
+    legacy = LegacyParams(1.5, 80, 70, 10, 99999, int(os.environ.get("RMCV_LEGACY_FIT", "0"))) if args.workload == "legacy" else None
 
     def run_path(c, st, hs):
         if legacy is not None:

@@ -16,33 +16,40 @@
 
 namespace rmcv {
 
-static constexpr int HULL_CHAIN_CAP = 512; // stack entries per quarter chain (a strictly convex lattice chain in a 4096 box has < 300)
-static constexpr int HULL_CAP = 1024;      // hull vertices (< 3.6 * 4096^(2/3) = 910)
+// Table sizes are run-time: the matcher first runs with small tables (most light-blob contours are a few dozen columns wide,
+// their hulls a few dozen points) so that many wavefronts fit a CU, and repeats the rare contour that does not fit with
+// the full-size ones.
+static constexpr int HULL_CHAIN_CAP = 512; // full size: stack entries per quarter chain (a strictly convex lattice chain in a 4096 box has < 300)
+static constexpr int HULL_CAP = 1024;      // full size: hull vertices (< 3.6 * 4096^(2/3) = 910)
 static constexpr int HULL_MAX_DIM = 4096;  // y is packed into 12 bits, the point index into 20
 
 struct HullLds {
-    uint32_t* col;  // [4 * wcap]            packed (y << 20 | index code)
-    uint16_t* stk;  // [4][HULL_CHAIN_CAP]   Sklansky stacks (entry numbers k)
-    int32_t* hidx;  // [HULL_CAP]            hull as point indices, OpenCV's order
-    float* hx;      // [HULL_CAP]
-    float* hy;      // [HULL_CAP]
-    float* inv;     // [HULL_CAP]            1/|edge|; doubles as the scratch of the cyclic shift
+    uint32_t* col;  // [4 * wcap]      packed (y << 20 | index code)
+    uint16_t* stk;  // [4][ccap]       Sklansky stacks (entry numbers k)
+    int32_t* hidx;  // [hcap]          hull as point indices, OpenCV's order
+    float* hx;      // [hcap]
+    float* hy;      // [hcap]
+    float* inv;     // [hcap]          1/|edge|; doubles as the scratch of the cyclic shift
+    int wcap, hcap, ccap;
 };
 
-__host__ __device__ inline size_t hull_lds_bytes(int wcap)
+__host__ __device__ inline size_t hull_lds_bytes(int wcap, int hcap, int ccap)
 {
-    return (size_t)4 * wcap * 4 + (size_t)4 * HULL_CHAIN_CAP * 2 + (size_t)HULL_CAP * 16;
+    return (size_t)4 * wcap * 4 + (size_t)4 * ccap * 2 + (size_t)hcap * 16;
 }
 
-__device__ inline void hull_lds_carve(unsigned char* base, int wcap, HullLds& H)
+__device__ inline void hull_lds_carve(unsigned char* base, int wcap, int hcap, int ccap, HullLds& H)
 {
+    H.wcap = wcap;
+    H.hcap = hcap;
+    H.ccap = ccap;
     H.col = reinterpret_cast<uint32_t*>(base);
     base += (size_t)4 * wcap * 4;
     H.hidx = reinterpret_cast<int32_t*>(base);
-    H.hx = reinterpret_cast<float*>(base + (size_t)HULL_CAP * 4);
-    H.hy = reinterpret_cast<float*>(base + (size_t)HULL_CAP * 8);
-    H.inv = reinterpret_cast<float*>(base + (size_t)HULL_CAP * 12);
-    H.stk = reinterpret_cast<uint16_t*>(base + (size_t)HULL_CAP * 16);
+    H.hx = reinterpret_cast<float*>(base + (size_t)hcap * 4);
+    H.hy = reinterpret_cast<float*>(base + (size_t)hcap * 8);
+    H.inv = reinterpret_cast<float*>(base + (size_t)hcap * 12);
+    H.stk = reinterpret_cast<uint16_t*>(base + (size_t)hcap * 16);
 }
 
 // LDS hand-over between the lanes of ONE wavefront (the functions below never synchronise across wavefronts)
@@ -64,7 +71,7 @@ __device__ __forceinline__ int hull_entry_idx(const uint32_t* col, int k)
 __device__ __forceinline__ int sgn_i64(long long v) { return (v > 0) - (v < 0); }
 
 // [OCV] Sklansky_ over entries start..end of the column table (x of entry k is k >> 2).  One lane.
-__device__ inline int hull_sklansky(const uint32_t* col, int start, int end, uint16_t* stack, int nsign, int sign2, int* ovf)
+__device__ inline int hull_sklansky(const uint32_t* col, int start, int end, uint16_t* stack, int cap, int nsign, int sign2, int* ovf)
 {
     const int incr = end > start ? 1 : -1;
     int pprev = start, pcur = pprev + incr, pnext = pcur + incr;
@@ -86,7 +93,7 @@ __device__ inline int hull_sklansky(const uint32_t* col, int start, int end, uin
             const int ay = cury - hull_entry_y(col, pprev);
             const long long convexity = (long long)ay * bx - (long long)ax * by;
             if (sgn_i64(convexity) == sign2 && (ax != 0 || ay != 0)) {
-                if (stacksize >= HULL_CHAIN_CAP) { *ovf = 1; break; }
+                if (stacksize >= cap) { *ovf = 1; break; }
                 pprev = pcur;
                 pcur = pnext;
                 pnext += incr;
@@ -164,16 +171,19 @@ __device__ inline int hull_wave(const rmcv_point* __restrict__ pts, int n, int m
         const int end = (lane & 2) ? miny_ind : maxy_ind;
         const int nsign = (lane & 2) ? 1 : -1;
         const int sign2 = (lane == 0 || lane == 3) ? 1 : -1;
-        cnt = hull_sklansky(H.col, start, end, H.stk + lane * HULL_CHAIN_CAP, nsign, sign2, &my_ovf);
+        cnt = hull_sklansky(H.col, start, end, H.stk + lane * H.ccap, H.ccap, nsign, sign2, &my_ovf);
     }
-    if (__ballot(my_ovf != 0)) *ovf = 1;
+    if (__ballot(my_ovf != 0)) {
+        *ovf = 1;
+        return 0;
+    }
     wave_lds_sync();
     const int c_tl = __shfl(cnt, 0), c_tr = __shfl(cnt, 1);
     int c_bl = __shfl(cnt, 2), c_br = __shfl(cnt, 3);
     const uint16_t* TL = H.stk;
-    const uint16_t* TR = H.stk + HULL_CHAIN_CAP;
-    const uint16_t* BL = H.stk + 2 * HULL_CHAIN_CAP;
-    const uint16_t* BR = H.stk + 3 * HULL_CHAIN_CAP;
+    const uint16_t* TR = H.stk + H.ccap;
+    const uint16_t* BL = H.stk + 2 * H.ccap;
+    const uint16_t* BR = H.stk + 3 * H.ccap;
     // counter-clockwise assembly: top-right chain forward, top-left chain backward, bottom-left forward, bottom-right backward
     const int stop_idx = c_tl > 2 ? TL[1] : c_tr > 2 ? TR[c_tr - 2] : -1;
     if (stop_idx >= 0) {
@@ -186,7 +196,7 @@ __device__ inline int hull_wave(const rmcv_point* __restrict__ pts, int n, int m
     }
     const int na = c_tr > 1 ? c_tr - 1 : 0, nb = c_tl > 1 ? c_tl - 1 : 0, nc = c_bl > 1 ? c_bl - 1 : 0, nd = c_br > 1 ? c_br - 1 : 0;
     const int nout = na + nb + nc + nd;
-    if (nout > HULL_CAP) {
+    if (nout > H.hcap) {
         *ovf = 1;
         return 0;
     }
@@ -383,18 +393,20 @@ __device__ inline void min_area_rect_wave(const rmcv_point* __restrict__ pts, in
 // integer channel sums by one positive factor (1/N), which preserves their order, so the sums are compared directly.
 __device__ inline int camp_from_mean_wave(const uint8_t* __restrict__ frame, int stride, int minx, int miny, int W, int Hh, int lane)
 {
+    // one flat loop over the W x Hh pixels (rows are short: a per-row loop would wait for one load round trip per row)
     unsigned long long s0 = 0, s1 = 0, s2 = 0;
-    for (int y = 0; y < Hh; y++) {
-        const uint8_t* row = frame + (int64_t)(miny + y) * stride + (int64_t)minx * 3;
-        unsigned a0 = 0, a1 = 0, a2 = 0;
-        for (int x = lane; x < W; x += 64) {
-            a0 += row[3 * x];
-            a1 += row[3 * x + 1];
-            a2 += row[3 * x + 2];
-        }
-        s0 += a0;
-        s1 += a1;
-        s2 += a2;
+    const uint8_t* roi = frame + (int64_t)miny * stride + (int64_t)minx * 3;
+    const int total = W * Hh, dy = 64 / W, dx = 64 - dy * W;
+    int y = lane / W, x = lane - y * W;
+#pragma unroll 4
+    for (int i = lane; i < total; i += 64) {
+        const uint8_t* px = roi + (int64_t)y * stride + 3 * x;
+        s0 += px[0];
+        s1 += px[1];
+        s2 += px[2];
+        y += dy;
+        x += dx;
+        if (x >= W) { x -= W; y++; }
     }
     for (int d = 32; d >= 1; d >>= 1) {
         s0 += __shfl_xor(s0, d);

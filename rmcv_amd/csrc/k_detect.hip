@@ -327,13 +327,16 @@ __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ poin
 // compaction; a matching contour's slot word is 1 | (camp + 2) << 4.
 struct MatchArgs {
     float min_ratio, max_ratio, tilt_angle, min_area, max_area;
-    int fit_ellipse, mode, wcap;
+    int fit_ellipse, mode;
+    int wcap, hcap, ccap; // hull table sizes of this launch (device_hull.h)
+    int pass;             // 0: all contours, small tables, what does not fit is marked MATCH_DEFERRED; 1: the marked ones, full tables
     const uint8_t* frames; // may be null: no camp vote (the blob gets CAMP_NEUTRAL)
     int64_t frame_pitch;
     int stride;
 };
 
 static constexpr int MATCH_CHUNKS = 16;
+static constexpr int MATCH_DEFERRED = 0x100; // slot word: kind 0 (skipped by the compaction) + "repeat with full-size tables"
 __global__ __launch_bounds__(64) void k_match(const rmcv_point* __restrict__ points, const int32_t* __restrict__ cont_start,
                                              const int32_t* __restrict__ cont_len, const int32_t* __restrict__ n_contours,
                                              int max_contours, int max_points, MatchArgs A, int32_t* __restrict__ slot_kind,
@@ -345,7 +348,8 @@ __global__ __launch_bounds__(64) void k_match(const rmcv_point* __restrict__ poi
     const int f = blockIdx.x, lane = threadIdx.x;
     WaveLds& L = *reinterpret_cast<WaveLds*>(match_smem);
     HullLds H;
-    hull_lds_carve(reinterpret_cast<unsigned char*>(match_smem) + sizeof(WaveLds), A.wcap, H);
+    hull_lds_carve(reinterpret_cast<unsigned char*>(match_smem) + sizeof(WaveLds), A.wcap, A.hcap, A.ccap, H);
+    const bool final_pass = A.pass == 1 || A.mode == 1;
     const int n = n_contours[f];
     const rmcv_point* pts = points + (int64_t)f * max_points;
     const int32_t* cs = cont_start + (int64_t)f * max_contours;
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(64) void k_match(const rmcv_point* __restrict__ poi
         const int k = A.mode == 1 ? e : elig[(int64_t)f * max_contours + e];
         const int c = n - 1 - k; // findContours order
         const int start = cs[k], len = cl[k];
+        if (A.pass == 1 && slot_kind[(int64_t)f * max_contours + c] != MATCH_DEFERRED) continue;
         int word = 0;
         rmcv_rrect box = {0, 0, 0, 0, 0};
         if (len >= 1 && start + len <= max_points && (A.mode == 1 || len >= 6)) { // objdetect.cpp:12
@@ -389,24 +394,33 @@ __global__ __launch_bounds__(64) void k_match(const rmcv_point* __restrict__ poi
             if (A.mode == 1) {
                 if (!ovf) min_area_rect_wave(cp, len, minx, W, H, lane, &box, &ovf);
                 word = 1;
+                if (ovf && lane == 0) atomicOr(&status[f], RMCV_FRAME_HULL);
             } else if (!(area < A.min_area || area > A.max_area)) { // :12
                 rmcv_rrect ellipse;
                 fit_ellipse_wave(cp, len, sx, sy, L, lane, &ellipse); // :15
-                if (A.fit_ellipse) box = ellipse;
-                else if (!ovf) min_area_rect_wave(cp, len, minx, W, H, lane, &box, &ovf); // :16
-                const float mx = box.w > box.h ? box.w : box.h, mn = box.w < box.h ? box.w : box.h;
-                const float ratio = mx / mn; // :19
-                bool ok = !(ratio > A.max_ratio || ratio < A.min_ratio);
-                const float angle = ellipse.angle > 90 ? ellipse.angle - 90 : ellipse.angle + 90; // :23
-                if (__builtin_fabsf(angle - 90) > A.tilt_angle) ok = false;                       // :24
-                if (ok) {
-                    int camp = RMCV_CAMP_NEUTRAL;
-                    if (A.frames) // :43-51
-                        camp = camp_from_mean_wave(A.frames + (int64_t)f * A.frame_pitch, A.stride, minx, miny, W, Hh, lane);
-                    word = 1 | ((camp + 2) << 4);
+                if (A.fit_ellipse) {
+                    box = ellipse;
+                    ovf = 0;
+                } else if (!ovf) {
+                    min_area_rect_wave(cp, len, minx, W, H, lane, &box, &ovf); // :16
+                }
+                if (ovf) { // the box is missing: repeat with the full-size tables, or give up (never for a findContours border)
+                    word = final_pass ? 0 : MATCH_DEFERRED;
+                    if (final_pass && lane == 0) atomicOr(&status[f], RMCV_FRAME_HULL);
+                } else {
+                    const float mx = box.w > box.h ? box.w : box.h, mn = box.w < box.h ? box.w : box.h;
+                    const float ratio = mx / mn; // :19
+                    bool ok = !(ratio > A.max_ratio || ratio < A.min_ratio);
+                    const float angle = ellipse.angle > 90 ? ellipse.angle - 90 : ellipse.angle + 90; // :23
+                    if (__builtin_fabsf(angle - 90) > A.tilt_angle) ok = false;                       // :24
+                    if (ok) {
+                        int camp = RMCV_CAMP_NEUTRAL;
+                        if (A.frames) // :43-51
+                            camp = camp_from_mean_wave(A.frames + (int64_t)f * A.frame_pitch, A.stride, minx, miny, W, Hh, lane);
+                        word = 1 | ((camp + 2) << 4);
+                    }
                 }
             }
-            if (ovf && lane == 0 && (A.mode == 1 || !A.fit_ellipse)) atomicOr(&status[f], RMCV_FRAME_HULL);
         }
         if (lane == 0) {
             slot_kind[(int64_t)f * max_contours + c] = word;
@@ -637,21 +651,32 @@ hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const r
     A.max_area = lp.max_area;
     A.fit_ellipse = lp.fit_ellipse;
     A.mode = mode;
-    A.wcap = lim.max_width < HULL_MAX_DIM ? lim.max_width : HULL_MAX_DIM;
     A.frames = with_frames ? b.frames : nullptr;
     A.frame_pitch = g.frame_pitch;
     A.stride = g.stride;
-    const size_t lds = sizeof(WaveLds) + hull_lds_bytes(A.wcap);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int full_w = lim.max_width < HULL_MAX_DIM ? lim.max_width : HULL_MAX_DIM;
+    const bool hull = mode == 1 || !lp.fit_ellipse;
+    // pass 0 (every contour): small hull tables, ~10 KB of LDS per wavefront; pass 1 repeats the contours pass 0 marked
+    // (wider than 256 columns, or a hull with more points than the small tables hold) with the full-size tables.  The hook
+    // (mode 1) is a single full-size pass; with fitEllipse there is no hull at all.
+    for (int pass = 0; pass < ((hull && mode == 0) ? 2 : 1); pass++) {
+        const bool full = mode == 1 || pass == 1;
+        A.pass = pass;
+        A.wcap = !hull ? 1 : full ? full_w : (full_w < 256 ? full_w : 256);
+        A.hcap = !hull ? 1 : full ? HULL_CAP : 128;
+        A.ccap = !hull ? 1 : full ? HULL_CHAIN_CAP : 64;
+        const size_t lds = sizeof(WaveLds) + hull_lds_bytes(A.wcap, A.hcap, A.ccap);
+        static size_t lds_set = 0;
+        if (lds > lds_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            lds_set = lds;
+        }
+        hipLaunchKernelGGL(k_match, dim3(g.n_frames, pass ? 2 : MATCH_CHUNKS), dim3(64), lds, s, b.points, b.cont_start, b.cont_len,
+                           b.n_contours, lim.max_contours, lim.max_points, A, b.slot_kind, b.slot_ell, b.elig, b.n_elig, b.status);
+        hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        lds_set = lds;
     }
-    hipLaunchKernelGGL(k_match, dim3(g.n_frames, MATCH_CHUNKS), dim3(64), lds, s, b.points, b.cont_start, b.cont_len, b.n_contours,
-                       lim.max_contours, lim.max_points, A, b.slot_kind, b.slot_ell, b.elig, b.n_elig, b.status);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
     return launch_pairs_tail(g, b, lim, p, pairs, s);
 }
 

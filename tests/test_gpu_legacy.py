@@ -202,3 +202,26 @@ def test_full_size_legacy_properties(oracle):
             bw, bh = np.ptp(cont["x"]), np.ptp(cont["y"])
             assert w * h <= bw * bh + 1e-3 * max(1.0, bw * bh)
     c.close()
+
+
+def test_find_lightblobs_contours_beyond_the_small_hull_tables(ctx, oracle):
+    """the matcher's first pass holds hulls of <= 128 points over <= 256 columns (a disc of radius 127 has 84 hull points and
+    fits); a 700-column ellipse and a 300-column bar take the second, full-size pass"""
+    h, w = 700, 1280
+    img = np.zeros((h, w, 3), np.uint8)
+    mask = np.zeros((h, w), np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    shapes = [((xx - 150) ** 2 + (yy - 150) ** 2 <= 127 ** 2, (255, 30, 0)),
+              (((xx - 800) / 350.0) ** 2 + ((yy - 200) / 60.0) ** 2 <= 1, (0, 30, 255)),
+              ((np.abs(xx - 400) <= 150) & (np.abs(yy - 500) <= 12), (20, 255, 20)),
+              ((np.abs(xx - 900) <= 4) & (np.abs(yy - 500) <= 40), (255, 0, 0))]
+    for m, colour in shapes:
+        img[m] = colour
+        mask[m] = 255
+    pts, offs = oracle.find_contours(mask)
+    gb, gs, gx = ctx.find_lightblobs(pts, offs, 0.5, 80, 180, 10, 1e9, img, False)
+    ob, os_, ox = oracle.find_lightblobs(img, pts, offs, 0.5, 80, 180, 10, 1e9, False)
+    assert len(ob) == 4 and np.array_equal(gs, os_)
+    assert gx.tobytes() == ox.tobytes() and gb.tobytes() == ob.tobytes()
+    widths = sorted(int(np.ptp(pts[offs[i]:offs[i + 1]]["x"])) + 1 for i in range(4))
+    assert widths[0] <= 256 and widths[1] <= 256 and widths[2] > 256 and widths[3] > 256
