@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
                     help="c3: 1280x1024 full path (the metric's config); c5: 1920x1200 full path + SVM digit classify on the icons; "
                          "legacy: c3 with rm::FindLightBlobs(fitEllipse=false) as the blob stage")
+    ap.add_argument("--pose", action="store_true",
+                    help="add the pose stage (rm::solve_PnP + world position per armour, SURVEY 8f-3) to every step")
     ap.add_argument("--streams", type=int, default=3,
                     help="contexts (buffer sets) the steps are pipelined over (1 = strictly serial steps)")
     ap.add_argument("--mode", choices=("pipeline", "alternate"), default="alternate",
@@ -57,7 +59,7 @@ def main():
     import torch.distributed as dist
 
     from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_ARMOURS, STAGE_BINARY, STAGE_BLOBS,
-                          STAGE_IDENTITY, Context, LegacyParams, default_params, synth)
+                          STAGE_IDENTITY, STAGE_POSE, Context, LegacyParams, default_params, synth)
     from rmcv_amd import dist as rdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,12 +84,14 @@ def main():
     # the HBM-bound pixel kernel of step i+1 streams -- what a continuous camera feed would do.
     ns = max(1, args.streams)
     ctxs = [Context(device=local_rank, max_frames=n, max_width=W, max_height=H) for _ in range(ns)]
-    stages = STAGE_ALL | (STAGE_IDENTITY if args.workload == "c5" else 0)
+    stages = STAGE_ALL | (STAGE_IDENTITY if args.workload == "c5" else 0) | (STAGE_POSE if args.pose else 0)
     svm = synth.svm_weights() if args.workload == "c5" else None   # svm.xml is not in the reference: seeded stand-in weights
     for c in ctxs:
         c.bind_device_frames(frames.data_ptr(), n, H, W, keepalive=frames)
         if svm:
             c.svm_load(*svm)
+        if args.pose:
+            c.pnp_load()                                          # camera constants of executable/main.cpp:7-19
     ctx = ctxs[0]
     params = default_params()                                     # main.cpp:172-176: BLUE, lb 80, close, ...
     legacy = LegacyParams(1.5, 80, 70, 10, 99999, int(os.environ.get("RMCV_LEGACY_FIT", "0"))) if args.workload == "legacy" else None
@@ -218,7 +222,8 @@ def main():
         "config": {"workload": "%s: batch=%d/GPU %dx%d BGR, blue lb=80, close3x3 + findContours + lightblob fit + armour "
                                "pairing%s%s" % (args.workload.upper(), n, W, H,
                                                 (" + icon rectification + 7-class linear SVM (synthetic weights)" if svm else "") +
-                                                (" [legacy blob stage: FindLightBlobs, minAreaRect boxes, camp vote]" if legacy else ""),
+                                                (" [legacy blob stage: FindLightBlobs, minAreaRect boxes, camp vote]" if legacy else "") +
+                                                (" + solve_PnP (IPPE square) and world position per armour" if args.pose else ""),
                                                 " + RCCL gather of armour lists (C4)" if world > 1 else ""),
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
                    "double_buffered_steps": ns, "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
@@ -263,6 +268,8 @@ def main():
                 return O.filter_armours(lb, p)
             if svm:
                 O.classify_armours(host[f], r["armours"], svm)
+            if args.pose:
+                O.locate_armours(r["armours"])
             return r["armours"]
         t0 = time.perf_counter()
         tot = 0

@@ -97,6 +97,8 @@ typedef struct {            /* capacities of one context; 0 = default */
 #define RMCV_STAGE_BLOBS 4    /* filter_lightblobs                   src/objdetect.cpp:55-87  */
 #define RMCV_STAGE_ARMOURS 8  /* filter_armours                      src/objdetect.cpp:114-166 */
 #define RMCV_STAGE_ALL 15
+#define RMCV_STAGE_POSE 32     /* solve_PnP + world position per armour, src/mobility.cpp:166-190, executable/main.cpp:183-192;
+                                 needs rmcv_pnp_load */
 #define RMCV_STAGE_IDENTITY 16 /* affine_correction + flatten + svm->predict per armour (BASELINE config 5),
                                  src/imgproc.cpp:9-35, src/core.cpp:202-216, executable/main.cpp:180-181; needs rmcv_svm_load */
 
@@ -222,6 +224,25 @@ int rmcv_lightblob_overlap(const rmcv_lightblob* blobs, int n, int left, int rig
 /* batch: like rmcv_batch_run, but RMCV_STAGE_BLOBS runs FindLightBlobs with `lp` on every frame's contours (blobs of all
  * camps, in findContours order); RMCV_STAGE_ARMOURS then pairs the blobs whose camp is p->camp. */
 int rmcv_batch_run_legacy(rmcv_ctx* ctx, const rmcv_params* p, const rmcv_legacy_params* lp, int stages, void* hip_stream);
+
+/* ---- armour pose: the "next" row SURVEY 8f-3 (src/mobility.cpp:166-190, executable/main.cpp:183-192) -------- */
+typedef struct {               /* what the process loop hands to rm::solve_PnP and the world transform */
+    double camera_matrix[9];   /* cammat, row-major 3x3                        executable/main.cpp:7-10  */
+    double dist[5];            /* discof: k1 k2 p1 p2 k3                       executable/main.cpp:11-13 */
+    double gripper2camera[16]; /* h_gripper2camera, row-major 4x4              executable/main.cpp:14-19 */
+    float  square_w, square_h; /* exactSize                                    executable/main.cpp:184 {27, 27} */
+} rmcv_pnp_config;
+void rmcv_default_pnp_config(rmcv_pnp_config* c); /* the literals of executable/main.cpp:7-19, 184 */
+int  rmcv_pnp_load(rmcv_ctx* ctx, const rmcv_pnp_config* cfg);
+/* single frame: for each armour rvec/tvec = rm::solve_PnP(armour.vertices, cammat, discof, exactSize) and
+ * position = base2gripper * (gripper2camera * [tvec; 1]) (executable/main.cpp:186-192).  base2gripper: row-major 4x4
+ * (h_base2gripper of executable/main.cpp:170), NULL = identity.  Outputs n x 3 doubles each, any may be NULL. */
+int  rmcv_locate_armours(rmcv_ctx* ctx, const rmcv_armour* armours, int n, const double* base2gripper, double* rvecs,
+                         double* tvecs, double* positions);
+/* batch: one base2gripper per frame (n_frames x 16 doubles, host; default identity), used by RMCV_STAGE_POSE */
+int  rmcv_batch_set_base2gripper(rmcv_ctx* ctx, const double* mats, int n_frames);
+/* batch: poses in the order of rmcv_batch_get_armours (after a run that included RMCV_STAGE_POSE) */
+int  rmcv_batch_get_poses(rmcv_ctx* ctx, double* rvecs, double* tvecs, double* positions, int cap, int32_t* n_total);
 
 /* ---- synthetic stream: host generator, integer-only, bit-reproducible --- */
 int      rmcv_synth_frame(uint8_t* bgr, int w, int h, int stride, uint64_t frame_index, int camp, int variant);

@@ -8,7 +8,8 @@
 // Usage: compile this header into ONE translation unit of librmcv in place of
 // those three bodies, after including the reference's own "core.h" (it supplies rm::camp, rm::range,
 // rm::contour, rm::lightblob, rm::armour and the cv:: types), and link librmcv_hip.so.
-// Also the legacy matcher rm::MatchLightBlob / rm::FindLightBlobs / rm::LightBlobOverlap (include/objdetect.h:22-37, 62).
+// Also the legacy matcher rm::MatchLightBlob / rm::FindLightBlobs / rm::LightBlobOverlap (include/objdetect.h:22-37, 62)
+// and rm::solve_PnP (include/mobility.h:106-108).
 // The legacy names of the north star are aliased at the bottom (docs/core_8h_source.html:101,114).
 //
 // Every signature mentions cv:: types, so this header only compiles where OpenCV headers exist.
@@ -202,6 +203,29 @@ inline bool LightBlobOverlap(const std::vector<rm::lightblob>& lightBlobs, int l
     if (rmcv_lightblob_overlap(in.data(), (int)in.size(), leftIndex, rightIndex, &overlap) != RMCV_OK)
         throw std::out_of_range("rm::LightBlobOverlap: rightIndex == lightBlobs.size() (the reference reads past the end here)");
     return overlap != 0;
+}
+
+// ---- armour pose (include/mobility.h:106-108; body src/mobility.cpp:166-190).  The default argument ROI = {0,0,0,0} lives on
+// the reference's declaration.  cameraMatrix: 3x3 CV_64F, distortionFactor: 1x5 (or 5x1) CV_64F, as executable/main.cpp:7-13.
+inline std::tuple<cv::Mat, cv::Mat> solve_PnP(const cv::Point2f points_image[4], cv::InputArray cameraMatrix,
+                                              cv::InputArray distortionFactor, const cv::Size2f& exactSize, const cv::Rect& ROI)
+{
+    const cv::Mat K = cameraMatrix.getMat(), D = distortionFactor.getMat();
+    CV_Assert(K.type() == CV_64F && K.total() == 9 && D.type() == CV_64F && D.total() == 5 && K.isContinuous() && D.isContinuous());
+    rmcv_pnp_config cfg;
+    rmcv_default_pnp_config(&cfg);
+    for (int i = 0; i < 9; i++) cfg.camera_matrix[i] = K.ptr<double>()[i];
+    for (int i = 0; i < 5; i++) cfg.dist[i] = D.ptr<double>()[i];
+    cfg.square_w = exactSize.width;
+    cfg.square_h = exactSize.height;
+    hip_detail::check(rmcv_pnp_load(hip_detail::ctx(), &cfg));
+    rmcv_armour a{};
+    const float ox = static_cast<float>(ROI.x), oy = static_cast<float>(ROI.y); // src/mobility.cpp:172, 182-185
+    for (int i = 0; i < 4; i++) { a.vertices[i][0] = points_image[i].x + ox; a.vertices[i][1] = points_image[i].y + oy; }
+    cv::Mat rotation_vector(3, 1, CV_64F), translation_vector(3, 1, CV_64F);
+    hip_detail::check(rmcv_locate_armours(hip_detail::ctx(), &a, 1, nullptr, rotation_vector.ptr<double>(),
+                                          translation_vector.ptr<double>(), nullptr));
+    return {rotation_vector, translation_vector};
 }
 
 using LightBlob = lightblob; // pre-2024 API names used by the north star

@@ -143,6 +143,22 @@ int  orc_find_lightblobs(const uint8_t* bgr, int w, int h, int stride, const orc
                          orc_rrect* boxes /* optional, per blob */);
 int  orc_lightblob_overlap(const orc_lightblob* blobs, int n, int left, int right); /* 1/0; -1: right == n (UB in the reference) */
 
+/* ------------------------------------------------------------------------------------------------
+ * "Next" row SURVEY 8f-3 (rmcv_oracle_pnp.c): per-armour pose
+ *   rm::solve_PnP /root/reference/src/mobility.cpp:166-190 ([OCV] solvePnP SOLVEPNP_IPPE_SQUARE = undistortPoints + IPPE),
+ *   camera -> world position /root/reference/executable/main.cpp:183-192, camera constants main.cpp:7-19. */
+typedef struct {
+    double camera_matrix[9];   /* row-major 3x3 */
+    double dist[5];            /* k1 k2 p1 p2 k3 */
+    double gripper2camera[16]; /* row-major 4x4, main.cpp:15-19 */
+    float  square_w, square_h; /* main.cpp:184 {27, 27} */
+} orc_pnp_config;
+void orc_default_pnp_config(orc_pnp_config* c);
+int  orc_solve_pnp(const float vertices[4][2], const orc_pnp_config* cfg, double rvec[3], double tvec[3]);
+void orc_armour_position(const double tvec[3], const double base2gripper[16], const double gripper2camera[16], double pos[3]);
+void orc_locate_armours(const orc_armour* armours, int n, const orc_pnp_config* cfg, const double base2gripper[16] /* NULL = I */,
+                        double* rvecs, double* tvecs, double* positions);
+
 #ifdef __cplusplus
 }
 #endif

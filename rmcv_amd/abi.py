@@ -22,7 +22,7 @@ assert POINT.itemsize == 8 and LIGHTBLOB.itemsize == 56 and ARMOUR.itemsize == 8
 OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 CAMP_RED, CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL = 0, 1, 2, -1
 MORPH_NONE, MORPH_DILATE, MORPH_CLOSE = 0, 1, 2
-STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY = 1, 2, 4, 8, 15, 16
+STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE = 1, 2, 4, 8, 15, 16, 32
 SVM_FEATURES = 1200
 FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_SLOW_PATH = 1, 2, 4, 8, 16
 
@@ -33,6 +33,7 @@ EXPORTS = [
     "rmcv_batch_counts", "rmcv_batch_get_binary", "rmcv_batch_get_contours", "rmcv_batch_get_blobs",
     "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_batch_compact_armours", "rmcv_synth_frame", "rmcv_synth_checksum",
     "rmcv_svm_load", "rmcv_classify_armours", "rmcv_batch_get_identities", "rmcv_batch_get_icons",
+    "rmcv_default_pnp_config", "rmcv_pnp_load", "rmcv_locate_armours", "rmcv_batch_set_base2gripper", "rmcv_batch_get_poses",
     "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
 ]
 
@@ -49,6 +50,12 @@ class LegacyParams(C.Structure):
     """rmcv_legacy_params: the float arguments of rm::MatchLightBlob / rm::FindLightBlobs (include/objdetect.h:22-37)"""
     _fields_ = [("min_ratio", C.c_float), ("max_ratio", C.c_float), ("tilt_angle", C.c_float), ("min_area", C.c_float),
                 ("max_area", C.c_float), ("fit_ellipse", C.c_int32)]
+
+
+class PnpConfig(C.Structure):
+    """rmcv_pnp_config: cammat / discof / h_gripper2camera / exactSize of the reference's executable/main.cpp:7-19, 184"""
+    _fields_ = [("camera_matrix", C.c_double * 9), ("dist", C.c_double * 5), ("gripper2camera", C.c_double * 16),
+                ("square_w", C.c_float), ("square_h", C.c_float)]
 
 
 class Limits(C.Structure):
@@ -84,6 +91,12 @@ def lib():
 
 def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_pnp_config():
+    c = PnpConfig()
+    lib().rmcv_default_pnp_config(C.byref(c))
+    return c
 
 
 def default_params(**kw):

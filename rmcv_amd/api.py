@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .abi import (ARMOUR, CAMP_BLUE, LIGHTBLOB, MORPH_CLOSE, POINT, RRECT, STAGE_ALL, LegacyParams, Limits, Params, RmcvError,
+from .abi import (ARMOUR, CAMP_BLUE, LIGHTBLOB, MORPH_CLOSE, POINT, RRECT, STAGE_ALL, LegacyParams, Limits, Params, PnpConfig, RmcvError, default_pnp_config,
                   default_params, lib, ptr)
 
 
@@ -104,6 +104,34 @@ class Context:
         out = np.zeros(1, RRECT)
         self._chk(lib().rmcv_fit_ellipse(self._h, ptr(pts), len(pts), ptr(out)))
         return out[0]
+
+    # ---------------------------------------------------------------- armour pose (src/mobility.cpp:166-190, main.cpp:183-192)
+    def pnp_load(self, cfg=None):
+        """camera matrix, distortion, gripper->camera transform, square size (defaults: the reference's main.cpp literals)"""
+        self._pnp = cfg or default_pnp_config()
+        self._chk(lib().rmcv_pnp_load(self._h, C.byref(self._pnp)))
+
+    def locate_armours(self, armours, base2gripper=None):
+        """per armour: rm::solve_PnP on its vertices + the world transform; returns (rvecs, tvecs, positions), each [n, 3]"""
+        arm = np.ascontiguousarray(armours, ARMOUR)
+        n = len(arm)
+        r, t, p = np.zeros((max(n, 1), 3)), np.zeros((max(n, 1), 3)), np.zeros((max(n, 1), 3))
+        b = None if base2gripper is None else np.ascontiguousarray(base2gripper, np.float64).reshape(16)
+        self._chk(lib().rmcv_locate_armours(self._h, ptr(arm), n, ptr(b) if b is not None else None, ptr(r), ptr(t), ptr(p)))
+        return r[:n], t[:n], p[:n]
+
+    def set_base2gripper(self, mats):
+        """one row-major 4x4 per frame of the batch (h_base2gripper, main.cpp:170)"""
+        m = np.ascontiguousarray(mats, np.float64).reshape(-1, 16)
+        self._chk(lib().rmcv_batch_set_base2gripper(self._h, ptr(m), len(m)))
+
+    def poses(self):
+        """(rvecs, tvecs, positions) of all armours of the batch in the order of armours()"""
+        cap = self.shape[0] * self.limits.max_armours
+        r, t, p = np.zeros((cap, 3)), np.zeros((cap, 3)), np.zeros((cap, 3))
+        tot = C.c_int32(0)
+        self._chk(lib().rmcv_batch_get_poses(self._h, ptr(r), ptr(t), ptr(p), cap, C.byref(tot)))
+        return r[:tot.value].copy(), t[:tot.value].copy(), p[:tot.value].copy()
 
     # ---------------------------------------------------------------- legacy matcher (src/objdetect.cpp:9-53, 89-112)
     def min_area_rect(self, pts):

@@ -185,6 +185,53 @@ PM_FN double pm_atan2(double y, double x)
     }
 }
 
+/* arccosine (IPPE's rotation-vector conversion, the solve_PnP row): the classic rational kernel R(z) ~ (asin(x) - x) / x^3
+ * on |x| <= 0.5 and the sqrt reductions outside, |error| < 1 ulp.  sqrt is IEEE (correctly rounded) on host and device. */
+PM_FN double pm_acos(double x)
+{
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pi = 3.14159265358979311600e+00;
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+                 pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+                 qS4 = 7.70381505559019352791e-02;
+    double ax = pm_fabs(x), z, p, q, r, s, w;
+    if (x != x) return x;
+    if (ax >= 1.0) {
+        if (x == 1.0) return 0.0;
+        if (x == -1.0) return pi + 2.0 * pio2_lo;
+        return (x - x) / (x - x); /* NaN */
+    }
+    if (ax < 0.5) {
+        if (ax < 6.938893903907228e-18) return pio2_hi + pio2_lo; /* 2^-57 */
+        z = x * x;
+        p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (x < 0) {
+        z = (1.0 + x) * 0.5;
+        p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        s = __builtin_sqrt(z);
+        r = p / q;
+        w = r * s - pio2_lo;
+        return pi - 2.0 * (s + w);
+    }
+    {
+        double df, c;
+        z = (1.0 - x) * 0.5;
+        s = __builtin_sqrt(z);
+        df = pm_hi_word_only(s);
+        c = (z - df * df) / (s + df);
+        p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        r = p / q;
+        w = r * s + c;
+        return 2.0 * (df + w);
+    }
+}
+
 /* float variants: one evaluation in double, one rounding */
 PM_FN float pm_atan2f(float y, float x) { return (float)pm_atan2((double)y, (double)x); }
 PM_FN float pm_sinf(float x) { return (float)pm_sin((double)x); }

@@ -231,6 +231,10 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
         if (!b.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
         HIPCHK(c, launch_classify(g, b, c->lim, s), "k_classify");
     }
+    if (stages & RMCV_STAGE_POSE) {
+        if (!b.pnp_cfg) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_POSE needs rmcv_pnp_load first");
+        HIPCHK(c, launch_pnp(g, b, c->lim, s), "k_pnp");
+    }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     c->last_stream = s;
     return RMCV_OK;
@@ -241,7 +245,7 @@ static int check_params(rmcv_ctx* c, const rmcv_params* p, int stages)
     if (!c) return RMCV_ERR_BAD_ARG;
     if (!p) return fail(c, RMCV_ERR_BAD_ARG, "null params");
     if (p->morph < RMCV_MORPH_NONE || p->morph > RMCV_MORPH_CLOSE) return fail(c, RMCV_ERR_BAD_ARG, "bad morph");
-    if (stages <= 0 || stages > (RMCV_STAGE_ALL | RMCV_STAGE_IDENTITY)) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
+    if (stages <= 0 || stages > (RMCV_STAGE_ALL | RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE)) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
     if (c->geom.n_frames <= 0 || !c->bufs.frames) {
         if (stages & RMCV_STAGE_BINARY) return fail(c, RMCV_ERR_BAD_ARG, "no frames bound");
     }
@@ -681,6 +685,110 @@ int rmcv_fit_ellipse(rmcv_ctx* c, const rmcv_point* pts, int n, rmcv_rrect* out)
     HIPCHK(c, hipMemcpy(&nn, c->bufs.n_neg, 4, hipMemcpyDeviceToHost), "D2H");
     if (nb != 1) return fail(c, RMCV_ERR_BAD_ARG, n < 6 ? "contour has fewer than 6 points" : "ellipse fit produced NaN");
     HIPCHK(c, hipMemcpy(out, c->bufs.ellipses, sizeof(rmcv_rrect), hipMemcpyDeviceToHost), "D2H ellipse");
+    return RMCV_OK;
+}
+
+// ---- armour pose ------------------------------------------------------------------------------------------
+void rmcv_default_pnp_config(rmcv_pnp_config* c)
+{
+    if (!c) return;
+    // executable/main.cpp:7-19: every literal carries an `f` suffix, i.e. it is a float widened to double
+    const float K[9] = {1782.672144409928f, 0.0f, 598.8983414505224f, 0.0f, 1783.860175007369f, 523.4209809658056f, 0.0f, 0.0f, 1.0f};
+    const float D[5] = {-0.03436366268485048f, 0.1953669264956857f, 0.0001485060439399386f, -0.003814875777013483f,
+                        -0.3181808766352414f};
+    const float G[16] = {0.0007941130268316332f, 0.009683274185178004f, -0.9999528006788897f, -27.25811584661768f,
+                         0.9989588796104363f, 0.04560298009571095f, 0.001234930707386894f, -51.46996511920027f,
+                         0.04561278583864914f, -0.9989127101040636f, -0.009636978810429797f, 77.11760876626687f,
+                         0.0f, 0.0f, 0.0f, 1.0f};
+    for (int i = 0; i < 9; i++) c->camera_matrix[i] = K[i];
+    for (int i = 0; i < 5; i++) c->dist[i] = D[i];
+    for (int i = 0; i < 16; i++) c->gripper2camera[i] = G[i];
+    c->square_w = 27.0f; // executable/main.cpp:184
+    c->square_h = 27.0f;
+}
+
+int rmcv_pnp_load(rmcv_ctx* c, const rmcv_pnp_config* cfg)
+{
+    if (!c || !cfg) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    Bufs& b = c->bufs;
+    if (!b.pnp_cfg) {
+        hipError_t e = dalloc(c, &b.pnp_cfg, 1);
+        if (e == hipSuccess) e = dalloc(c, &b.base2gripper, (size_t)c->lim.max_frames * 16);
+        if (e == hipSuccess) e = dalloc(c, &b.poses, (size_t)c->lim.max_frames * c->lim.max_armours * 9);
+        if (e != hipSuccess) { b.pnp_cfg = nullptr; return fail(c, RMCV_ERR_NOMEM, "pnp buffers", e); }
+        std::vector<double> eye((size_t)c->lim.max_frames * 16, 0.0);
+        for (int f = 0; f < c->lim.max_frames; f++)
+            for (int k = 0; k < 4; k++) eye[(size_t)f * 16 + 5 * k] = 1.0;
+        HIPCHK(c, hipMemcpy(b.base2gripper, eye.data(), eye.size() * sizeof(double), hipMemcpyHostToDevice), "H2D base2gripper");
+    }
+    HIPCHK(c, hipMemcpy(b.pnp_cfg, cfg, sizeof(*cfg), hipMemcpyHostToDevice), "H2D pnp config");
+    return RMCV_OK;
+}
+
+int rmcv_batch_set_base2gripper(rmcv_ctx* c, const double* mats, int n_frames)
+{
+    if (!c || !mats || n_frames < 1) return RMCV_ERR_BAD_ARG;
+    if (!c->bufs.pnp_cfg) return fail(c, RMCV_ERR_BAD_ARG, "rmcv_pnp_load first");
+    if (n_frames > c->lim.max_frames) return fail(c, RMCV_ERR_CAPACITY, "more frames than the context holds");
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(c->bufs.base2gripper, mats, (size_t)n_frames * 16 * sizeof(double), hipMemcpyHostToDevice), "H2D base2gripper");
+    return RMCV_OK;
+}
+
+static void scatter_poses(const std::vector<double>& all, size_t src, double* rvecs, double* tvecs, double* positions, size_t dst)
+{
+    for (int k = 0; k < 3; k++) {
+        if (rvecs) rvecs[3 * dst + k] = all[9 * src + k];
+        if (tvecs) tvecs[3 * dst + k] = all[9 * src + 3 + k];
+        if (positions) positions[3 * dst + k] = all[9 * src + 6 + k];
+    }
+}
+
+int rmcv_batch_get_poses(rmcv_ctx* c, double* rvecs, double* tvecs, double* positions, int cap, int32_t* n_total)
+{
+    if (!c || !c->bufs.poses) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    const int nf = c->geom.n_frames;
+    std::vector<int32_t> cnt(nf);
+    std::vector<double> all((size_t)nf * c->lim.max_armours * 9);
+    HIPCHK(c, hipMemcpy(cnt.data(), c->bufs.n_armours, (size_t)nf * 4, hipMemcpyDeviceToHost), "D2H");
+    HIPCHK(c, hipMemcpy(all.data(), c->bufs.poses, all.size() * sizeof(double), hipMemcpyDeviceToHost), "D2H poses");
+    int64_t total = 0;
+    for (int f = 0; f < nf; f++) total += cnt[f];
+    if (n_total) *n_total = (int32_t)total;
+    if (total > cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    size_t o = 0;
+    for (int f = 0; f < nf; f++)
+        for (int a = 0; a < cnt[f]; a++) scatter_poses(all, (size_t)f * c->lim.max_armours + a, rvecs, tvecs, positions, o++);
+    return RMCV_OK;
+}
+
+int rmcv_locate_armours(rmcv_ctx* c, const rmcv_armour* armours, int n, const double* base2gripper, double* rvecs, double* tvecs,
+                        double* positions)
+{
+    if (!c || n < 0 || (n > 0 && !armours)) return RMCV_ERR_BAD_ARG;
+    if (!c->bufs.pnp_cfg) return fail(c, RMCV_ERR_BAD_ARG, "rmcv_pnp_load first");
+    if (n > c->lim.max_armours) return fail(c, RMCV_ERR_CAPACITY, "too many armours for this context");
+    if (n == 0) return RMCV_OK;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    HIPCHK(c, hipMemcpy(c->bufs.armours, armours, (size_t)n * sizeof(rmcv_armour), hipMemcpyHostToDevice), "H2D armours");
+    HIPCHK(c, hipMemcpy(c->bufs.n_armours, &n, 4, hipMemcpyHostToDevice), "H2D");
+    HIPCHK(c, hipMemcpy(c->bufs.base2gripper, base2gripper ? base2gripper : eye, sizeof(eye), hipMemcpyHostToDevice), "H2D base2gripper");
+    Geom g1 = c->geom;
+    g1.n_frames = 1;
+    HIPCHK(c, launch_pnp(g1, c->bufs, c->lim, c->stream), "k_pnp");
+    HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+    std::vector<double> all((size_t)n * 9);
+    HIPCHK(c, hipMemcpy(all.data(), c->bufs.poses, all.size() * sizeof(double), hipMemcpyDeviceToHost), "D2H poses");
+    for (int a = 0; a < n; a++) scatter_poses(all, (size_t)a, rvecs, tvecs, positions, (size_t)a);
     return RMCV_OK;
 }
 

@@ -63,11 +63,16 @@ struct Bufs {
     int svm_classes;
     int32_t* identity;     // [frame][max_armours]
     uint8_t* icons;        // [frame][max_armours][1200]  rectified 20x20 BGR icons
+    // armour pose; allocated by rmcv_pnp_load
+    rmcv_pnp_config* pnp_cfg;
+    double* base2gripper;  // [frame][16]
+    double* poses;         // [frame][max_armours][9]  rvec | tvec | world position
 };
 
 // kernel launchers (each enqueues on `s` and returns the launch error)
 hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, const rmcv_legacy_params& lp,
                         int mode, bool with_frames, bool pairs, hipStream_t s);
+hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, hipStream_t s);
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);

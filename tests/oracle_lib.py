@@ -253,3 +253,35 @@ def find_lightblobs(bgr, pts, offs, min_ratio, max_ratio, tilt_angle, min_area, 
 def lightblob_overlap(blobs, left, right):
     blobs = np.ascontiguousarray(blobs, LIGHTBLOB)
     return lib().orc_lightblob_overlap(_p(blobs), len(blobs), int(left), int(right))
+
+
+# ---------------------------------------------------------------- solve_PnP (oracle/rmcv_oracle_pnp.c)
+class PnpConfig(C.Structure):
+    _fields_ = [("camera_matrix", C.c_double * 9), ("dist", C.c_double * 5), ("gripper2camera", C.c_double * 16),
+                ("square_w", C.c_float), ("square_h", C.c_float)]
+
+
+def default_pnp_config():
+    c = PnpConfig()
+    lib().orc_default_pnp_config(C.byref(c))
+    return c
+
+
+def solve_pnp(vertices, cfg=None):
+    """vertices: 4x2 float32 (armour.vertices).  returns (rc, rvec[3], tvec[3])"""
+    cfg = cfg or default_pnp_config()
+    v = np.ascontiguousarray(vertices, np.float32).reshape(4, 2)
+    r, t = np.zeros(3), np.zeros(3)
+    rc = lib().orc_solve_pnp(_p(v), C.byref(cfg), _p(r), _p(t))
+    return rc, r, t
+
+
+def locate_armours(armours, cfg=None, base2gripper=None):
+    """returns (rvecs[n,3], tvecs[n,3], positions[n,3])"""
+    cfg = cfg or default_pnp_config()
+    arm = np.ascontiguousarray(armours, ARMOUR)
+    n = len(arm)
+    r, t, p = np.zeros((max(n, 1), 3)), np.zeros((max(n, 1), 3)), np.zeros((max(n, 1), 3))
+    b = None if base2gripper is None else np.ascontiguousarray(base2gripper, np.float64).reshape(16)
+    lib().orc_locate_armours(_p(arm), n, C.byref(cfg), _p(b) if b is not None else None, _p(r), _p(t), _p(p))
+    return r[:n], t[:n], p[:n]

@@ -66,6 +66,17 @@ int main(int argc, char** argv)
     int overlaps = 0;
     for (int i = 0; i + 2 < (int)legacy.size(); i++) overlaps += rm::LightBlobOverlap(legacy, i, i + 2) ? 1 : 0;
     std::printf("matched %zu overlaps %d\n", matched, overlaps);
+    // the pose of every armour: rm::solve_PnP with the camera constants of executable/main.cpp:7-13
+    rmcv_pnp_config pc;
+    rmcv_default_pnp_config(&pc);
+    cv::Mat cammat(3, 3, CV_64F), discof(1, 5, CV_64F);
+    for (int i = 0; i < 9; i++) cammat.ptr<double>()[i] = pc.camera_matrix[i];
+    for (int i = 0; i < 5; i++) discof.ptr<double>()[i] = pc.dist[i];
+    for (auto& a : armours) {
+        auto [rvec, tvec] = rm::solve_PnP(a.vertices, cammat, discof, {27, 27}, cv::Rect(0, 0, 0, 0));
+        std::printf("pose %a %a %a %a %a %a\n", rvec.ptr<double>()[0], rvec.ptr<double>()[1], rvec.ptr<double>()[2],
+                    tvec.ptr<double>()[0], tvec.ptr<double>()[1], tvec.ptr<double>()[2]);
+    }
     rm::LightBlob* alias_check = positive.empty() ? nullptr : &positive[0];
     (void)alias_check;
     return 0;

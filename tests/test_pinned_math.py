@@ -23,6 +23,7 @@ void r_atan2f(const float* y, const float* x, float* o, int n) { for (int i = 0;
 void r_sinf(const float* x, float* o, int n) { for (int i = 0; i < n; i++) o[i] = sinf(x[i]); }
 void r_cosf(const float* x, float* o, int n) { for (int i = 0; i < n; i++) o[i] = cosf(x[i]); }
 double t_fmod180(double x) { return pm_fmod180(x); }
+void t_acos(const double* x, double* o, int n) { for (int i = 0; i < n; i++) o[i] = pm_acos(x[i]); }
 '''
 
 
@@ -93,3 +94,13 @@ def test_float_variants(pm):
         theirs(_p(th), _p(r), n)
         assert np.count_nonzero(o != ref(th.astype(np.float64)).astype(np.float32)) <= 1
         assert np.abs(o.view(np.int32) - r.view(np.int32)).max() <= 1
+
+
+def test_acos_double(pm):
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.uniform(-1, 1, 200000), np.linspace(-1, 1, 4001), 1 - np.geomspace(1e-16, 1e-3, 2000),
+                        -1 + np.geomspace(1e-16, 1e-3, 2000), rng.uniform(-1e-9, 1e-9, 1000)])
+    o = np.empty_like(x)
+    pm.t_acos(_p(x), _p(o), len(x))
+    assert ulps(o, np.arccos(x)).max() <= 1
+    assert o[np.argmax(x == 1.0)] == 0.0 if (x == 1.0).any() else True

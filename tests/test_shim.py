@@ -40,6 +40,9 @@ def test_shim_matches_oracle(tmp_path, oracle):
         got = [[float.fromhex(t) for t in line.split()[1:]] for line in arm_lines]
         exp = [[float(v) for v in a["vertices"].reshape(-1)] for a in ref["armours"]]
         assert got == exp
+        poses = [[float.fromhex(t) for t in l.split()[1:]] for l in out if l.startswith("pose")]
+        wr, wt, _ = oracle.locate_armours(ref["armours"])
+        assert poses == [list(r) + list(t) for r, t in zip(wr.tolist(), wt.tolist())]
         # legacy matcher through the shim: FindLightBlobs(fitEllipse=false), MatchLightBlob(fitEllipse=true), LightBlobOverlap
         frame = synth.frame(index)
         lb, _, _ = oracle.find_lightblobs(frame, ref["pts"], ref["offs"], 1.5, 80, 70, 10, 99999, False)
