@@ -17,9 +17,12 @@
 // LAB/NEG, and re-scans only the rows the trace touched below the start.  Exact for every input.
 //
 // Output is kept in DISCOVERY order (cont_start/cont_len); findContours order is its reverse.
+#include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "rmcv_internal.h"
+#include "wave_detect.h"
 
 namespace rmcv {
 
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
                                                         int32_t* cont_len, int32_t* n_contours, int32_t* n_points,
                                                         int32_t* status, int max_contours, int max_points, int force_literal,
                                                         int32_t* __restrict__ elig, int32_t* __restrict__ n_elig,
-                                                        int32_t* __restrict__ slot_kind)
+                                                        int32_t* __restrict__ slot_kind, SparseTail X)
 {
     extern __shared__ unsigned long long smem_raw[];
     __builtin_amdgcn_s_setprio(3); // latency-bound: issue ahead of the streaming pixel kernel of the next batch sharing the CU
@@ -709,8 +712,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
             n_elig[f] = S.nelig;
             status[f] = S.lit[2] | RMCV_FRAME_SLOW_PATH;
         }
-        return;
-    }
+    } else {
     STAMP();
 #ifdef RMCV_PROFILE
     if (tid == 0 && (f == 0 || f == 100))
@@ -735,9 +737,37 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint64_t* __restr
         n_elig[f] = S.nelig;
         status[f] = 0;
     }
+    }
+    if (!X.fused) return;
+    // ---------------- fused tail: rm::filter_lightblobs + rm::filter_armours of THIS frame in the same workgroup, so a batch
+    // has one sparse launch and a frame's stages follow each other without waiting for the slowest frame of every stage.
+    // The 8 wavefronts take the contours of the work list (one contour each at a time), then wavefront 0 compacts and pairs.
+    __syncthreads(); // the lists this workgroup wrote to global memory are visible to all of its wavefronts
+    const int nc = complex ? S.lit[0] : S.nkept, ne = S.nelig;
+    __syncthreads(); // everybody has read the counters: the contour tables make room for the fit's wave-private rows
+    {
+        WaveLds& L = reinterpret_cast<WaveLds*>(smem_raw)[wave];
+        const int32_t* el = elig + (int64_t)f * max_contours;
+        // static split: pulling contours from an LDS counter instead measured 1 % slower (a frame has ~10 eligible contours)
+        for (int e = wave; e < ne; e += CT_THREADS / 64)
+            fit_contour_slot(f, el[e], nc, pts, cs, cl, max_contours, max_points, X.G, slot_kind, X.slot_ell, L, lane);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const FitTail& T = X.T;
+        const int np = blob_compact_frame(f, lane, slot_kind, X.slot_ell, nc, max_contours, T.enemy, T.blobs, T.blob_src, T.ellipses,
+                                          T.neg_idx, T.n_blobs, T.n_neg, T.status, T.max_blobs);
+        if (T.do_pairs) {
+            __threadfence(); // the pair loop re-reads, across lanes, the blobs this wave just wrote
+            armours_frame(f, lane, T.blobs, np, T.max_blobs, T.angle_diff_max, T.shear_max, T.length_ratio_max, T.enemy, T.armours,
+                          T.n_armours, T.status, T.max_armours);
+        }
+    }
 }
 
-hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)
+static_assert(sizeof(ContoursLds) >= (CT_THREADS / 64) * sizeof(WaveLds), "the fit rows reuse the contour tables");
+
+static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, hipStream_t s)
 {
     static const int force_literal = getenv("RMCV_CONTOURS_LITERAL") ? atoi(getenv("RMCV_CONTOURS_LITERAL")) : 0; // dev/test knob
     static bool attr_set = false;
@@ -749,8 +779,43 @@ hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipS
     }
     hipLaunchKernelGGL(k_contours, dim3(g.n_frames), dim3(CT_THREADS), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg,
                        g.w, g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points,
-                       b.status, lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind);
+                       b.status, lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind, X);
     return hipGetLastError();
+}
+
+hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)
+{
+    SparseTail X;
+    memset(&X, 0, sizeof(X));
+    return launch_contours_x(g, b, lim, X, s);
+}
+
+// findContours + filter_lightblobs (+ filter_armours) of every frame in ONE launch
+hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s)
+{
+    SparseTail X;
+    memset(&X, 0, sizeof(X));
+    X.fused = 1;
+    X.G = {p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi};
+    X.slot_ell = b.slot_ell;
+    FitTail& T = X.T;
+    T.blobs = b.blobs;
+    T.blob_src = b.blob_src;
+    T.ellipses = b.ellipses;
+    T.neg_idx = b.neg_idx;
+    T.n_blobs = b.n_blobs;
+    T.n_neg = b.n_neg;
+    T.status = b.status;
+    T.armours = b.armours;
+    T.n_armours = b.n_armours;
+    T.max_blobs = lim.max_blobs;
+    T.max_armours = lim.max_armours;
+    T.enemy = p.camp;
+    T.do_pairs = pairs ? 1 : 0;
+    T.angle_diff_max = p.angle_diff_max;
+    T.shear_max = p.shear_max;
+    T.length_ratio_max = p.length_ratio_max;
+    return launch_contours_x(g, b, lim, X, s);
 }
 
 // contours of every frame as CSR in findContours order (reverse discovery), for download

@@ -219,14 +219,20 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     if (!(stages & RMCV_STAGE_CONTOURS)) HIPCHK(c, hipMemsetAsync(b.status, 0, (size_t)g.n_frames * 4, s), "memset status");
     if (stages & RMCV_STAGE_BINARY) HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, s), "k_binary");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
-    if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
+    // findContours + filter_lightblobs (+ filter_armours) as ONE per-frame kernel when the stages are asked for together;
+    // the per-stage events of rmcv_batch_run_timed need per-stage launches (RMCV_FUSE_SPARSE=0: dev knob for A/B runs)
+    static const bool fuse_ok = !(getenv("RMCV_FUSE_SPARSE") && atoi(getenv("RMCV_FUSE_SPARSE")) == 0);
+    const bool one_sparse = fuse_ok && !timed && !lp && (stages & RMCV_STAGE_CONTOURS) && (stages & RMCV_STAGE_BLOBS);
+    if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, s), "k_contours (fused)");
+    else if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     const bool fused = (stages & RMCV_STAGE_BLOBS) && (stages & RMCV_STAGE_ARMOURS); // one launch for both
-    if (lp && (stages & RMCV_STAGE_BLOBS)) HIPCHK(c, launch_match(g, b, c->lim, *p, *lp, 0, b.frames != nullptr, fused, s), "k_match");
+    if (one_sparse) {
+    } else if (lp && (stages & RMCV_STAGE_BLOBS)) HIPCHK(c, launch_match(g, b, c->lim, *p, *lp, 0, b.frames != nullptr, fused, s), "k_match");
     else if (fused) HIPCHK(c, launch_blobs_armours(g, b, c->lim, *p, s), "k_fit");
     else if (stages & RMCV_STAGE_BLOBS) HIPCHK(c, launch_blobs(g, b, c->lim, *p, s), "k_fit");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
-    if (!fused && (stages & RMCV_STAGE_ARMOURS)) HIPCHK(c, launch_armours(g, b, c->lim, *p, s), "k_armours");
+    if (!one_sparse && !fused && (stages & RMCV_STAGE_ARMOURS)) HIPCHK(c, launch_armours(g, b, c->lim, *p, s), "k_armours");
     if (stages & RMCV_STAGE_IDENTITY) {
         if (!b.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
         HIPCHK(c, launch_classify(g, b, c->lim, s), "k_classify");

@@ -1,0 +1,409 @@
+// wave_detect.h -- wave-cooperative device code of rm::filter_lightblobs / rm::filter_armours shared by k_detect.hip (the
+// stand-alone kernels of the stage-wise entry points) and k_contours.hip (the fused per-frame kernel): the ellipse fit of one
+// contour by one wavefront, the ordered compaction into the positive / negative lists and the pair loop.
+#pragma once
+#include "device_fit.h"
+#include "rmcv_internal.h"
+
+namespace rmcv {
+
+__device__ __forceinline__ int lanes_below(uint64_t m, int lane) { return __popcll(m & ((1ull << lane) - 1)); }
+
+// ---- wave-cooperative per-contour work ------------------------------------------------------------------
+// One wavefront owns one contour.  What is order dependent (the double-precision sums of scaled coordinates)
+// stays a strictly sequential chain in contour order, but the chains are independent of each other, so the 21
+// entries of the 6x6 scatter matrix (resp. 20 and 9 sums of the general fit) are accumulated by 21 different
+// lanes at once: per 64-point chunk every lane prepares the design-matrix row of ITS point (order independent)
+// in wave-private LDS, then lane e walks the 64 rows in order for ITS entry.  Integer-exact sums (shoelace area,
+// coordinate sums) are reduced in any order -- every partial sum is an exactly representable integer.
+struct WaveLds {
+    double rows[64][6];
+    double terms[64];
+    double dm[32];
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// sequential sum, in point order, of one double per point (the per-point term is computed by the point's lane)
+template <typename F>
+__device__ __forceinline__ double seq_sum_terms(int n, int lane, WaveLds& L, F term)
+{
+    double s = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const double t = i < n ? term(i) : 0.0;
+        const int m = n - base < 64 ? n - base : 64;
+        if (m == 64) {
+#pragma unroll
+            for (int j = 0; j < 64; j++) s += lane_get(t, j); // in point order: lane j holds point base+j
+        } else {
+            for (int j = 0; j < m; j++) s += lane_get(t, j);
+        }
+    }
+    return s;
+}
+
+// NR = row length, NS = number of sums; lane e < NS accumulates rows[j][la] * (lb < 0 ? konst : rows[j][lb])
+template <int NR, typename F>
+__device__ __forceinline__ double seq_sum_products(int n, int lane, WaveLds& L, int ns, int la, int lb, double konst, F make_row)
+{
+    double acc = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        if (i < n) {
+            double r[NR];
+            make_row(i, r);
+#pragma unroll
+            for (int k = 0; k < NR; k++) L.rows[lane][k] = r[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int m = n - base < 64 ? n - base : 64;
+        if (lane < ns) {
+            if (lb >= 0) {
+#pragma unroll 8
+                for (int j = 0; j < m; j++) acc += L.rows[j][la] * L.rows[j][lb];
+            } else {
+#pragma unroll 8
+                for (int j = 0; j < m; j++) acc += L.rows[j][la] * konst;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return acc;
+}
+
+// upper-triangle index e -> (a, b), a <= b, row-major, for a k x k symmetric matrix
+__device__ __forceinline__ void tri_index(int e, int k, int* a, int* b)
+{
+    int r = 0, rem = e;
+    while (r < k && rem >= k - r) { rem -= k - r; r++; }
+    *a = r;
+    *b = r + rem;
+}
+
+// cv::fitEllipseDirect (objdetect.cpp:68) for one contour, by one wavefront.  sumx/sumy = integer coordinate sums.
+// returns 0 = direct solution, 1 = general fit.  All results are wave-uniform.
+#ifdef RMCV_PROFILE
+#define FSTAMP(k) do { if (prof) prof[k] = wall_clock64(); } while (0)
+#else
+#define FSTAMP(k) do {} while (0)
+#endif
+__device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n, long long sumx, long long sumy, WaveLds& L, int lane,
+                                rmcv_rrect* box, long long* prof = nullptr)
+{
+    FSTAMP(0);
+    // ------------------------------------------------ direct (Fitzgibbon / Halir-Flusser)
+    {
+        const double cx = (double)sumx / n, cy = (double)sumy / n;
+        const double s = seq_sum_terms(n, lane, L, [&](int i) {
+            return dabs((float)pts[i].x - cx) + dabs((float)pts[i].y - cy);
+        });
+        const double scale = 100.0 / (s > FLT_EPSILON ? s : (double)FLT_EPSILON);
+        FSTAMP(1);
+        int la = 0, lb = 0;
+        tri_index(lane < 21 ? lane : 0, 6, &la, &lb);
+        double DM[6][6], TM[3][3], M[3][3], Ts = 0;
+        float eps = 0;
+        int iter;
+        for (iter = 0; iter < 2; iter++) {
+            const double acc = seq_sum_products<6>(n, lane, L, 21, la, lb, 0.0, [&](int i, double* r) {
+                float ox, oy;
+                get_ofs(i, eps, &ox, &oy);
+                const double px = (((float)pts[i].x + ox) - cx) * scale, py = (((float)pts[i].y + oy) - cy) * scale;
+                r[0] = px * px; r[1] = px * py; r[2] = py * py; r[3] = px; r[4] = py; r[5] = 1.0;
+            });
+            const double inv_n = 1.0 / n;
+            if (lane < 21) L.dm[lane] = acc * inv_n;
+            __builtin_amdgcn_wave_barrier();
+            {
+                int e = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = a; b < 6; b++, e++) DM[a][b] = DM[b][a] = L.dm[e];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double det = direct_reduce(DM, TM, &Ts, M);
+            if (dabs(det) > 1.0e-10) break;
+            eps = (float)(s / (n * 2) * 1e-2);
+        }
+        FSTAMP(2);
+        if (iter < 2) {
+            direct_finish(M, TM, Ts, scale, cx, cy, box, lane);
+            FSTAMP(3);
+            if (is_good_box(box)) return 0;
+        }
+        FSTAMP(3);
+    }
+    // ------------------------------------------------ general conic fit (fallback)
+    {
+        float cx, cy;
+        if (sumx < (1ll << 24) && sumy < (1ll << 24)) { // float accumulation is exact below 2^24
+            cx = (float)sumx;
+            cy = (float)sumy;
+        } else {
+            cx = 0;
+            cy = 0;
+            for (int i = 0; i < n; i++) { cx += (float)pts[i].x; cy += (float)pts[i].y; }
+        }
+        cx /= (float)n;
+        cy /= (float)n;
+        const double s = seq_sum_terms(n, lane, L, [&](int i) {
+            const float px = (float)pts[i].x - cx, py = (float)pts[i].y - cy;
+            return dabs((double)px) + dabs((double)py);
+        });
+        const double scale = 100.0 / (s > FLT_EPSILON ? s : (double)FLT_EPSILON);
+        double gfp[5], rp[5] = {0, 0, 0, 0, 0};
+        float eps = 0.0f;
+        int la = 0, lb = 0;
+        if (lane < 15) tri_index(lane, 5, &la, &lb);
+        else { la = lane < 20 ? lane - 15 : 0; lb = -1; }
+        for (int iter = 0; iter < 2; iter++) {
+            const double acc = seq_sum_products<5>(n, lane, L, 20, la, lb, 10000.0, [&](int i, double* r) {
+                float ox = 0, oy = 0;
+                if (iter) get_ofs(i, eps, &ox, &oy);
+                const float fx = ((float)pts[i].x + ox) - cx, fy = ((float)pts[i].y + oy) - cy;
+                const double px = fx * scale, py = fy * scale;
+                r[0] = -px * px; r[1] = -py * py; r[2] = -px * py; r[3] = px; r[4] = py;
+            });
+            if (lane < 20) L.dm[lane] = acc;
+            __builtin_amdgcn_wave_barrier();
+            double wmax, wmin;
+            LaneVec G(lane), g(lane);
+            { // lane a*5+b takes G(a,b) = G(b,a) from the upper-triangle sums; lane a takes g(a)
+                const int a = lane / 5, b = lane - 5 * a;
+                const int lo = a < b ? a : b, hi = a < b ? b : a;
+                const int e = lo * 5 - lo * (lo - 1) / 2 + (hi - lo);
+                G.reg = lane < 25 ? L.dm[e] : 0.0;
+                g.reg = lane < 5 ? L.dm[15 + lane] : 0.0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            normal_solve(G, g, 5, gfp, &wmax, &wmin, lane);
+            if (iter == 0 && wmax * FLT_EPSILON > wmin) {
+                eps = (float)(s / (n * 2) * 1e-3);
+                continue;
+            }
+            break;
+        }
+        FSTAMP(4);
+        general_centre(gfp, rp);
+        if (lane < 6) tri_index(lane, 3, &la, &lb);
+        else { la = lane < 9 ? lane - 6 : 0; lb = -1; }
+        const double r0 = rp[0], r1 = rp[1];
+        const double acc = seq_sum_products<3>(n, lane, L, 9, la, lb, 1.0, [&](int i, double* r) {
+            float ox = 0, oy = 0;
+            if (eps != 0.0f) get_ofs(i, eps, &ox, &oy);
+            const float fx = ((float)pts[i].x + ox) - cx, fy = ((float)pts[i].y + oy) - cy;
+            const double px = fx * scale, py = fy * scale;
+            r[0] = (px - r0) * (px - r0); r[1] = (py - r1) * (py - r1); r[2] = (px - r0) * (py - r1);
+        });
+        if (lane < 9) L.dm[lane] = acc;
+        __builtin_amdgcn_wave_barrier();
+        LaneVec G(lane), g(lane);
+        {
+            const int a = lane / 3, b = lane - 3 * a;
+            const int lo = a < b ? a : b, hi = a < b ? b : a;
+            const int e = lo * 3 - lo * (lo - 1) / 2 + (hi - lo);
+            G.reg = lane < 9 ? L.dm[e] : 0.0;
+            g.reg = lane < 3 ? L.dm[6 + lane] : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        FSTAMP(5);
+        normal_solve(G, g, 3, gfp, 0, 0, lane);
+        general_finish(gfp, rp, scale, cx, cy, box);
+        FSTAMP(6);
+    }
+    return 1;
+}
+
+// the per-contour part of rm::filter_lightblobs (objdetect.cpp:62-80) for the contour with discovery index k of frame f, by one
+// wavefront: size/area gate, ellipse fit, ratio/tilt tests -> slot kind (0 skipped, 1 positive, 2 negative) + fitted ellipse
+struct FitGates {
+    float tilt_max, ratio_lo, ratio_hi;
+    double area_lo, area_hi;
+};
+__device__ inline void fit_contour_slot(int f, int k, int n, const rmcv_point* __restrict__ pts, const int32_t* __restrict__ cs,
+                                        const int32_t* __restrict__ cl, int max_contours, int max_points, const FitGates& G,
+                                        int32_t* __restrict__ slot_kind, rmcv_rrect* __restrict__ slot_ell, WaveLds& L, int lane)
+{
+    const int c = n - 1 - k; // findContours order
+    const int start = cs[k], len = cl[k];
+    int kind = 0;
+    rmcv_rrect ell = {0, 0, 0, 0, 0};
+    if (len >= 6 && start + len <= max_points) { // objdetect.cpp:64
+        const rmcv_point* cp = pts + start;
+        // cv::contourArea + coordinate sums: integer-exact, any reduction order
+        double a00 = 0;
+        long long sx = 0, sy = 0;
+        for (int i = lane; i < len; i += 64) {
+            const rmcv_point p = cp[i], q = cp[i == 0 ? len - 1 : i - 1];
+            a00 += (double)(float)q.x * (float)p.y - (double)(float)q.y * (float)p.x;
+            sx += p.x;
+            sy += p.y;
+        }
+        a00 = wave_sum_f64(a00);
+        sx = wave_sum_i64(sx);
+        sy = wave_sum_i64(sy);
+        const double area = dabs(a00 * 0.5);
+        if (area >= G.area_lo && area <= G.area_hi) {
+#ifdef RMCV_PROFILE
+            long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int path = fit_ellipse_wave(cp, len, sx, sy, L, lane, &ell, pr);
+            if (lane == 0 && f == 0 && len > 150)
+                printf("[fit f%d c%d n=%d path=%d] s %.1f moments+reduce %.1f finish %.1f | gen s+G+solve %.1f refit %.1f solve3+finish %.1f us\n", f, c,
+                       len, path, (pr[1] - pr[0]) / 100.0, (pr[2] - pr[1]) / 100.0, (pr[3] - pr[2]) / 100.0,
+                       (pr[4] - pr[3]) / 100.0, (pr[5] - pr[4]) / 100.0, (pr[6] - pr[5]) / 100.0);
+#else
+            fit_ellipse_wave(cp, len, sx, sy, L, lane, &ell); // :68  (:69 minAreaRect is dead code in the reference)
+#endif
+            bool negative = false;
+            const float mx = ell.w > ell.h ? ell.w : ell.h, mn = ell.w < ell.h ? ell.w : ell.h;
+            const float ratio = mx / mn; // :71-73
+            if (!(ratio >= G.ratio_lo && ratio <= G.ratio_hi)) negative = true;
+            const float angle = ell.angle > 90 ? ell.angle - 90 : ell.angle + 90; // :78
+            if (__builtin_fabsf(angle - 90) > G.tilt_max) negative = true;        // :79
+            kind = negative ? 2 : 1;
+        }
+    }
+    if (lane == 0) {
+        slot_kind[(int64_t)f * max_contours + c] = kind;
+        slot_ell[(int64_t)f * max_contours + c] = ell;
+    }
+}
+
+struct FitTail { // what k_pairs needs to finish filter_lightblobs and run filter_armours
+    rmcv_lightblob* blobs;
+    int32_t* blob_src;
+    rmcv_rrect* ellipses;
+    int32_t* neg_idx;
+    int32_t* n_blobs;
+    int32_t* n_neg;
+    int32_t* status;
+    rmcv_armour* armours;
+    int32_t* n_armours;
+    int max_blobs, max_armours, enemy, do_pairs;
+    float angle_diff_max, shear_max, length_ratio_max;
+};
+
+// ordered compaction of the per-contour results of frame f into the reference's `positive` / `negative` lists
+// (one wavefront); returns the number of positives
+__device__ inline int blob_compact_frame(int f, int lane, const int32_t* slot_kind, const rmcv_rrect* slot_ell, int n, int max_contours,
+                                  int enemy, rmcv_lightblob* blobs, int32_t* blob_src, rmcv_rrect* ellipses, int32_t* neg_idx,
+                                  int32_t* n_blobs, int32_t* n_neg, int32_t* status, int max_blobs)
+{
+    rmcv_lightblob* ob = blobs + (int64_t)f * max_blobs;
+    int32_t* osrc = blob_src + (int64_t)f * max_blobs;
+    rmcv_rrect* oell = ellipses + (int64_t)f * max_blobs;
+    int32_t* oneg = neg_idx + (int64_t)f * max_contours;
+    int np = 0, nn = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int c = base + lane;
+        const int word = c < n ? slot_kind[(int64_t)f * max_contours + c] : 0;
+        const int kind = word & 15, camp_code = word >> 4; // the legacy matcher votes a camp per contour (code = camp + 2)
+        const uint64_t mp = __ballot(kind == 1), mn_ = __ballot(kind == 2);
+        if (kind == 1) {
+            const int o = np + lanes_below(mp, lane);
+            if (o < max_blobs) {
+                const rmcv_rrect ell = slot_ell[(int64_t)f * max_contours + c];
+                make_lightblob(&ell, camp_code ? camp_code - 2 : enemy, &ob[o]); // :83 -> core.cpp:9-19
+                osrc[o] = c;
+                oell[o] = ell;
+            }
+        } else if (kind == 2) {
+            oneg[nn + lanes_below(mn_, lane)] = c; // :82
+        }
+        np += __popcll(mp);
+        nn += __popcll(mn_);
+    }
+    if (np > max_blobs) {
+        if (lane == 0) atomicOr(&status[f], RMCV_FRAME_OVF_BLOBS);
+        np = max_blobs;
+    }
+    if (lane == 0) {
+        n_blobs[f] = np;
+        n_neg[f] = nn;
+    }
+    return np;
+}
+
+__device__ __forceinline__ bool pair_ok(const rmcv_lightblob& a, const rmcv_lightblob& b, float angle_diff_max,
+                                        float shear_max, float length_ratio_max)
+{
+    const float angle_difference = __builtin_fabsf(a.angle - b.angle); // objdetect.cpp:131
+    if (angle_difference > angle_diff_max) return false;
+    const float y = __builtin_fabsf(a.center[1] - b.center[1]);
+    const float x = __builtin_fabsf(a.center[0] - b.center[0]);
+    const float rect_angle = pm_atan2f(y, x) * 180.0f / (float)RMCV_PI; // :137
+    const float shear_i = __builtin_fabsf(a.angle > 90 ? __builtin_fabsf(a.angle - rect_angle) - 90
+                                                       : __builtin_fabsf(180 - a.angle - rect_angle) - 90);
+    const float shear_j = __builtin_fabsf(b.angle > 90 ? __builtin_fabsf(b.angle - rect_angle) - 90
+                                                       : __builtin_fabsf(180 - b.angle - rect_angle) - 90);
+    if (shear_i > shear_max || shear_j > shear_max) return false; // :144
+    const float hi = a.size[1], hj = b.size[1];
+    const float mn = hi < hj ? hi : hj, mx = hi < hj ? hj : hi;
+    if (mn / mx < length_ratio_max) return false;                                                     // :149
+    if (__builtin_fabsf(a.center[1] - b.center[1]) > (a.size[1] + b.size[1]) / 2) return false;       // :153
+    if (__builtin_fabsf(a.center[0] - b.center[0]) > (a.size[1] + b.size[1]) * 2) return false;       // :157
+    return true;
+}
+
+// rm::filter_armours for frame f (one wavefront, n = number of light blobs)
+__device__ inline void armours_frame(int f, int lane, const rmcv_lightblob* blobs, int n, int max_blobs, float angle_diff_max,
+                              float shear_max, float length_ratio_max, int enemy, rmcv_armour* armours, int32_t* n_armours,
+                              int32_t* status, int max_armours)
+{
+    const rmcv_lightblob* lb = blobs + (int64_t)f * max_blobs;
+    rmcv_armour* out = armours + (int64_t)f * max_armours;
+    int na = 0;
+    if (n >= 2) { // :120
+        for (int i = 0; i < n - 1; i++) {
+            const rmcv_lightblob a = lb[i];
+            if (a.target != enemy) continue; // :124
+            for (int jb = i + 1; jb < n; jb += 64) {
+                const int j = jb + lane;
+                bool ok = false;
+                rmcv_lightblob b;
+                if (j < n) {
+                    b = lb[j];
+                    ok = (b.target == enemy) && pair_ok(a, b, angle_diff_max, shear_max, length_ratio_max);
+                }
+                const uint64_t m = __ballot(ok);
+                if (ok) {
+                    const int o = na + lanes_below(m, lane);
+                    if (o < max_armours) {
+                        make_armour(&a, &b, &out[o]); // :161 -> core.cpp:21-49
+                        out[o].blob_i = i;
+                        out[o].blob_j = j;
+                    }
+                }
+                na += __popcll(m);
+            }
+        }
+    }
+    if (lane == 0) {
+        if (na > max_armours) {
+            atomicOr(&status[f], RMCV_FRAME_OVF_ARMOURS);
+            na = max_armours;
+        }
+        n_armours[f] = na;
+    }
+}
+
+// what the fused per-frame kernel (k_contours.hip) needs beyond findContours' own arguments
+struct SparseTail {
+    int fused; // 0: findContours only
+    FitGates G;
+    rmcv_rrect* slot_ell;
+    FitTail T;
+};
+
+} // namespace rmcv

@@ -9,3 +9,4 @@ for r in csv.DictReader(open(f)):
     if "rmcv" in r["Name"]: print(r["Name"][:34].ljust(34), r["Calls"], round(float(r["AverageNs"])/1000,1), "us  min", round(float(r["MinNs"])/1000,1), "max", round(float(r["MaxNs"])/1000,1))
 PY
 tail -1 $out/b.json | cut -c1-200
+python3 tools/ovl_timeline.py $out/d
