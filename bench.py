@@ -59,7 +59,7 @@ def main():
     import torch.distributed as dist
 
     from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_ARMOURS, STAGE_BINARY, STAGE_BLOBS,
-                          STAGE_IDENTITY, STAGE_POSE, Context, LegacyParams, default_params, synth)
+                          STAGE_IDENTITY, STAGE_POSE, OPT_SPARSE_WAVES, Context, LegacyParams, default_params, synth)
     from rmcv_amd import dist as rdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,6 +95,8 @@ def main():
         stages = int(os.environ["RMCV_BENCH_STAGES"])
     svm = synth.svm_weights() if args.workload == "c5" else None   # svm.xml is not in the reference: seeded stand-in weights
     for k, c in enumerate(ctxs):
+        # several batches in flight: 4 wavefronts per frame in the sparse kernel (throughput); a lone batch: 8 (latency)
+        c.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
         c.bind_device_frames(frames_k[k].data_ptr(), n, H, W, keepalive=frames_k[k])
         if svm:
             c.svm_load(*svm)
@@ -155,6 +157,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("RMCV_BENCH_STAGES"):                      # dev knob: later stages need the planes of a full pass
+        for k in range(ns):
+            ctxs[k].run(params, STAGE_ALL, streams[k].cuda_stream)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         recs = step()
     barrier()
@@ -245,7 +251,7 @@ def main():
                                                 (" + solve_PnP (IPPE square) and world position per armour" if args.pose else ""),
                                                 " + RCCL gather of armour lists (C4)" if world > 1 else ""),
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
-                   "double_buffered_steps": ns, "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
+                   "double_buffered_steps": ns, "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
                    "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad},
         "path_hbm_frac": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
         "stage_ms": {"binary": round(float(stage[0]), 4), "contours": round(float(stage[1]), 4),

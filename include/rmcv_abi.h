@@ -119,6 +119,11 @@ void rmcv_default_limits(rmcv_limits* l);
 int  rmcv_ctx_create(int device, const rmcv_limits* limits /* nullable */, rmcv_ctx** out);
 void rmcv_ctx_destroy(rmcv_ctx* ctx);
 const char* rmcv_last_error(const rmcv_ctx* ctx);
+/* tuning knobs of a context.  RMCV_OPT_SPARSE_WAVES: wavefronts per frame of the fused sparse kernel (findContours + fits +
+ * pairing) in batch runs -- 8 (default): lowest latency of a lone batch; 4: highest throughput when several batches are in flight
+ * on different streams (leaves register-file room on every CU for the pixel kernels of the next batches).  Results are identical. */
+#define RMCV_OPT_SPARSE_WAVES 1
+int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 
 /* ---- single frame, host buffers: one call per reference function ---------------------- */
 

@@ -22,13 +22,14 @@ assert POINT.itemsize == 8 and LIGHTBLOB.itemsize == 56 and ARMOUR.itemsize == 8
 OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 CAMP_RED, CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL = 0, 1, 2, -1
 MORPH_NONE, MORPH_DILATE, MORPH_CLOSE = 0, 1, 2
+OPT_SPARSE_WAVES = 1
 STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE = 1, 2, 4, 8, 15, 16, 32
 SVM_FEATURES = 1200
 FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_SLOW_PATH = 1, 2, 4, 8, 16
 
 EXPORTS = [
     "rmcv_abi_version", "rmcv_default_params", "rmcv_default_limits", "rmcv_ctx_create", "rmcv_ctx_destroy",
-    "rmcv_last_error", "rmcv_extract_color", "rmcv_filter_lightblobs", "rmcv_filter_armours", "rmcv_fit_ellipse",
+    "rmcv_last_error", "rmcv_ctx_set_option", "rmcv_extract_color", "rmcv_filter_lightblobs", "rmcv_filter_armours", "rmcv_fit_ellipse",
     "rmcv_batch_upload", "rmcv_batch_set_device_frames", "rmcv_batch_run", "rmcv_batch_sync", "rmcv_batch_run_timed",
     "rmcv_batch_counts", "rmcv_batch_get_binary", "rmcv_batch_get_contours", "rmcv_batch_get_blobs",
     "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_batch_compact_armours", "rmcv_synth_frame", "rmcv_synth_checksum",

@@ -105,6 +105,10 @@ class Context:
         self._chk(lib().rmcv_fit_ellipse(self._h, ptr(pts), len(pts), ptr(out)))
         return out[0]
 
+    def set_option(self, option, value):
+        """tuning knobs (abi.OPT_SPARSE_WAVES: 8 = latency of a lone batch, 4 = throughput with several batches in flight)"""
+        self._chk(lib().rmcv_ctx_set_option(self._h, int(option), int(value)))
+
     # ---------------------------------------------------------------- armour pose (src/mobility.cpp:166-190, main.cpp:183-192)
     def pnp_load(self, cfg=None):
         """camera matrix, distortion, gripper->camera transform, square size (defaults: the reference's main.cpp literals)"""

@@ -1,0 +1,28 @@
+// k_contours_w4.hip -- the per-frame sparse kernel (k_contours_kernel.inc) with 4 wavefronts per frame: the throughput setting
+// (RMCV_OPT_SPARSE_WAVES = 4).  Its own translation unit, see k_contours.hip.
+#include "contours_device.h"
+
+namespace rmcv {
+
+#define KC_KERNEL k_contours_w4
+#define KC_THREADS 256
+#include "k_contours_kernel.inc"
+#undef KC_KERNEL
+#undef KC_THREADS
+
+hipError_t launch_contours_w4(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int force_literal, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_w4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(ContoursLds));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_contours_w4, dim3(g.n_frames), dim3(256), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
+                       g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
+                       lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind, X);
+    return hipGetLastError();
+}
+
+} // namespace rmcv

@@ -29,6 +29,7 @@ struct rmcv_ctx {
     hipStream_t last_stream = nullptr;
     int geom_w = -1, geom_h = -1; // geometry the planes were zeroed for
     uint32_t k1_base = 0;         // see Bufs::strip_base
+    int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
     char err[256] = {0};
     std::vector<void*> allocs;
 };
@@ -223,7 +224,7 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     // the per-stage events of rmcv_batch_run_timed need per-stage launches (RMCV_FUSE_SPARSE=0: dev knob for A/B runs)
     static const bool fuse_ok = !(getenv("RMCV_FUSE_SPARSE") && atoi(getenv("RMCV_FUSE_SPARSE")) == 0);
     const bool one_sparse = fuse_ok && !timed && !lp && (stages & RMCV_STAGE_CONTOURS) && (stages & RMCV_STAGE_BLOBS);
-    if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, s), "k_contours (fused)");
+    if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, c->sparse_waves, s), "k_contours (fused)");
     else if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     const bool fused = (stages & RMCV_STAGE_BLOBS) && (stages & RMCV_STAGE_ARMOURS); // one launch for both
@@ -318,6 +319,16 @@ int rmcv_batch_run_legacy(rmcv_ctx* c, const rmcv_params* p, const rmcv_legacy_p
     if (!lp) return fail(c, RMCV_ERR_BAD_ARG, "null legacy params");
     hipSetDevice(c->device);
     return run_stages(c, p, stages, hip_stream ? (hipStream_t)hip_stream : c->stream, false, lp);
+}
+
+int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
+{
+    if (!c) return RMCV_ERR_BAD_ARG;
+    if (option == RMCV_OPT_SPARSE_WAVES && (value == 4 || value == 8)) {
+        c->sparse_waves = value;
+        return RMCV_OK;
+    }
+    return fail(c, RMCV_ERR_BAD_ARG, "unknown option or value");
 }
 
 int rmcv_batch_sync(rmcv_ctx* c)

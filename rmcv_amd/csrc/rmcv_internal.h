@@ -72,7 +72,7 @@ struct Bufs {
 // kernel launchers (each enqueues on `s` and returns the launch error)
 hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, const rmcv_legacy_params& lp,
                         int mode, bool with_frames, bool pairs, hipStream_t s);
-hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s);
+hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, int waves, hipStream_t s);
 hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, hipStream_t s);
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);

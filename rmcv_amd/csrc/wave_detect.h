@@ -406,4 +406,6 @@ struct SparseTail {
     FitTail T;
 };
 
+hipError_t launch_contours_w4(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int force_literal, hipStream_t s);
+
 } // namespace rmcv

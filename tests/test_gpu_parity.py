@@ -312,3 +312,41 @@ def test_borrowed_device_frames_with_row_and_frame_padding(oracle):
             assert np.array_equal(c.binary(f), ref["binary"]), (h, w, f)
             assert arm[offs[f]:offs[f + 1]].tobytes() == ref["armours"].tobytes(), (h, w, f)
         c.close()
+
+
+def test_sparse_kernel_with_four_wavefronts(oracle):
+    """RMCV_OPT_SPARSE_WAVES = 4 (the throughput setting bench.py uses with several batches in flight): same results"""
+    from rmcv_amd import OPT_SPARSE_WAVES, Context, RmcvError
+    n = 6
+    c = Context(device=0, max_frames=n, max_width=1280, max_height=1024)
+    with pytest.raises(RmcvError):
+        c.set_option(OPT_SPARSE_WAVES, 3)
+    with pytest.raises(RmcvError):
+        c.set_option(99, 1)
+    c.set_option(OPT_SPARSE_WAVES, 4)
+    for variant in (0, 1):
+        frames = synth.batch(4000 + variant, n, 1280, 1024, CAMP_BLUE, variant)
+        c.upload(frames)
+        c.run(default_params(), STAGE_ALL)
+        c.sync()
+        arm, aoffs = c.armours()
+        for f in range(n):
+            ref = oracle.detect_frame(frames[f], oracle.default_params())
+            pts, offs = c.contours(f)
+            assert np.array_equal(offs, ref["offs"]) and np.array_equal(pts, ref["pts"]), f
+            blobs, _ = c.blobs(f)
+            assert blobs.tobytes() == ref["blobs"].tobytes(), f
+            assert arm[aoffs[f]:aoffs[f + 1]].tobytes() == ref["armours"].tobytes(), f
+    # nested shapes: the literal fallback inside the 4-wavefront workgroup
+    img = np.zeros((1, 256, 256, 3), np.uint8)
+    img[0, 40:200, 40:200] = (255, 0, 0)
+    img[0, 80:160, 80:160] = 0
+    img[0, 100:140, 100:140] = (255, 0, 0)
+    c.upload(img)
+    c.run(default_params(), STAGE_ALL)
+    c.sync()
+    ref = oracle.detect_frame(img[0], oracle.default_params())
+    pts, offs = c.contours(0)
+    assert np.array_equal(offs, ref["offs"]) and np.array_equal(pts, ref["pts"])
+    assert c.counts()["status"][0] & 16
+    c.close()

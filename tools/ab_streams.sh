@@ -4,8 +4,8 @@ import json
 j=json.loads(open('gpurun_out/abs.log').read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step'], j['config']['armours_gathered'])"; }
 for rep in 1 2; do
 E=A=1 run --streams 3
-E=RMCV_FUSE_SPARSE=0 run --streams 3
-E=A=1 run --streams 1
-E=RMCV_FUSE_SPARSE=0 run --streams 1
-E=A=1 run --streams 2
+E=RMCV_BENCH_STAGES=1 run --streams 3
+E=RMCV_BENCH_STAGES=14 run --streams 3
+E=RMCV_BENCH_STAGES=14 run --streams 2
+E=RMCV_BENCH_STAGES=14 run --streams 1
 done
