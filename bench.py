@@ -26,6 +26,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A step's kernels must not share a
+# queue with another batch's or with RCCL's stream: the null stream + three batch streams + RCCL's own need five, and with four
+# the gather of every step cost 15 % (736 k against 843 k frames/s, tools/ab_dist.sh).  Read by the HIP runtime at start-up.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+
 FRAMES = 256
 WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200),   # BASELINE.json configs[2] (the metric's config) and configs[4]
              "legacy": (1280, 1024)}                     # FindLightBlobs (minAreaRect boxes, camp vote) in place of filter_lightblobs
@@ -251,7 +256,7 @@ def main():
                                                 (" + solve_PnP (IPPE square) and world position per armour" if args.pose else ""),
                                                 " + RCCL gather of armour lists (C4)" if world > 1 else ""),
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
-                   "double_buffered_steps": ns, "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
+                   "double_buffered_steps": ns, "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
                    "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad},
         "path_hbm_frac": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
         "stage_ms": {"binary": round(float(stage[0]), 4), "contours": round(float(stage[1]), 4),
