@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=FRAMES, help="frames per GPU per step")
     ap.add_argument("--variant", type=int, default=0, help="0 plain stream, 1 stress stream")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline sample (0 = skip)")
@@ -197,6 +197,20 @@ def main():
     for _ in range(reps):
         stage += np.asarray(ctx.run_timed(params, stages, sh))
     stage /= reps
+    # one batch at a time, HIP events around the whole batch, median and min over >= 20 passes
+    lone = []
+    ctx.set_option(OPT_SPARSE_WAVES, 8)                            # the latency setting: a lone batch has the CUs to itself
+    for _ in range(max(20, reps)):
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(stream):
+            ea.record(stream)
+            run_path(ctx, stages, sh)
+            ctx.compact_armours_into(rec.data_ptr() + head, cap, rec.data_ptr(), sh)
+            eb.record(stream)
+        torch.cuda.synchronize()
+        lone.append(ea.elapsed_time(eb))
+    lone.sort()
+    ctx.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
     fused_ms = None
     if legacy is None:          # what the steps actually launch: findContours + filter_lightblobs + filter_armours as one kernel
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -258,6 +272,8 @@ def main():
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
                    "double_buffered_steps": ns, "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
                    "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad},
+        "lone_batch_ms": {"median": round(lone[len(lone) // 2], 4), "min": round(lone[0], 4), "passes": len(lone),
+                          "note": "one batch at a time on one stream, events around detect + compaction (latency, not the metric)"},
         "path_hbm_frac": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
         "stage_ms": {"binary": round(float(stage[0]), 4), "contours": round(float(stage[1]), 4),
                      "blobs": round(float(stage[2]), 4), "armours": round(float(stage[3]), 4),
