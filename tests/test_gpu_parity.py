@@ -350,3 +350,33 @@ def test_sparse_kernel_with_four_wavefronts(oracle):
     assert np.array_equal(offs, ref["offs"]) and np.array_equal(pts, ref["pts"])
     assert c.counts()["status"][0] & 16
     c.close()
+
+
+@pytest.mark.parametrize("variant,waves", [(0, 4), (1, 8)])
+def test_full_size_every_stage_of_every_frame(oracle, variant, waves):
+    """BASELINE.json's full batch (256 x 1280x1024), both synthetic streams, both sparse-kernel settings: binary image, contours,
+    light blobs and armours of EVERY frame against the oracle (run on 16 host threads)"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from rmcv_amd import OPT_SPARSE_WAVES, Context
+    n = 256
+    c = Context(device=0, max_frames=n, max_width=1280, max_height=1024)
+    c.set_option(OPT_SPARSE_WAVES, waves)
+    frames = synth.batch(50000 + 1000 * variant, n, 1280, 1024, CAMP_BLUE, variant, threads=16)
+    arm, offs = c.detect_batch(frames)
+    assert not (c.counts()["status"] & 15).any()
+    p = oracle.default_params()
+    with ThreadPoolExecutor(16) as ex:
+        refs = list(ex.map(lambda f: oracle.detect_frame(frames[f], p), range(n)))
+    n_blobs = 0
+    for f in range(n):
+        ref = refs[f]
+        assert np.array_equal(c.binary(f), ref["binary"]), f
+        pts, co = c.contours(f)
+        assert np.array_equal(co, ref["offs"]) and np.array_equal(pts, ref["pts"]), f
+        blobs, _ = c.blobs(f)
+        assert blobs.tobytes() == ref["blobs"].tobytes(), f
+        assert arm[offs[f]:offs[f + 1]].tobytes() == ref["armours"].tobytes(), f
+        n_blobs += len(blobs)
+    assert n_blobs > 2 * n and offs[-1] > n // 2
+    c.close()
