@@ -119,7 +119,7 @@ def main():
     cap = n * 16
     head, _ = rdist.record_layout(n, cap)
     recs_buf = [rdist.new_record(n, cap, dev) for _ in range(ns)]
-    # alternate stream priorities: HIP maps streams of different priority to different hardware queues, which is
+    # one stream per batch in flight (priorities alternate; with GPU_MAX_HW_QUEUES = 6 every stream has its own hardware queue, which is
     # what lets kernels of two steps actually run concurrently
     prios = [int(x) for x in os.environ.get("RMCV_BENCH_PRIOS", "").split(",") if x] or [0, -1]
     streams = [torch.cuda.Stream(device=dev, priority=prios[k % len(prios)]) for k in range(ns)]
