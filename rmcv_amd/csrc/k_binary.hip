@@ -101,11 +101,10 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
-                                                 int* __restrict__ strip_ctr, uint32_t strip_base)
+                                                 int* __restrict__ strip_ctr, uint32_t strip_base, int taper_head, int taper_tail)
 {
     extern __shared__ uint64_t smem[];
     const int halo = morph; // NONE 0, DILATE 1, CLOSE 2
-    const int srh = SR + 2 * halo;
     uint64_t* T = smem;
     uint64_t* D = smem + (size_t)(SR + 4) * ww;
 
@@ -125,16 +124,26 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
     __syncthreads(); // also: the LDS planes of the previous strip are free
     // The queue heads run free (no reset between launches): every workgroup of a launch draws until its first index
-    // >= per_xcd, so one launch advances each head by exactly per_xcd + gridDim.x/8 and the host knows the value the
+    // >= n_queue, so one launch advances each head by exactly n_queue + gridDim.x/8 and the host knows the value the
     // next launch starts from (strip_base, modulo 2^32).
+    // Tapered queue: the first taper_head and the last taper_tail strips of an XCD's range are handed out as four 8-row
+    // pieces each, so the kernel's ramp (nothing is stored before a first strip is complete) and its tail (workgroups
+    // finish up to one strip apart) are a quarter as long.
+    const int n_mid = per_xcd - taper_head - taper_tail;
+    const int n_queue = 4 * taper_head + n_mid + 4 * taper_tail;
     if (tid == 0) s_next = (int)((uint32_t)atomicAdd(&strip_ctr[xcd], 1) - strip_base);
     __syncthreads();
     const int j = s_next;
-    if ((uint32_t)j >= (uint32_t)per_xcd) break;
-    const int L = xcd * per_xcd + j;
+    if ((uint32_t)j >= (uint32_t)n_queue) break;
+    int s_local, piece = 0, sr = SR;
+    if (j < 4 * taper_head) { s_local = j >> 2; piece = j & 3; sr = SR / 4; }
+    else if (j < 4 * taper_head + n_mid) { s_local = taper_head + (j - 4 * taper_head); }
+    else { const int jj = j - 4 * taper_head - n_mid; s_local = taper_head + n_mid + (jj >> 2); piece = jj & 3; sr = SR / 4; }
+    const int L = xcd * per_xcd + s_local;
     if (L >= n_blocks) continue; // tail of the last XCD's range: draw on, so that every head advances alike
     const int f = L / strips, strip = L - f * strips;
-    const int y0 = strip * SR;
+    const int y0 = strip * SR + piece * (SR / 4);
+    const int srh = sr + 2 * halo;
     const uint8_t* frame = frames + (int64_t)f * frame_pitch;
 
     // ---------------- phase 1: load + threshold -> T
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
         R = D;
         if (morph == RMCV_MORPH_CLOSE) {
             // ---------------- phase 3: erode -> T (rows 2 .. srh-3 = the strip)
-            const int items3 = SR * ww;
+            const int items3 = sr * ww;
             for (int it = tid; it < items3; it += 256) {
                 const int r_ = div_r(it, r_ww);
                 const int rr = 2 + r_, k = it - r_ * ww;
@@ -299,14 +308,14 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     }
 
     // ---------------- row masks for the contour stage: bit k = word k of the row is non-zero
-    if (ww <= 32 && tid < SR && y0 + tid < h) {
+    if (ww <= 32 && tid < sr && y0 + tid < h) {
         uint32_t m = 0;
         for (int k = 0; k < ww; k++) m |= (uint32_t)(R[(tid + halo) * ww + k] != 0) << k;
         rowmask[(int64_t)f * h + y0 + tid] = m;
     }
     // ---------------- phase 4: expand to bytes + bit plane
     {
-        const int items = SR * wq;
+        const int items = sr * wq;
         int s = tid / wq, q = tid - s * wq;
         const int dr = 256 / wq, dq = 256 - dr * wq;
         uint8_t* bin = binary + (int64_t)f * w * h;
@@ -371,15 +380,21 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     if (grid > ((n_blocks + 7) & ~7)) grid = (n_blocks + 7) & ~7;
     grid = (grid + 7) & ~7;
     const uint32_t base = *b.strip_base; // launches of one context are stream-ordered
+    // tapered queue (see the kernel): 16 strips at the head (one 8-row piece per workgroup of an XCD at 2 per CU) and 32 at the tail
+    static const int taper_on = getenv("RMCV_K1_TAPER") ? atoi(getenv("RMCV_K1_TAPER")) : 1; // dev knob for A/B runs
+    const int per_xcd = (n_blocks + 7) >> 3;
+    int taper_head = 0, taper_tail = 0;
+    if (taper_on && per_xcd >= 192) { taper_head = 16; taper_tail = 32; }
+    const int n_queue = 4 * taper_head + (per_xcd - taper_head - taper_tail) + 4 * taper_tail;
 #define RMCV_K1_LAUNCH(F, V, LDS)                                                                                       \
     hipLaunchKernelGGL((k_binary<CA, CB, F, V>), dim3(grid), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, \
-                       g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr, base)
+                       g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr, base, taper_head, taper_tail)
     if (coalesced) RMCV_K1_LAUNCH(true, 1, planes + 4 * 3072);
     else if (fast) RMCV_K1_LAUNCH(true, 0, planes);
     else RMCV_K1_LAUNCH(false, 0, planes);
 #undef RMCV_K1_LAUNCH
     const hipError_t e = hipGetLastError();
-    if (e == hipSuccess) *b.strip_base = base + (uint32_t)((n_blocks + 7) >> 3) + (uint32_t)(grid >> 3);
+    if (e == hipSuccess) *b.strip_base = base + (uint32_t)n_queue + (uint32_t)(grid >> 3);
     return e;
 }
 
