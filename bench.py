@@ -64,7 +64,7 @@ def main():
     import torch.distributed as dist
 
     from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_ARMOURS, STAGE_BINARY, STAGE_BLOBS,
-                          STAGE_IDENTITY, STAGE_POSE, OPT_SPARSE_WAVES, Context, LegacyParams, default_params, synth)
+                          STAGE_IDENTITY, STAGE_NO_IMAGE, STAGE_POSE, OPT_SPARSE_WAVES, Context, LegacyParams, default_params, synth)
     from rmcv_amd import dist as rdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,13 +134,15 @@ def main():
     pipelined = args.mode == "pipeline" and ns > 1
     sparse_stages = stages & ~STAGE_BINARY
 
+    cur_stages = [stages]
+
     def step():
         k = step_no[0] % ns
         first_use = step_no[0] < ns
         step_no[0] += 1
         if not pipelined:
             with torch.cuda.stream(streams[k]):
-                run_path(ctxs[k], stages, streams[k].cuda_stream)
+                run_path(ctxs[k], cur_stages[0], streams[k].cuda_stream)
                 ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
                 return rdist.gather_records(recs_buf[k]) if use_dist else [recs_buf[k]]
         with torch.cuda.stream(sA):
@@ -302,6 +304,22 @@ def main():
             d2 = time.perf_counter() - t0
             ex[name + "_fps"] = round(n * args.steps / d2, 1)
         out["c2_binary_only"] = ex
+        # detection only: the byte image `binary` is not written (RMCV_STAGE_NO_IMAGE; only the reference's debug view reads it,
+        # executable/main.cpp:200-201).  NOT the metric: 3 B/px of algorithmic traffic instead of 4.
+        if not pipelined and legacy is None:
+            cur_stages[0] = stages | STAGE_NO_IMAGE
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            d3 = (time.perf_counter() - t0) / args.steps
+            cur_stages[0] = stages
+            out["detect_only_no_image"] = {"fps": round(n / d3, 1), "ms_per_step": round(d3 * 1e3, 4), "bytes_per_frame": 3 * W * H,
+                                           "hbm_frac": round(n * 3 * W * H / d3 / 1e9 / HBM_PEAK_GBS, 4),
+                                           "note": "same armour lists; the 0/255 image is not materialised"}
 
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

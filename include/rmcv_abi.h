@@ -99,6 +99,9 @@ typedef struct {            /* capacities of one context; 0 = default */
 #define RMCV_STAGE_ALL 15
 #define RMCV_STAGE_POSE 32     /* solve_PnP + world position per armour, src/mobility.cpp:166-190, executable/main.cpp:183-192;
                                  needs rmcv_pnp_load */
+#define RMCV_STAGE_NO_IMAGE 64 /* modifier of RMCV_STAGE_BINARY: do not write the 0/255 byte image (rmcv_batch_get_binary then returns
+                                 stale data).  The reference returns `binary` from extract_color but only its debug view reads
+                                 it (executable/main.cpp:200-201); a detection-only deployment saves 1 of the 4 bytes per pixel. */
 #define RMCV_STAGE_IDENTITY 16 /* affine_correction + flatten + svm->predict per armour (BASELINE config 5),
                                  src/imgproc.cpp:9-35, src/core.cpp:202-216, executable/main.cpp:180-181; needs rmcv_svm_load */
 

@@ -318,14 +318,15 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
         const int items = sr * wq;
         int s = tid / wq, q = tid - s * wq;
         const int dr = 256 / wq, dq = 256 - dr * wq;
-        uint8_t* bin = binary + (int64_t)f * w * h;
+        uint8_t* bin = binary ? binary + (int64_t)f * w * h : nullptr;
         uint64_t* plane = bits + (int64_t)f * plane_pitch;
         for (int it = tid; it < items; it += 256) {
             const int y = y0 + s;
             if (y < h) {
                 const uint64_t word = R[(s + halo) * ww + (q >> 2)];
                 const uint32_t m = (uint32_t)(word >> (16 * (q & 3))) & 0xFFFFu;
-                if (FAST) {
+                if (!binary) { // RMCV_STAGE_NO_IMAGE: the 0/255 byte image is not wanted, only the bit plane below
+                } else if (FAST) {
                     uint4 o;
                     o.x = expand4(m);
                     o.y = expand4(m >> 4);
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
 }
 
 template <int CA, int CB>
-static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, hipStream_t s)
+static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, hipStream_t s)
 {
     const int strips = (g.h + SR - 1) / SR;
     const int n_blocks = g.n_frames * strips;
@@ -388,7 +389,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     const int n_queue = 4 * taper_head + (per_xcd - taper_head - taper_tail) + 4 * taper_tail;
 #define RMCV_K1_LAUNCH(F, V, LDS)                                                                                       \
     hipLaunchKernelGGL((k_binary<CA, CB, F, V>), dim3(grid), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, \
-                       g.h, g.ww, lb, all_pass, morph, b.binary, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr, base, taper_head, taper_tail)
+                       g.h, g.ww, lb, all_pass, morph, image ? b.binary : nullptr, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr, base, taper_head, taper_tail)
     if (coalesced) RMCV_K1_LAUNCH(true, 1, planes + 4 * 3072);
     else if (fast) RMCV_K1_LAUNCH(true, 0, planes);
     else RMCV_K1_LAUNCH(false, 0, planes);
@@ -398,12 +399,12 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     return e;
 }
 
-hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, hipStream_t s)
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, hipStream_t s)
 {
     // imgproc.cpp:56-65: GUIDELIGHT G-R; BLUE B-R; everything else (RED, NEUTRAL) R-B.  BGR byte order.
-    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, s);
-    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, s);
-    return launch_binary_t<2, 0>(g, b, lower_bound, morph, s);
+    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, s);
+    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, s);
+    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, s);
 }
 
 // binary (0 / non-zero bytes) -> padded bit plane; used when a caller hands in its own binary image

@@ -218,7 +218,7 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     // k_contours writes every frame's status word; without that stage the word is cleared here
     if (!(stages & RMCV_STAGE_CONTOURS)) HIPCHK(c, hipMemsetAsync(b.status, 0, (size_t)g.n_frames * 4, s), "memset status");
-    if (stages & RMCV_STAGE_BINARY) HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, s), "k_binary");
+    if (stages & RMCV_STAGE_BINARY) HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), s), "k_binary");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     // findContours + filter_lightblobs (+ filter_armours) as ONE per-frame kernel when the stages are asked for together;
     // the per-stage events of rmcv_batch_run_timed need per-stage launches (RMCV_FUSE_SPARSE=0: dev knob for A/B runs)
@@ -252,7 +252,7 @@ static int check_params(rmcv_ctx* c, const rmcv_params* p, int stages)
     if (!c) return RMCV_ERR_BAD_ARG;
     if (!p) return fail(c, RMCV_ERR_BAD_ARG, "null params");
     if (p->morph < RMCV_MORPH_NONE || p->morph > RMCV_MORPH_CLOSE) return fail(c, RMCV_ERR_BAD_ARG, "bad morph");
-    if (stages <= 0 || stages > (RMCV_STAGE_ALL | RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE)) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
+    if (stages <= 0 || stages > (RMCV_STAGE_ALL | RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE | RMCV_STAGE_NO_IMAGE)) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
     if (c->geom.n_frames <= 0 || !c->bufs.frames) {
         if (stages & RMCV_STAGE_BINARY) return fail(c, RMCV_ERR_BAD_ARG, "no frames bound");
     }

@@ -380,3 +380,26 @@ def test_full_size_every_stage_of_every_frame(oracle, variant, waves):
         n_blobs += len(blobs)
     assert n_blobs > 2 * n and offs[-1] > n // 2
     c.close()
+
+
+def test_no_image_modifier_changes_nothing_but_the_image(ctx, oracle):
+    """RMCV_STAGE_NO_IMAGE: contours / blobs / armours as with the image; the byte image buffer is left alone"""
+    from rmcv_amd import STAGE_NO_IMAGE
+    n = 4
+    frames = synth.batch(600, n, 1280, 1024, CAMP_BLUE, 1)
+    ctx.upload(np.zeros_like(frames))
+    ctx.run(default_params(), STAGE_ALL)            # leaves an all-zero image in the buffer
+    ctx.sync()
+    ctx.upload(frames)
+    ctx.run(default_params(), STAGE_ALL | STAGE_NO_IMAGE)
+    ctx.sync()
+    arm, offs = ctx.armours()
+    for f in range(n):
+        ref = oracle.detect_frame(frames[f], oracle.default_params())
+        pts, co = ctx.contours(f)
+        assert np.array_equal(co, ref["offs"]) and np.array_equal(pts, ref["pts"]), f
+        assert arm[offs[f]:offs[f + 1]].tobytes() == ref["armours"].tobytes(), f
+        assert not ctx.binary(f).any()              # stale on purpose
+    ctx.run(default_params(), STAGE_ALL)
+    ctx.sync()
+    assert np.array_equal(ctx.binary(0), oracle.detect_frame(frames[0], oracle.default_params())["binary"])
