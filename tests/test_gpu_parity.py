@@ -403,3 +403,24 @@ def test_no_image_modifier_changes_nothing_but_the_image(ctx, oracle):
     ctx.run(default_params(), STAGE_ALL)
     ctx.sync()
     assert np.array_equal(ctx.binary(0), oracle.detect_frame(frames[0], oracle.default_params())["binary"])
+
+
+def test_c5_geometry_every_frame(oracle):
+    """BASELINE config 5's geometry (1920x1200: 37.5 strips per frame, so the last strip of every frame is partial and the tapered
+    strip queue hands out pieces that lie wholly below the image): binary, contours, armours of every frame"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from rmcv_amd import Context
+    n = 64
+    c = Context(device=0, max_frames=n, max_width=1920, max_height=1200)
+    frames = synth.batch(70000, n, 1920, 1200, CAMP_BLUE, 1, threads=16)
+    arm, offs = c.detect_batch(frames)
+    p = oracle.default_params()
+    with ThreadPoolExecutor(16) as ex:
+        refs = list(ex.map(lambda f: oracle.detect_frame(frames[f], p), range(n)))
+    for f in range(n):
+        assert np.array_equal(c.binary(f), refs[f]["binary"]), f
+        pts, co = c.contours(f)
+        assert np.array_equal(co, refs[f]["offs"]) and np.array_equal(pts, refs[f]["pts"]), f
+        assert arm[offs[f]:offs[f + 1]].tobytes() == refs[f]["armours"].tobytes(), f
+    c.close()
