@@ -252,6 +252,17 @@ int  rmcv_batch_set_base2gripper(rmcv_ctx* ctx, const double* mats, int n_frames
 /* batch: poses in the order of rmcv_batch_get_armours (after a run that included RMCV_STAGE_POSE) */
 int  rmcv_batch_get_poses(rmcv_ctx* ctx, double* rvecs, double* tvecs, double* positions, int cap, int32_t* n_total);
 
+/* ---- tracker bookkeeping: the "next" row SURVEY 8f-4 (src/core.cpp:124-162) -------------------------------------------
+ * Host-side predicates over caller memory: the tracker is sequential per target by nature (executable/main.cpp:57-88) and works
+ * on a handful of armours.  Only what the reference can observe is provided: the Kalman state of rm::armour::reset / update
+ * (src/core.cpp:51-122) is private and never read anywhere in the reference. */
+/* rm::armour::max_IoU (src/core.cpp:144-162): *index = the armour of `list` with the largest IoU of bounding boxes with `self`
+ * (first on ties, -1 when none overlaps), *iou = that IoU */
+int rmcv_max_iou(const rmcv_armour* self, const rmcv_armour* list, int n, int32_t* index, float* iou);
+/* rm::armour::identity_max (src/core.cpp:124-142): soft-max vote over an identity histogram; ids ascending (the reference keeps a
+ * std::map<int,int>); *max_id = -1 for an empty histogram */
+int rmcv_identity_max(const int32_t* ids, const int32_t* counts, int n, int32_t* max_id, double* prob);
+
 /* ---- synthetic stream: host generator, integer-only, bit-reproducible --- */
 int      rmcv_synth_frame(uint8_t* bgr, int w, int h, int stride, uint64_t frame_index, int camp, int variant);
 uint64_t rmcv_synth_checksum(const uint8_t* bgr, int w, int h, int stride);

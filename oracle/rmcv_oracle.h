@@ -159,6 +159,10 @@ void orc_armour_position(const double tvec[3], const double base2gripper[16], co
 void orc_locate_armours(const orc_armour* armours, int n, const orc_pnp_config* cfg, const double base2gripper[16] /* NULL = I */,
                         double* rvecs, double* tvecs, double* positions);
 
+/* "Next" row SURVEY 8f-4 (rmcv_oracle_track.c): the observable part of the tracker, core.cpp:124-162 */
+void orc_max_iou(const orc_armour* self, const orc_armour* list, int n, int32_t* index, float* iou);
+void orc_identity_max(const int32_t* ids /* ascending */, const int32_t* counts, int n, int32_t* max_id, double* prob);
+
 #ifdef __cplusplus
 }
 #endif

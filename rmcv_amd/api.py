@@ -181,6 +181,28 @@ class Context:
             raise RmcvError(rc, "rightIndex == size(): out of range in the reference")
         return bool(o.value)
 
+    @staticmethod
+    def max_iou(self_armour, armours):
+        """rm::armour::max_IoU: (index, IoU) of the best-overlapping armour, index -1 when none overlaps"""
+        me = np.ascontiguousarray(self_armour, ARMOUR).reshape(1)
+        arr = np.ascontiguousarray(armours, ARMOUR)
+        idx, iou = C.c_int32(0), C.c_float(0)
+        rc = lib().rmcv_max_iou(ptr(me), ptr(arr), len(arr), C.byref(idx), C.byref(iou))
+        if rc:
+            raise RmcvError(rc, "rmcv_max_iou")
+        return idx.value, iou.value
+
+    @staticmethod
+    def identity_max(history):
+        """rm::armour::identity_max over {identity: count}: (identity, probability)"""
+        ids = np.array(sorted(history), np.int32)
+        cnt = np.array([history[int(k)] for k in ids], np.int32)
+        mid, pr = C.c_int32(0), C.c_double(0)
+        rc = lib().rmcv_identity_max(ptr(ids), ptr(cnt), len(ids), C.byref(mid), C.byref(pr))
+        if rc:
+            raise RmcvError(rc, "rmcv_identity_max")
+        return mid.value, pr.value
+
     def run_legacy(self, legacy, params=None, stages=STAGE_ALL, stream=None):
         """batch path with rm::FindLightBlobs (legacy: LegacyParams) in place of rm::filter_lightblobs"""
         self._params = params or default_params()

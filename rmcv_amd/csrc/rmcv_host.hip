@@ -4,6 +4,7 @@
 // (/root/reference/CMakeLists.txt:13-16); the calls a maintainer re-hosts on this ABI are exactly
 // rm::extract_color / rm::filter_lightblobs / rm::filter_armours (executable/main.cpp:172-176).
 // No CPU path exists here: every entry point enqueues hand-written HIP kernels.
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -806,6 +807,71 @@ int rmcv_locate_armours(rmcv_ctx* c, const rmcv_armour* armours, int n, const do
     std::vector<double> all((size_t)n * 9);
     HIPCHK(c, hipMemcpy(all.data(), c->bufs.poses, all.size() * sizeof(double), hipMemcpyDeviceToHost), "D2H poses");
     for (int a = 0; a < n; a++) scatter_poses(all, (size_t)a, rvecs, tvecs, positions, (size_t)a);
+    return RMCV_OK;
+}
+
+// ---- tracker bookkeeping: host-side, see include/rmcv_abi.h --------------------------------------------------
+namespace {
+struct RectF { float x, y, w, h; };
+inline bool rect_empty(const RectF& r) { return r.w <= 0 || r.h <= 0; }
+// cv::Rect_<float>::operator& (the overflow-safe form of OpenCV >= 4.5)
+inline RectF rect_and(const RectF& a, const RectF& b)
+{
+    const RectF zero = {0, 0, 0, 0};
+    if (rect_empty(a) || rect_empty(b)) return zero;
+    const RectF& rx_min = (a.x < b.x) ? a : b;
+    const RectF& rx_max = (a.x < b.x) ? b : a;
+    const RectF& ry_min = (a.y < b.y) ? a : b;
+    const RectF& ry_max = (a.y < b.y) ? b : a;
+    if ((rx_min.x < 0 && rx_min.x + rx_min.w < rx_max.x) || (ry_min.y < 0 && ry_min.y + ry_min.h < ry_max.y)) return zero;
+    RectF o;
+    o.w = std::min(rx_min.w - (rx_max.x - rx_min.x), rx_max.w);
+    o.h = std::min(ry_min.h - (ry_max.y - ry_min.y), ry_max.h);
+    o.x = rx_max.x;
+    o.y = ry_max.y;
+    return rect_empty(o) ? zero : o;
+}
+} // namespace
+
+int rmcv_max_iou(const rmcv_armour* self, const rmcv_armour* list, int n, int32_t* index, float* iou_out)
+{
+    if (!self || !index || !iou_out || n < 0 || (n > 0 && !list)) return RMCV_ERR_BAD_ARG;
+    int idx = -1;
+    float max = 0;
+    const RectF me = {self->bbox[0], self->bbox[1], self->bbox[2], self->bbox[3]};
+    for (int i = 0; i < n; i++) { // src/core.cpp:148-160
+        const RectF other = {list[i].bbox[0], list[i].bbox[1], list[i].bbox[2], list[i].bbox[3]};
+        const RectF in = rect_and(me, other);
+        const float union_area = me.w * me.h + other.w * other.h - in.w * in.h;
+        const float iou = in.w * in.h / union_area;
+        if (iou > max) {
+            max = iou;
+            idx = i;
+        }
+    }
+    *index = idx;
+    *iou_out = max;
+    return RMCV_OK;
+}
+
+int rmcv_identity_max(const int32_t* ids, const int32_t* counts, int n, int32_t* max_id, double* prob_out)
+{
+    if (!max_id || !prob_out || n < 0 || (n > 0 && (!ids || !counts))) return RMCV_ERR_BAD_ARG;
+    for (int i = 1; i < n; i++)
+        if (ids[i] <= ids[i - 1]) return RMCV_ERR_BAD_ARG; // std::map order
+    double sum = 0;
+    for (int i = 0; i < n; i++) sum += exp((double)counts[i]); // src/core.cpp:127
+    double max = 0;
+    int id = -1;
+    for (int i = 0; i < n; i++) {
+        const double prob = exp((double)counts[i]) / sum; // :133
+        if (prob > max) {
+            max = prob;
+            id = ids[i];
+        }
+    }
+    *max_id = id;
+    *prob_out = max;
     return RMCV_OK;
 }
 

@@ -285,3 +285,20 @@ def locate_armours(armours, cfg=None, base2gripper=None):
     b = None if base2gripper is None else np.ascontiguousarray(base2gripper, np.float64).reshape(16)
     lib().orc_locate_armours(_p(arm), n, C.byref(cfg), _p(b) if b is not None else None, _p(r), _p(t), _p(p))
     return r[:n], t[:n], p[:n]
+
+
+# ---------------------------------------------------------------- observable tracker parts (oracle/rmcv_oracle_track.c)
+def max_iou(self_armour, armours):
+    me = np.ascontiguousarray(self_armour, ARMOUR).reshape(1)
+    arr = np.ascontiguousarray(armours, ARMOUR)
+    idx, iou = C.c_int32(0), C.c_float(0)
+    lib().orc_max_iou(_p(me), _p(arr), len(arr), C.byref(idx), C.byref(iou))
+    return idx.value, iou.value
+
+
+def identity_max(history):
+    ids = np.array(sorted(history), np.int32)
+    cnt = np.array([history[int(k)] for k in ids], np.int32)
+    mid, pr = C.c_int32(0), C.c_double(0)
+    lib().orc_identity_max(_p(ids), _p(cnt), len(ids), C.byref(mid), C.byref(pr))
+    return mid.value, pr.value
