@@ -190,157 +190,8 @@ __device__ void literal_frame(int lane, const uint64_t* F, uint64_t* LAB, uint64
     *st_out = st;
 }
 
-// ---- wave-cooperative border following ------------------------------------------------------------------
-// The 64 lanes of a wavefront hold a 64-row x 64-column window of F (lane i = row wy0+i) in registers; the walk
-// itself is wave-uniform scalar work that fetches the three rows it needs with v_readlane -- no memory access per
-// step.  The window is re-centred (one load per lane) when the walk leaves it.
-struct WWin {
-    uint64_t fw;
-    int xb, wy0;
-};
-
-__device__ __forceinline__ uint64_t rl64(uint64_t v, int l)
-{
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ void wwin_load(WWin& W, const uint32_t* F32, int prow, int h, int x, int y, int lane)
-{
-    W.xb = ((x - 24) >> 5) * 32;
-    W.wy0 = y - 12;
-    const int r = W.wy0 + lane;
-    W.fw = (r >= -1 && r <= h) ? win_load(F32, prow, r, W.xb) : 0ull;
-}
-
-__device__ __forceinline__ uint32_t nbmask3(uint64_t r0, uint64_t r1, uint64_t r2, int sh)
-{
-    const uint32_t u = (uint32_t)(r0 >> sh) & 7u, m = (uint32_t)(r1 >> sh) & 7u, d = (uint32_t)(r2 >> sh) & 7u;
-    return ((m >> 2) & 1u) | (((u >> 2) & 1u) << 1) | (((u >> 1) & 1u) << 2) | ((u & 1u) << 3) | ((m & 1u) << 4) |
-           ((d & 1u) << 5) | (((d >> 1) & 1u) << 6) | (((d >> 2) & 1u) << 7);
-}
-
-// ---- table-driven walk + parallel replay -----------------------------------------------------------------
-// One border-following step is a pure function of (direction back to the previous pixel, 3x3 neighbourhood):
-// a 4096-entry byte table in LDS, index = s_back<<9 | up<<6 | mid<<3 | down (each 3 bits: x-1, x, x+1), value =
-// s_new | right_exit<<3 | (dx+1)<<4 | (dy+1)<<6.  The walk records a 4-bit code per step in lane registers (lane
-// n>>5 holds steps 32*(n>>5)..+31), so a kept contour is not walked twice: the codes are replayed by all lanes in
-// parallel (prefix sum of the per-lane displacements) to write the points and the labels.
-static constexpr int CODE_CAP = 2048; // steps recorded per contour (64 lanes x 128 bits / 4); longer ones are re-walked
-
 __device__ __forceinline__ int dir_dx(int s) { return (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0); }
 __device__ __forceinline__ int dir_dy(int s) { return (s >= 1 && s <= 3) ? -1 : ((s >= 5) ? 1 : 0); }
-
-__device__ void lut_build(uint8_t* lut, int tid, int nthreads)
-{
-    for (int idx = tid; idx < 4096; idx += nthreads) {
-        const int s_end = idx >> 9;
-        const uint32_t u = (idx >> 6) & 7, m = (idx >> 3) & 7, d = idx & 7;
-        const uint32_t nb = ((m >> 2) & 1u) | (((u >> 2) & 1u) << 1) | (((u >> 1) & 1u) << 2) | ((u & 1u) << 3) | ((m & 1u) << 4) |
-                            ((d & 1u) << 5) | (((d >> 1) & 1u) << 6) | (((d >> 2) & 1u) << 7);
-        uint8_t e = 0;
-        if (nb) {
-            const int k = (s_end + 1) & 7;
-            const uint32_t rot = ((nb | (nb << 8)) >> k) & 0xFFu;
-            const int sn = (k + (__ffs((int)rot) - 1)) & 7;
-            const int rex = ((unsigned)(sn - 1) < (unsigned)s_end) ? 1 : 0;
-            e = (uint8_t)(sn | (rex << 3) | ((dir_dx(sn) + 1) << 4) | ((dir_dy(sn) + 1) << 6));
-        }
-        lut[idx] = e;
-    }
-}
-
-// Walk the border from (x0,y0) without writing anything to memory.  Returns the number of points; *state:
-// 0 = complete, 1 = single pixel, 2 = aborted (a raster-earlier pixel was met: (x0,y0) is not a first pixel).
-__device__ int walk_record(WWin& W, const uint32_t* F32, int prow, int h, int x0, int y0, int lane, const uint8_t* lut,
-                           int* state, uint64_t* c0_out, uint64_t* c1_out)
-{
-    const uint32_t key0 = ((uint32_t)y0 << 16) | (uint32_t)x0;
-    int x = x0, y = y0, n = 0;
-    uint64_t c0 = 0, c1 = 0;
-    *state = 0;
-    int s_back;
-    int x1, y1;
-    {
-        const int ly = y - W.wy0;
-        const uint32_t nb = nbmask3(rl64(W.fw, ly - 1), rl64(W.fw, ly), rl64(W.fw, ly + 1), x - W.xb - 1);
-        int s = 4;
-        do { s = (s - 1) & 7; } while (!((nb >> s) & 1u) && s != 4);
-        if (s == 4) { // single pixel: one step, no move, negative label (icvFetchContour's isolated-pixel case)
-            *state = 1;
-            *c0_out = (lane == 0) ? 8ull : 0ull;
-            *c1_out = 0;
-            return 1;
-        }
-        x1 = x0 + dir_dx(s);
-        y1 = y0 + dir_dy(s);
-        s_back = s;
-    }
-    for (;;) {
-        const int ly = y - W.wy0, sh = x - W.xb - 1;
-        const uint32_t u = (uint32_t)(rl64(W.fw, ly - 1) >> sh) & 7u, m = (uint32_t)(rl64(W.fw, ly) >> sh) & 7u,
-                       d = (uint32_t)(rl64(W.fw, ly + 1) >> sh) & 7u;
-        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lut[(s_back << 9) | (u << 6) | (m << 3) | d]);
-        if ((((uint32_t)y << 16) | (uint32_t)x) < key0) { *state = 2; break; }
-        // ---- straight vertical runs in one go.  In the steady states "came from the north, go on south" and "came from
-        // the south, go on north" every further pixel of the column is judged with the SAME back direction, so whether
-        // it repeats this very step is a function of its own 3x3 neighbourhood: all 64 window rows evaluate the table
-        // at once (rows above/below via lane shuffles), a ballot gives the length of the run, and its steps are
-        // recorded together.  (Bars are mostly vertical edges: this removes most of the sequential steps.)
-        int extra = 0;
-        const int sdir = (int)(e & 7u);
-        if ((sdir == 6 && s_back == 2) || (sdir == 2 && s_back == 6 && x != x0)) {
-            const uint64_t up = __shfl_up(W.fw, 1), dn = __shfl_down(W.fw, 1);
-            const uint32_t ur = (uint32_t)(up >> sh) & 7u, mr = (uint32_t)(W.fw >> sh) & 7u, dr = (uint32_t)(dn >> sh) & 7u;
-            const bool same = lane >= 1 && lane <= 62 && (uint32_t)lut[(s_back << 9) | (ur << 6) | (mr << 3) | dr] == e;
-            const uint64_t okm = __ballot(same);
-            if (sdir == 6) { // rows below the current one
-                const uint64_t t = ly < 63 ? okm >> (ly + 1) : 0ull;
-                extra = (~t) ? __ffsll((long long)~t) - 1 : 64;
-            } else {         // rows above
-                const uint64_t t = ly > 0 ? okm << (64 - ly) : 0ull;
-                extra = (~t) ? __clzll((long long)~t) : 64;
-                // the raster-smallest pixel of the run is its top end
-                if (extra > 0 && ((((uint32_t)(y - extra)) << 16) | (uint32_t)x) < key0) { *state = 2; break; }
-            }
-        }
-        { // record the step(s) in the lanes that own them -- branch-free (selects, no EXEC change in the hot loop)
-            const int a = n - 32 * lane, b = n + extra + 1 - 32 * lane; // this lane owns steps [0,32) of [a,b)
-            const int lo = a < 0 ? 0 : a, hi = b > 32 ? 32 : b;
-            const bool any = lo < hi && n + extra < CODE_CAP;
-            const uint64_t pat = 0x1111111111111111ull * (uint64_t)(e & 15u);
-            // nibble ranges [lo,hi) split over the two 16-step registers
-            const int l0 = lo < 16 ? lo : 16, h0 = hi < 16 ? hi : 16, l1 = lo > 16 ? lo - 16 : 0, h1 = hi > 16 ? hi - 16 : 0;
-            const uint64_t m0 = (h0 >= 16 ? ~0ull : ((1ull << (4 * h0)) - 1)) & ~((1ull << (4 * l0)) - 1);
-            const uint64_t m1 = (h1 >= 16 ? ~0ull : ((1ull << (4 * h1)) - 1)) & ~((1ull << (4 * l1)) - 1);
-            c0 |= (any && l0 < h0) ? (pat & m0) : 0ull;
-            c1 |= (any && l1 < h1) ? (pat & m1) : 0ull;
-        }
-        n += 1 + extra;
-        const int cx = x, cy = y + extra * ((int)((e >> 6) & 3u) - 1);
-        x += (int)((e >> 4) & 3u) - 1;
-        y += (1 + extra) * ((int)((e >> 6) & 3u) - 1);
-        if (x == x0 && y == y0 && cx == x1 && cy == y1) break; // i4 == i0 && i3 == i1
-        if (n >= (1 << 22)) break;                             // cannot happen on a consistent plane
-        const int wx = x - W.xb, wy = y - W.wy0;
-        if (wx < 1 || wx > 62 || wy < 1 || wy > 62) wwin_load(W, F32, prow, h, x, y, lane);
-        s_back = ((int)(e & 7u) + 4) & 7;
-    }
-    *c0_out = c0;
-    *c1_out = c1;
-    return n;
-}
-
-__device__ __forceinline__ int wave_excl_scan_i32(int v, int lane)
-{
-    int inc = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(inc, d);
-        if (lane >= d) inc += t;
-    }
-    return inc - v;
-}
 
 // Sparse label store of the fast path: one LDS slot per NON-EMPTY word of F (labels only exist where F is set).
 // slot(y, k) = rowbase[y] + popcount(rowmask[y] & ((1 << k) - 1)).
@@ -352,62 +203,9 @@ struct LabelStore {
     __device__ __forceinline__ int slot(int y, int k) const { return rowbase[y] + __popc(rowmask[y] & ((1u << k) - 1u)); }
 };
 
-// all lanes replay the recorded steps: points -> out[0..n), labels -> the LDS label store (n <= CODE_CAP).
-// The codes sit 32 per lane (lane n>>5); the replay spreads them over all 64 lanes, spl = 1, 2, 4 .. 32 consecutive
-// steps per lane (each lane fetches its owner's code registers with a shuffle), so a 150-point contour costs 4
-// dependent LDS round trips per lane instead of 32.
-__device__ void replay_emit(int n, int x0, int y0, int lane, uint64_t c0, uint64_t c1, rmcv_point* out, const LabelStore& LS)
-{
-    int spl = 1;
-    while (spl * 64 < n) spl <<= 1; // <= 32 because n <= CODE_CAP
-    const int first = lane * spl;
-    int cnt = n - first;
-    cnt = cnt < 0 ? 0 : (cnt > spl ? spl : cnt);
-    const int owner = (first >> 5) & 63, sub = first & 31;
-    const uint64_t o0 = __shfl(c0, owner), o1 = __shfl(c1, owner);
-    // the lane's codes, 4 bits each, starting at bit 0 (sub is a multiple of spl, so the run never straddles c0/c1
-    // unless spl == 32, where sub == 0)
-    const uint64_t lo = sub < 16 ? (o0 >> (4 * sub)) : (o1 >> (4 * (sub - 16)));
-    const uint64_t hi = o1; // only used when spl == 32 (steps 16..31)
-    int dx = 0, dy = 0;
-    for (int j = 0; j < cnt; j++) {
-        const int sdir = (int)((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16))) & 7u);
-        dx += dir_dx(sdir);
-        dy += dir_dy(sdir);
-    }
-    int x = x0 + wave_excl_scan_i32(dx, lane), y = y0 + wave_excl_scan_i32(dy, lane);
-    int pslot = -1, py = -1, pk = -1; // pending label word
-    unsigned long long plab = 0, pneg = 0;
-    for (int j = 0; j < cnt; j++) {
-        const uint32_t code = (uint32_t)(j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16))) & 15u;
-        rmcv_point p;
-        p.x = x;
-        p.y = y;
-        out[first + j] = p;
-        if (y != py || (x >> 6) != pk) {
-            if (plab) atomicOr(LS.lab + pslot, plab);
-            if (pneg) atomicOr(LS.neg + pslot, pneg);
-            py = y;
-            pk = x >> 6;
-            pslot = LS.slot(y, pk);
-            plab = 0;
-            pneg = 0;
-        }
-        plab |= 1ull << (x & 63);
-        if (code & 8u) pneg |= 1ull << (x & 63);
-        x += dir_dx((int)(code & 7u));
-        y += dir_dy((int)(code & 7u));
-    }
-    if (plab) atomicOr(LS.lab + pslot, plab);
-    if (pneg) atomicOr(LS.neg + pslot, pneg);
-}
-
 // ---- k_contours: one workgroup (8 wavefronts) per frame ---------------------------------------------------
-//  T  every thread scans non-empty rows for LOCAL TOPS (run starts whose run touches nothing in the row above):
-//     the raster-first pixel of every 8-connected component is one of them
-//  S  wavefronts pull tops from a queue and walk them; a walk that meets no raster-earlier pixel started at the
-//     first pixel of a component and followed its outer border -> kept, replayed into points + labels.
-//     Walks are independent, so all components of a frame are followed concurrently.
+//  C  all borders of the frame at once as cycles of visits (cycles_frame below): nodes from the bit plane, linked, ranked by
+//     pointer doubling -> points + labels of every outer border.
 //  V  verification of OpenCV's RETR_EXTERNAL bookkeeping on the merged labels: every kept start must have been
 //     accepted (nearest labelled pixel to its left negative or absent) and every other unlabelled run start
 //     rejected.  True for frames without nested components; then discovery order = raster order of the starts.
@@ -418,7 +216,6 @@ __device__ void replay_emit(int n, int x0, int y0, int lane, uint64_t c0, uint64
 // LDS budget: the workgroup shares its CU with the pixel kernels of the next two batches (2 x 2 x 11.5 KB) and with other
 // frames' workgroups, so the tables are sized for ~50 KB (3 per CU); measured +4-8 % on the 3-stream bench against 75 KB.
 // Frames beyond a capacity take the literal path (tests/test_gpu_parity.py covers each limit).
-static constexpr int CAND_CAP = 1024;
 static constexpr int KEPT_CAP = 512;
 static constexpr int SLOT_CAP = 1024;  // non-empty words of a frame the LDS label store can hold
 // Workgroup size is a template parameter: 8 wavefronts walk and fit the bars of a frame concurrently (lowest latency for one
@@ -426,19 +223,371 @@ static constexpr int SLOT_CAP = 1024;  // non-empty words of a frame the LDS lab
 // one (VGPR budget per SIMD: 2 x 160 for this kernel at 8 wavefronts, 2 x 80 per pixel kernel, 512 in all) -- the better choice
 // when several batches are in flight (886 k against 800 k frames/s with three batches; 0.57 against 0.475 ms for a lone batch).
 static constexpr int CT_THREADS_MAX = 512;
+static constexpr int NN_CAP = VISIT_CAP;    // border visits (nodes) of a frame the cycle formulation holds in LDS
 static constexpr int CT_MAXH = 2048;   // rows covered by the LDS row tables (taller/wider frames take the literal path)
 
 struct ContoursLds {
     unsigned long long lab[SLOT_CAP], neg[SLOT_CAP];
     uint32_t rowmask[CT_MAXH];
-    uint32_t cand[CAND_CAP];
     uint32_t kkey[KEPT_CAP];
     int32_t koff[KEPT_CAP], klen[KEPT_CAP];
     uint16_t rows[CT_MAXH], rowbase[CT_MAXH];
     int scan[CT_THREADS_MAX];
-    uint8_t lut[4096];
-    int ncand, next, nkept, cursor, flags, nrows, nslots, nelig, lit[3];
-    int dummy[64]; // per-lane sinks: lanes != 0 add 0 here so that a wave-wide atomic does not serialise on one word
+    // cycle formulation (cycles_frame): border pixels / two-visit pixels per slot, node-id base and (row, word) per slot, node tables
+    unsigned long long bmask[SLOT_CAP], e2mask[SLOT_CAP];
+    uint16_t nbase[SLOT_CAP], spos[SLOT_CAP];
+    uint16_t n_a[NN_CAP], n_b[NN_CAP], n_d[NN_CAP];
+    uint32_t ringtab[256];
+    int nnodes, nkept, cursor, flags, nrows, nslots, nelig, lit[3];
 };
+
+// ---- cycle formulation of the border following --------------------------------------------------------------------------
+// Every VISIT of Suzuki's follower to a pixel is a node: (pixel, maximal arc of consecutive background neighbours that contains
+// a 4-neighbour; the follower arrives with its back to the foreground neighbour at the arc's clockwise end and leaves towards
+// the one at its counter-clockwise end).  The follower's step is a bijection on nodes, so a border is a CYCLE of nodes; its
+// points in OpenCV's order are the cycle read from its raster-first node, and it is an outer border iff that node's arc
+// contains the west neighbour (tools/proto/cycle_contours.py checks this restatement against the oracle).  Instead of walking
+// a border step by step (one wavefront, ~0.3 us per step, the longest contour of a frame bounding the stage) all nodes of the
+// frame are created at once from the bit plane, linked, and ranked by pointer doubling: log2(nodes) rounds of the whole
+// workgroup, independent of how long any single contour is.
+//   ringtab[ring]: cnt:3 | back0..3 (3 bits each) | next0..3 (3 bits each) | west(arc 0):1 | neg0..3:4   (arc 0 = the arc with W)
+//   pxy[node]    : x:12 | y:12 | back:3 | neg:1 | west:1 | next:3   (global scratch: written once, read twice)
+constexpr uint32_t ring_entry(int ring)
+{
+    uint32_t backs[4] = {0, 0, 0, 0}, nexts[4] = {0, 0, 0, 0}, negs[4] = {0, 0, 0, 0};
+    int cnt = 0, west0 = 0;
+    if (ring == 0) { // isolated pixel: one visit that stays; OpenCV gives it the negative label
+        cnt = 1;
+        west0 = 1;
+        negs[0] = 1;
+    } else {
+        int wa = -1;
+        for (int b = 0; b < 8; b++) {
+            if (!((ring >> b) & 1)) continue;
+            int d = (b + 1) & 7, axis = 0, west = 0, len = 0;
+            while (!((ring >> d) & 1)) {
+                axis |= !(d & 1);
+                west |= d == 4;
+                d = (d + 1) & 7;
+                len++;
+            }
+            if (!len || !axis) continue; // no background 4-neighbour in the arc: the follower never comes this way
+            if (cnt < 4) {
+                backs[cnt] = (uint32_t)b;
+                nexts[cnt] = (uint32_t)d;
+                negs[cnt] = ((unsigned)(d - 1) < (unsigned)b) ? 1u : 0u; // the sweep passed the east neighbour
+                if (west) wa = cnt;
+            }
+            cnt++;
+        }
+        if (wa > 0 && wa < 4) { // the west arc first
+            uint32_t t = backs[0]; backs[0] = backs[wa]; backs[wa] = t;
+            t = nexts[0]; nexts[0] = nexts[wa]; nexts[wa] = t;
+            t = negs[0]; negs[0] = negs[wa]; negs[wa] = t;
+        }
+        west0 = wa >= 0;
+    }
+    uint32_t e = (uint32_t)(cnt > 7 ? 7 : cnt);
+    for (int a = 0; a < 4; a++) e |= (backs[a] << (3 + 3 * a)) | (nexts[a] << (15 + 3 * a)) | (negs[a] << (28 + a));
+    e |= (uint32_t)west0 << 27;
+    return e;
+}
+struct RingTab {
+    uint32_t v[256];
+    constexpr RingTab() : v()
+    {
+        for (int r = 0; r < 256; r++) v[r] = ring_entry(r);
+    }
+};
+static __device__ const RingTab RINGTAB = RingTab();
+
+// 8-bit ring of pixel bit b of word c from the three rows' words (l = word k-1, c = word k, r = word k+1 of each row)
+__device__ __forceinline__ uint32_t ring_of(int b, uint64_t ul, uint64_t uc, uint64_t ur, uint64_t ml, uint64_t mc, uint64_t mr,
+                                            uint64_t dl, uint64_t dc, uint64_t dr)
+{
+    // 3 bits (x-1, x, x+1) of a row
+    auto three = [&](uint64_t l, uint64_t c, uint64_t r) -> uint32_t {
+        if (b == 0) return (uint32_t)(l >> 63) | ((uint32_t)(c & 3ull) << 1);
+        if (b == 63) return (uint32_t)(c >> 62) | ((uint32_t)(r & 1ull) << 2);
+        return (uint32_t)(c >> (b - 1)) & 7u;
+    };
+    const uint32_t u = three(ul, uc, ur), m = three(ml, mc, mr), d = three(dl, dc, dr);
+    return ((m >> 2) & 1u) | (((u >> 2) & 1u) << 1) | (((u >> 1) & 1u) << 2) | ((u & 1u) << 3) | ((m & 1u) << 4) | ((d & 1u) << 5) |
+           (((d >> 1) & 1u) << 6) | (((d >> 2) & 1u) << 7);
+}
+
+// findContours of one frame by the whole workgroup (T threads); on return S.kkey/koff/klen/nkept/cursor describe the kept contours
+// exactly as the walk-based S phase leaves them, the points are written and the labels are in the LDS label store.
+// FL (= FL_COMPLEX) is OR-ed into S.flags when a capacity is exceeded or a pixel is visited three times.
+template <int T>
+__device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int prow, int h, int ww, int nrows, int tid,
+                             rmcv_point* __restrict__ pts, int max_points, int max_contours, int FL, uint32_t* __restrict__ pxy)
+{
+    constexpr int NPT = NN_CAP / T; // nodes per thread in the doubling rounds
+    const LabelStore LS = {S.rowmask, S.rowbase, S.lab, S.neg};
+    uint16_t* const nxt = S.n_a; // successor, later the distance from the cycle's start
+    uint16_t* const mn = S.n_b;  // smallest node id of the cycle
+    uint16_t* const jp = S.n_d;  // doubling pointer, later the kept-contour slot of a start node
+#ifdef RMCV_PROFILE
+    long long tc_[10]; int tci_ = 0;
+#define CSTAMP() do { __syncthreads(); tc_[tci_++] = wall_clock64(); } while (0)
+#else
+#define CSTAMP() do {} while (0)
+#endif
+    CSTAMP();
+    for (int i = tid; i < 256; i += T) S.ringtab[i] = RINGTAB.v[i];
+    if (tid == 0) S.nnodes = 0;
+    __syncthreads();
+    CSTAMP();
+    // slot -> (row, word): y | k << 11
+    for (int r = tid; r < nrows; r += T) {
+        const int y = S.rows[r];
+        uint32_t occ = S.rowmask[y];
+        int slot = S.rowbase[y];
+        while (occ) {
+            const int k = __ffs((int)occ) - 1;
+            occ &= occ - 1;
+            S.spos[slot++] = (uint16_t)(y | (k << 11));
+        }
+    }
+    __syncthreads();
+    CSTAMP();
+    // ---- N1: per non-empty word: border pixels, pixels visited twice, node count
+    const int nslots = S.nslots;
+    for (int slot = tid; slot < nslots; slot += T) {
+        const int y = S.spos[slot] & 2047, k = S.spos[slot] >> 11;
+        const int64_t base = (int64_t)(y + 1) * prow + 1;
+        const uint64_t mc = F[base + k];
+        const uint64_t ul = F[base - prow + k - 1], uc = F[base - prow + k], ur = F[base - prow + k + 1];
+        const uint64_t ml = F[base + k - 1], mr = F[base + k + 1];
+        const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
+        const uint64_t left = (mc << 1) | (ml >> 63), right = (mc >> 1) | (mr << 63);
+        uint64_t B = mc & ~(uc & dc & left & right), E2 = 0, rem = B;
+        while (rem) {
+            const int b = __ffsll((long long)rem) - 1;
+            rem &= rem - 1;
+            const uint32_t cnt = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)] & 7u;
+            if (cnt == 2) E2 |= 1ull << b;
+            else if (cnt != 1) atomicOr(&S.flags, FL);
+        }
+        S.bmask[slot] = B;
+        S.e2mask[slot] = E2;
+        S.nbase[slot] = (uint16_t)(__popcll(B) + __popcll(E2));
+    }
+    __syncthreads();
+    { // exclusive prefix of the node counts over the slots (raster order): node ids ascend in raster order
+        const int ns = nslots, per = (ns + T - 1) / T;
+        int sum = 0;
+        for (int u = 0; u < per; u++) {
+            const int i = tid * per + u;
+            if (i < ns) sum += S.nbase[i];
+        }
+        S.scan[tid] = sum;
+        __syncthreads();
+        for (int d = 1; d < T; d <<= 1) {
+            const int v = tid >= d ? S.scan[tid - d] : 0;
+            __syncthreads();
+            S.scan[tid] += v;
+            __syncthreads();
+        }
+        int run = S.scan[tid] - sum;
+        for (int u = 0; u < per; u++) {
+            const int i = tid * per + u;
+            if (i < ns) {
+                const int c = S.nbase[i];
+                S.nbase[i] = (uint16_t)(run < 65535 ? run : 65535);
+                run += c;
+            }
+        }
+        if (tid == T - 1) {
+            S.nnodes = S.scan[tid];
+            if (S.scan[tid] > NN_CAP) S.flags |= FL;
+        }
+    }
+    __syncthreads();
+    if (S.flags & FL) return;
+    const int nn = S.nnodes;
+    CSTAMP();
+    // ---- N2: the nodes
+    for (int slot = tid; slot < nslots; slot += T) {
+        const uint64_t B = S.bmask[slot];
+        if (!B) continue;
+        const int y = S.spos[slot] & 2047, k = S.spos[slot] >> 11;
+        const int64_t base = (int64_t)(y + 1) * prow + 1;
+        const uint64_t mc = F[base + k];
+        const uint64_t ul = F[base - prow + k - 1], uc = F[base - prow + k], ur = F[base - prow + k + 1];
+        const uint64_t ml = F[base + k - 1], mr = F[base + k + 1];
+        const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
+        int id = S.nbase[slot];
+        uint64_t rem = B;
+        while (rem) {
+            const int b = __ffsll((long long)rem) - 1;
+            rem &= rem - 1;
+            const uint32_t e = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)];
+            const int cnt = (int)(e & 7u);
+            const uint32_t xy = (uint32_t)(k * 64 + b) | ((uint32_t)y << 12);
+            for (int a = 0; a < cnt && a < 2; a++) {
+                const uint32_t back = (e >> (3 + 3 * a)) & 7u, nextd = (e >> (15 + 3 * a)) & 7u, ng = (e >> (28 + a)) & 1u;
+                const uint32_t west = a == 0 ? (e >> 27) & 1u : 0u;
+                if (id < NN_CAP) pxy[id] = xy | (back << 24) | (ng << 27) | (west << 28) | (nextd << 29);
+                id++;
+            }
+        }
+    }
+    __syncthreads();
+    CSTAMP();
+    // ---- N3: successor and predecessor of every node
+    for (int i = tid; i < nn; i += T) {
+        const uint32_t p = pxy[i];
+        const int x = (int)(p & 0xFFFu), y = (int)((p >> 12) & 0xFFFu), nd = (int)(p >> 29);
+        int succ = i;
+        const int xs = x + dir_dx(nd), ys = y + dir_dy(nd);
+        const int ks = xs >> 6, bs = xs & 63;
+        bool ok = xs >= 0 && ys >= 0 && ys < h && ks < ww && ((S.rowmask[ys] >> ks) & 1u);
+        int slot2 = 0;
+        if (ok) {
+            slot2 = LS.slot(ys, ks);
+            ok = (S.bmask[slot2] >> bs) & 1ull;
+        }
+        if (ok) {
+            const uint64_t below = (1ull << bs) - 1;
+            const int id0 = S.nbase[slot2] + __popcll(S.bmask[slot2] & below) + __popcll(S.e2mask[slot2] & below);
+            const int two = (int)((S.e2mask[slot2] >> bs) & 1ull);
+            const uint32_t back2 = (uint32_t)((nd + 4) & 7);
+            succ = id0 + ((two && ((pxy[id0] >> 24) & 7u) != back2) ? 1 : 0);
+        }
+        // an isolated pixel has no foreground neighbour at all: its "next" leads to background -> it stays (ok == false, succ == i);
+        // for any other node a missing successor would contradict the bijection: flagged
+        if (!ok) {
+            const int k0 = x >> 6;
+            const int64_t base = (int64_t)(y + 1) * prow + 1;
+            const uint32_t ring = ring_of(x & 63, F[base - prow + k0 - 1], F[base - prow + k0], F[base - prow + k0 + 1], F[base + k0 - 1],
+                                          F[base + k0], F[base + k0 + 1], F[base + prow + k0 - 1], F[base + prow + k0], F[base + prow + k0 + 1]);
+            if (ring != 0) atomicOr(&S.flags, FL);
+        }
+        nxt[i] = (uint16_t)succ;
+    }
+    __syncthreads();
+    if (S.flags & FL) return;
+    CSTAMP();
+    // ---- N4: smallest node id of every cycle, by pointer doubling
+    int rounds = 0;
+    while ((1 << rounds) < nn) rounds++;
+    for (int i = tid; i < nn; i += T) {
+        mn[i] = (uint16_t)i;
+        jp[i] = nxt[i];
+    }
+    __syncthreads();
+    for (int rd = 0; rd < rounds; rd++) {
+        uint16_t m2[NPT], j2[NPT];
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int i = tid + u * T;
+            if (i < nn) {
+                const int t = jp[i];
+                m2[u] = mn[t];
+                j2[u] = jp[t];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int i = tid + u * T;
+            if (i < nn) {
+                if (m2[u] < mn[i]) mn[i] = m2[u];
+                jp[i] = j2[u];
+            }
+        }
+        __syncthreads();
+    }
+    CSTAMP();
+    // ---- N5: number of steps from every node FORWARD to its cycle's start (the smallest id); a node's position in the contour is
+    // the cycle length minus that.  The doubling pointers are the successors with the start made absorbing.
+    uint16_t* const dist = nxt; // in place: the successors are read into the doubling pointers first
+    uint16_t succ0[NPT]; // the successor of a start node: the last node of its contour
+#pragma unroll
+    for (int u = 0; u < NPT; u++) {
+        const int i = tid + u * T;
+        succ0[u] = 0;
+        if (i < nn) {
+            const bool start = mn[i] == i;
+            succ0[u] = nxt[i];
+            jp[i] = start ? (uint16_t)i : nxt[i];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nn; i += T) dist[i] = mn[i] == i ? 0 : 1;
+    __syncthreads();
+    for (int rd = 0; rd < rounds; rd++) {
+        uint16_t d2[NPT], j2[NPT];
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int i = tid + u * T;
+            if (i < nn) {
+                const int t = jp[i];
+                d2[u] = dist[t];
+                j2[u] = jp[t];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int i = tid + u * T;
+            if (i < nn) {
+                dist[i] = (uint16_t)(dist[i] + d2[u]);
+                jp[i] = j2[u];
+            }
+        }
+        __syncthreads();
+    }
+    CSTAMP();
+    // ---- N6: every cycle whose start visit contains the west neighbour is an outer border: allocate its output
+#pragma unroll
+    for (int u = 0; u < NPT; u++) {
+        const int i = tid + u * T;
+        if (i >= nn) continue;
+        uint16_t ks = 0xFFFF;
+        if (mn[i] == i && ((pxy[i] >> 28) & 1u)) {
+            const int len = dist[succ0[u]] + 1;
+            const int off = atomicAdd(&S.cursor, len);
+            const int slot = atomicAdd(&S.nkept, 1);
+            if (slot >= KEPT_CAP || slot >= max_contours || off + len > max_points) {
+                atomicOr(&S.flags, FL);
+            } else {
+                const uint32_t p = pxy[i];
+                S.kkey[slot] = ((p >> 12) & 0xFFFu) << 16 | (p & 0xFFFu);
+                S.koff[slot] = off;
+                S.klen[slot] = len;
+                ks = (uint16_t)slot;
+            }
+        }
+        if (mn[i] == i) jp[i] = ks;
+    }
+    __syncthreads();
+    if (S.flags & FL) return;
+    // ---- N7: points and labels
+    for (int i = tid; i < nn; i += T) {
+        const int ks = jp[mn[i]];
+        if (ks == 0xFFFF) continue; // a hole border
+        const uint32_t p = pxy[i];
+        const int x = (int)(p & 0xFFFu), y = (int)((p >> 12) & 0xFFFu);
+        rmcv_point q;
+        q.x = x;
+        q.y = y;
+        const int len = S.klen[ks], pos = dist[i] ? len - dist[i] : 0;
+        if (pos >= 0 && pos < len) pts[S.koff[ks] + pos] = q; // (always, for a consistent plane)
+        const int slot = LS.slot(y, x >> 6);
+        atomicOr(&S.lab[slot], 1ull << (x & 63));
+        if ((p >> 27) & 1u) atomicOr(&S.neg[slot], 1ull << (x & 63));
+    }
+    __syncthreads();
+#ifdef RMCV_PROFILE
+    CSTAMP();
+    if (tid == 0 && (blockIdx.x == 100))
+        printf("[cycles f%d nn=%d rounds=%d] ringtab %.1f N1+scan %.1f N2 %.1f N3 %.1f N4 %.1f N5 %.1f N6+N7 %.1f us\n", (int)blockIdx.x, nn, rounds,
+               (tc_[1] - tc_[0]) / 100.0, (tc_[2] - tc_[1]) / 100.0, (tc_[3] - tc_[2]) / 100.0, (tc_[4] - tc_[3]) / 100.0,
+               (tc_[5] - tc_[4]) / 100.0, (tc_[6] - tc_[5]) / 100.0, (tc_[7] - tc_[6]) / 100.0);
+#endif
+}
 
 } // namespace rmcv

@@ -47,7 +47,7 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
     if (waves == 4) return launch_contours_w4(g, b, lim, X, force_literal, s);
     hipLaunchKernelGGL(k_contours_w8, dim3(g.n_frames), dim3(512), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
                        g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
-                       lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind, X);
+                       lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy);
     return hipGetLastError();
 }
 

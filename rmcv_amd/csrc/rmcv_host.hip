@@ -149,6 +149,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.cont_len, F * d.max_contours);
     if (e == hipSuccess) e = dalloc(c, &b.n_contours, F);
     if (e == hipSuccess) e = dalloc(c, &b.n_points, F);
+    if (e == hipSuccess) e = dalloc(c, &b.visit_xy, F * VISIT_CAP);
     if (e == hipSuccess) e = dalloc(c, &b.blobs, F * d.max_blobs);
     if (e == hipSuccess) e = dalloc(c, &b.blob_src, F * d.max_blobs);
     if (e == hipSuccess) e = dalloc(c, &b.ellipses, F * d.max_blobs);

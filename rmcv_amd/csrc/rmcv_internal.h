@@ -22,6 +22,8 @@ struct Geom {
     int64_t plane_pitch; // words per frame = (h + 2) * prow
 };
 
+static constexpr int VISIT_CAP = 4096; // border visits of one frame the contour stage holds (contours_device.h); more -> literal scanner
+
 struct Limits {
     int max_frames, max_width, max_height, max_contours, max_points, max_blobs, max_armours;
 };
@@ -42,6 +44,7 @@ struct Bufs {
     int32_t* cont_len;     // [frame][max_contours]
     int32_t* n_contours;   // [frame]
     int32_t* n_points;     // [frame]
+    uint32_t* visit_xy;    // [frame][VISIT_CAP] scratch of the contour stage: packed (x, y, directions) of every border visit
     // light blobs (positive list, in findContours order) and the negative list (contour indices)
     rmcv_lightblob* blobs; // [frame][max_blobs]
     int32_t* blob_src;     // [frame][max_blobs]   contour index (findContours order)
