@@ -11,6 +11,10 @@
 // the nearest labelled pixel to its left on the row is NEG or there is none.  Only run starts and
 // labelled pixels matter, so a row is scanned 64 pixels per operation.
 //
+// Fast path (cycles_frame, contours_device.h): every visit of the border follower to a pixel is a node, the follower's step a
+// bijection on nodes, a border a cycle; all nodes of a frame are built at once, linked and ranked by pointer doubling.  The
+// RETR_EXTERNAL bookkeeping is then verified on the merged labels; frames where it does not hold (nested components) take the
+// literal scanner:
 // k_contours_literal: one wavefront per frame.  Lane l owns row 64*band + l of the current band and
 // keeps the first acceptable candidate of its row; the wave repeatedly takes the raster-first one,
 // traces it (border following on a 3-row x 64-bit register window of F), ORs the labels into
