@@ -68,6 +68,7 @@ class Context:
         nc, npnt = C.c_int32(0), C.c_int32(0)
         self._chk(lib().rmcv_extract_color(self._h, ptr(image), w, h, 3 * w, int(target), int(lower_bound), int(morph),
                                            ptr(binary), ptr(pts), cap_p, ptr(offs), cap_c, C.byref(nc), C.byref(npnt)))
+        self.shape = (1, h, w)
         return pts[:npnt.value].copy(), offs[:nc.value + 1].copy(), binary
 
     def filter_lightblobs(self, pts, offs, tilt_max=70.0, ratio_range=(1.5, 80.0), area_range=(10.0, 99999.0),

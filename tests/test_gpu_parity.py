@@ -424,3 +424,50 @@ def test_c5_geometry_every_frame(oracle):
         assert np.array_equal(co, refs[f]["offs"]) and np.array_equal(pts, refs[f]["pts"]), f
         assert arm[offs[f]:offs[f + 1]].tobytes() == refs[f]["armours"].tobytes(), f
     c.close()
+
+
+def test_cycle_formulation_paths(oracle):
+    """which path findContours takes: thin lines / diagonals / spurs (pixels visited twice) stay on the cycle path (status 0), a
+    pixel visited three times (the centre of a 'Y' of 1-px lines) or a frame with more than 4096 border visits goes to the
+    literal scanner (status bit 16); the results are equal either way"""
+    from rmcv_amd import Context
+    c = Context(device=0, max_frames=1, max_width=512, max_height=512, max_contours=16384, max_points=1 << 17)
+
+    def run(canvas):
+        n, npts = _check_contours(c, canvas, oracle)
+        return int(c.counts()["status"][0]), n, npts
+
+    a = np.zeros((200, 300), np.uint8)
+    a[20, 30:200] = 255                                   # horizontal 1-px line: every inner pixel is visited twice
+    a[40:150, 50] = 255                                   # vertical 1-px line
+    for i in range(60):
+        a[60 + i, 100 + i] = 255                          # diagonal
+        a[60 + i, 260 - i] = 255                          # anti-diagonal
+    a[160:170, 10:40] = 255
+    a[165, 40:60] = 255                                   # a block with a spur
+    st, n, npts = run(a)
+    assert st == 0 and n == 5 and npts > 500
+    b = np.zeros((64, 64), np.uint8)
+    b[32, 10:50] = 255
+    b[10:50, 30] = 255                                    # '+': the follower passes the centre diagonally, no pixel is visited 3 times
+    st, n, _ = run(b)
+    assert st == 0 and n == 1
+    b = np.zeros((64, 64), np.uint8)
+    for i in range(1, 12):
+        b[30 - i, 30 - i] = b[30 - i, 30 + i] = b[30 + i, 30] = 255
+    b[30, 30] = 255                                       # 'Y' of 1-px lines: the centre is visited three times
+    st, n, _ = run(b)
+    assert st & 16 and n == 1
+    d = np.zeros((300, 300), np.uint8)
+    for r in range(22):
+        d[4 + 3 * r, 10:110] = 255                         # 22 lines of 100 pixels = 22 x 198 = 4356 visits: more than 4096
+    st, n, _ = run(d)
+    assert st & 16 and n == 22
+    d[4 + 3 * 20:4 + 3 * 22, :] = 0                        # 20 lines = 3960 visits fit
+    st, n, npts = run(d)
+    assert st == 0 and n == 20 and npts == 20 * 198
+    e = np.zeros((300, 300), np.uint8)
+    e[::3, ::3] = 255                                      # 10 000 isolated pixels again, but > SLOT capacity as well
+    st, n, _ = run(e)
+    assert n == 10000
+    c.close()
