@@ -356,37 +356,42 @@ __device__ __forceinline__ bool pair_ok(const rmcv_lightblob& a, const rmcv_ligh
     return true;
 }
 
-// rm::filter_armours for frame f (one wavefront, n = number of light blobs)
+// rm::filter_armours for frame f (one wavefront, n = number of light blobs).  The reference's double loop visits the pairs
+// (i, j), i < j, in lexicographic order; here pair number p (same order) is lane p of a round of 64 pairs, so a frame's ~20 pairs
+// are tested -- and the accepted ones built -- in one round instead of one round per i.
 __device__ inline void armours_frame(int f, int lane, const rmcv_lightblob* blobs, int n, int max_blobs, float angle_diff_max,
-                              float shear_max, float length_ratio_max, int enemy, rmcv_armour* armours, int32_t* n_armours,
-                              int32_t* status, int max_armours)
+                                     float shear_max, float length_ratio_max, int enemy, rmcv_armour* armours, int32_t* n_armours,
+                                     int32_t* status, int max_armours)
 {
     const rmcv_lightblob* lb = blobs + (int64_t)f * max_blobs;
     rmcv_armour* out = armours + (int64_t)f * max_armours;
     int na = 0;
     if (n >= 2) { // :120
-        for (int i = 0; i < n - 1; i++) {
-            const rmcv_lightblob a = lb[i];
-            if (a.target != enemy) continue; // :124
-            for (int jb = i + 1; jb < n; jb += 64) {
-                const int j = jb + lane;
-                bool ok = false;
-                rmcv_lightblob b;
-                if (j < n) {
-                    b = lb[j];
-                    ok = (b.target == enemy) && pair_ok(a, b, angle_diff_max, shear_max, length_ratio_max);
-                }
-                const uint64_t m = __ballot(ok);
-                if (ok) {
-                    const int o = na + lanes_below(m, lane);
-                    if (o < max_armours) {
-                        make_armour(&a, &b, &out[o]); // :161 -> core.cpp:21-49
-                        out[o].blob_i = i;
-                        out[o].blob_j = j;
-                    }
-                }
-                na += __popcll(m);
+        const int total = n * (n - 1) / 2;
+        // this lane's pair of the first round, advanced by 64 pairs per round
+        int i = 0, rem = lane;
+        while (i < n - 1 && rem >= n - 1 - i) { rem -= n - 1 - i; i++; }
+        for (int base = 0; base < total; base += 64) {
+            const int j = i + 1 + rem;
+            bool ok = false;
+            rmcv_lightblob a, b;
+            if (base + lane < total) {
+                a = lb[i];
+                b = lb[j];
+                ok = a.target == enemy && b.target == enemy && pair_ok(a, b, angle_diff_max, shear_max, length_ratio_max); // :124-157
             }
+            const uint64_t m = __ballot(ok);
+            if (ok) {
+                const int o = na + lanes_below(m, lane);
+                if (o < max_armours) {
+                    make_armour(&a, &b, &out[o]); // :161 -> core.cpp:21-49
+                    out[o].blob_i = i;
+                    out[o].blob_j = j;
+                }
+            }
+            na += __popcll(m);
+            rem += 64;
+            while (i < n - 1 && rem >= n - 1 - i) { rem -= n - 1 - i; i++; }
         }
     }
     if (lane == 0) {
