@@ -64,7 +64,7 @@ def main():
     import torch.distributed as dist
 
     from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_ARMOURS, STAGE_BINARY, STAGE_BLOBS,
-                          STAGE_IDENTITY, STAGE_NO_IMAGE, STAGE_POSE, OPT_SPARSE_WAVES, Context, LegacyParams, default_params, synth)
+                          STAGE_IDENTITY, STAGE_NO_IMAGE, STAGE_POSE, OPT_PIXEL_GROUPS, OPT_SPARSE_WAVES, Context, LegacyParams, default_params, synth)
     from rmcv_amd import dist as rdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,6 +102,7 @@ def main():
     for k, c in enumerate(ctxs):
         # several batches in flight: 4 wavefronts per frame in the sparse kernel (throughput); a lone batch: 8 (latency)
         c.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
+        c.set_option(OPT_PIXEL_GROUPS, 2 if ns >= 2 else 4)       # likewise: 2 pixel workgroups per CU when batches overlap, 4 alone
         c.bind_device_frames(frames_k[k].data_ptr(), n, H, W, keepalive=frames_k[k])
         if svm:
             c.svm_load(*svm)
@@ -201,7 +202,8 @@ def main():
     stage /= reps
     # one batch at a time, HIP events around the whole batch, median and min over >= 20 passes
     lone = []
-    ctx.set_option(OPT_SPARSE_WAVES, 8)                            # the latency setting: a lone batch has the CUs to itself
+    ctx.set_option(OPT_SPARSE_WAVES, 8)                            # the latency settings: a lone batch has the CUs to itself
+    ctx.set_option(OPT_PIXEL_GROUPS, 4)
     for _ in range(max(20, reps)):
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(stream):
@@ -213,6 +215,7 @@ def main():
         lone.append(ea.elapsed_time(eb))
     lone.sort()
     ctx.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
+    ctx.set_option(OPT_PIXEL_GROUPS, 2 if ns >= 2 else 4)
     fused_ms = None
     if legacy is None:          # what the steps actually launch: findContours + filter_lightblobs + filter_armours as one kernel
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -272,7 +275,7 @@ def main():
                                                 (" + solve_PnP (IPPE square) and world position per armour" if args.pose else ""),
                                                 " + RCCL gather of armour lists (C4)" if world > 1 else ""),
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
-                   "double_buffered_steps": ns, "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
+                   "double_buffered_steps": ns, "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "pixel_groups_per_cu": 2 if ns >= 2 else 4, "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
                    "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad},
         "lone_batch_ms": {"median": round(lone[len(lone) // 2], 4), "min": round(lone[0], 4), "passes": len(lone),
                           "note": "one batch at a time on one stream, events around detect + compaction (latency, not the metric)"},

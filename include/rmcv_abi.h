@@ -126,6 +126,9 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * pairing) in batch runs -- 8 (default): lowest latency of a lone batch; 4: highest throughput when several batches are in flight
  * on different streams (leaves register-file room on every CU for the pixel kernels of the next batches).  Results are identical. */
 #define RMCV_OPT_SPARSE_WAVES 1
+/* RMCV_OPT_PIXEL_GROUPS: persistent workgroups per CU of the pixel kernel, 1..8 -- 4 (default): fastest for a lone batch; 2: leaves
+ * wave slots and registers on every CU to the kernels of the other batches in flight.  Results are identical. */
+#define RMCV_OPT_PIXEL_GROUPS 2
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 
 /* ---- single frame, host buffers: one call per reference function ---------------------- */

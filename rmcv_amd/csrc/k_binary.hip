@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
 }
 
 template <int CA, int CB>
-static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, hipStream_t s)
+static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, int groups, hipStream_t s)
 {
     const int strips = (g.h + SR - 1) / SR;
     const int n_blocks = g.n_frames * strips;
@@ -365,11 +365,12 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
                       ((uintptr_t)b.frames % 16 == 0);
     static const int forced = getenv("RMCV_K1_LOADV") ? atoi(getenv("RMCV_K1_LOADV")) : -1; // dev knob for A/B runs
     const bool coalesced = fast && g.stride == 3 * g.w && forced == 1; // A/B on MI355X: no faster than per-lane 48 B loads
-    // persistent grid: RMCV_K1_BPC workgroups per CU.  Measured on MI355X: the kernel alone runs equally fast with 2..8
-    // workgroups per CU (0.279-0.285 ms; 0.42 ms with 1).  2 (= 2 of the 8 wave slots of every SIMD) leaves room for the
-    // pixel kernel of the next batch AND the sparse kernels of the previous one on the same CU: with 3 batches in flight
-    // 803 k frames/s against 720 k with 4 per CU (tools/ab_streams.sh).
-    static const int bpc = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 2;
+    // persistent grid: `groups` workgroups per CU (RMCV_OPT_PIXEL_GROUPS; RMCV_K1_BPC overrides for A/B runs).  Measured on
+    // MI355X: alone the kernel is fastest with 4 (0.257-0.262 ms; 0.277-0.285 with 2, 0.42 with 1) -- the default, for a lone
+    // batch.  2 (= 2 of the 8 wave slots and 2 x 80 VGPRs of every SIMD) leaves room for the pixel kernel of the next batch AND
+    // the sparse kernel of the previous one on the same CU: with 3 batches in flight 930 k frames/s against 790 k with 4.
+    static const int bpc_env = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 0;
+    const int bpc = bpc_env > 0 ? bpc_env : groups;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -399,12 +400,12 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     return e;
 }
 
-hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, hipStream_t s)
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s)
 {
     // imgproc.cpp:56-65: GUIDELIGHT G-R; BLUE B-R; everything else (RED, NEUTRAL) R-B.  BGR byte order.
-    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, s);
-    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, s);
-    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, s);
+    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, groups, s);
+    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, groups, s);
+    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, groups, s);
 }
 
 // binary (0 / non-zero bytes) -> padded bit plane; used when a caller hands in its own binary image

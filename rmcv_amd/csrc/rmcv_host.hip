@@ -31,6 +31,7 @@ struct rmcv_ctx {
     int geom_w = -1, geom_h = -1; // geometry the planes were zeroed for
     uint32_t k1_base = 0;         // see Bufs::strip_base
     int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
+    int pixel_groups = 4;         // RMCV_OPT_PIXEL_GROUPS
     char err[256] = {0};
     std::vector<void*> allocs;
 };
@@ -220,7 +221,7 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     // k_contours writes every frame's status word; without that stage the word is cleared here
     if (!(stages & RMCV_STAGE_CONTOURS)) HIPCHK(c, hipMemsetAsync(b.status, 0, (size_t)g.n_frames * 4, s), "memset status");
-    if (stages & RMCV_STAGE_BINARY) HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), s), "k_binary");
+    if (stages & RMCV_STAGE_BINARY) HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, s), "k_binary");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     // findContours + filter_lightblobs (+ filter_armours) as ONE per-frame kernel when the stages are asked for together;
     // the per-stage events of rmcv_batch_run_timed need per-stage launches (RMCV_FUSE_SPARSE=0: dev knob for A/B runs)
@@ -328,6 +329,10 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
     if (!c) return RMCV_ERR_BAD_ARG;
     if (option == RMCV_OPT_SPARSE_WAVES && (value == 4 || value == 8)) {
         c->sparse_waves = value;
+        return RMCV_OK;
+    }
+    if (option == RMCV_OPT_PIXEL_GROUPS && value >= 1 && value <= 8) {
+        c->pixel_groups = value;
         return RMCV_OK;
     }
     return fail(c, RMCV_ERR_BAD_ARG, "unknown option or value");

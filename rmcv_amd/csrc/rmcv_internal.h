@@ -77,7 +77,7 @@ hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const r
                         int mode, bool with_frames, bool pairs, hipStream_t s);
 hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, int waves, hipStream_t s);
 hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
-hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, hipStream_t s);
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s);
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
