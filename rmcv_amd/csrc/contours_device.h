@@ -239,6 +239,8 @@ struct ContoursLds {
     uint16_t n_a[NN_CAP], n_b[NN_CAP], n_d[NN_CAP];
     uint32_t ringtab[256];
     int nnodes, nkept, cursor, flags, nrows, nslots, nelig, lit[3];
+    int wnext;    // fused tail: next entry of the sorted work list
+    int sink[64]; // per-lane sinks: lanes != 0 add 0 here so that a wave-wide atomic stays convergent and does not serialise on one word
 };
 
 // ---- cycle formulation of the border following --------------------------------------------------------------------------
