@@ -239,6 +239,8 @@ struct ContoursLds {
     uint16_t n_a[NN_CAP], n_b[NN_CAP], n_d[NN_CAP];
     uint32_t ringtab[256];
     int nnodes, nkept, cursor, flags, nrows, nslots, nelig, lit[3];
+    uint8_t kacc[KEPT_CAP]; // cycles_frame: outer border e is (still) accepted by the RETR_EXTERNAL rule
+    int revoked;            // ... some acceptance was revoked in this round
     int wnext;    // fused tail: next entry of the sorted work list
     int sink[64]; // per-lane sinks: lanes != 0 add 0 here so that a wave-wide atomic stays convergent and does not serialise on one word
 };
@@ -543,7 +545,7 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
         __syncthreads();
     }
     CSTAMP();
-    // ---- N6: every cycle whose start visit contains the west neighbour is an outer border: allocate its output
+    // ---- N6: every cycle whose start visit contains the west neighbour is an outer border: a candidate contour
 #pragma unroll
     for (int u = 0; u < NPT; u++) {
         const int i = tid + u * T;
@@ -551,15 +553,14 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
         uint16_t ks = 0xFFFF;
         if (mn[i] == i && ((pxy[i] >> 28) & 1u)) {
             const int len = dist[succ0[u]] + 1;
-            const int off = atomicAdd(&S.cursor, len);
             const int slot = atomicAdd(&S.nkept, 1);
-            if (slot >= KEPT_CAP || slot >= max_contours || off + len > max_points) {
+            if (slot >= KEPT_CAP || slot >= max_contours) {
                 atomicOr(&S.flags, FL);
             } else {
                 const uint32_t p = pxy[i];
                 S.kkey[slot] = ((p >> 12) & 0xFFFu) << 16 | (p & 0xFFFu);
-                S.koff[slot] = off;
                 S.klen[slot] = len;
+                S.kacc[slot] = 1;
                 ks = (uint16_t)slot;
             }
         }
@@ -567,22 +568,99 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
     }
     __syncthreads();
     if (S.flags & FL) return;
-    // ---- N7: points and labels
+    // ---- N7: RETR_EXTERNAL.  OpenCV's scanner skips an outer-border start when the last labelled pixel it met on the row is
+    // positive, and only the borders it traced carry labels: a component inside a hole of a traced one is skipped.  A start's
+    // left context consists of raster-earlier borders only, so the scanner's decisions are the fixed point of "label the accepted
+    // borders, revoke every accepted start whose nearest labelled pixel to the left is positive": a revocation is always final
+    // (such a start lies inside a hole of the labelled border), an acceptance may be revoked once a wrongly accepted neighbour
+    // lost its labels.  Frames without nested components -- the usual case -- take one round.
+    const int ncand = S.nkept;
+    for (int round = 0;; round++) {
+        if (tid == 0) S.revoked = 0;
+        for (int i = tid; i < S.nslots; i += T) { S.lab[i] = 0; S.neg[i] = 0; }
+        __syncthreads();
+        for (int i = tid; i < nn; i += T) {
+            const int ks = jp[mn[i]];
+            if (ks == 0xFFFF || !S.kacc[ks]) continue; // a hole border, or a border that is not (or no longer) accepted
+            const uint32_t p = pxy[i];
+            const int x = (int)(p & 0xFFFu), y = (int)((p >> 12) & 0xFFFu);
+            const int slot = LS.slot(y, x >> 6);
+            atomicOr(&S.lab[slot], 1ull << (x & 63));
+            if ((p >> 27) & 1u) atomicOr(&S.neg[slot], 1ull << (x & 63));
+        }
+        __syncthreads();
+        for (int e = tid; e < ncand; e += T) {
+            if (!S.kacc[e]) continue;
+            const uint32_t key = S.kkey[e];
+            const int x0 = (int)(key & 0xFFFFu), y0 = (int)(key >> 16);
+            const uint32_t occ = S.rowmask[y0];
+            int k = x0 >> 6;
+            unsigned long long l = S.lab[LS.slot(y0, k)] & ((1ull << (x0 & 63)) - 1);
+            uint32_t left = occ & ((1u << k) - 1u);
+            while (!l && left) {
+                k = 31 - __clz((int)left);
+                left &= ~(1u << k);
+                l = S.lab[LS.slot(y0, k)];
+            }
+            if (l) {
+                const int top = 63 - __clzll((long long)l);
+                if (!((S.neg[LS.slot(y0, k)] >> top) & 1ull)) { // positive: inside a hole of that border
+                    S.kacc[e] = 0;
+                    S.revoked = 1;
+                }
+            }
+        }
+        __syncthreads();
+        const int again = S.revoked;
+        __syncthreads();
+        if (!again) break;
+        if (round >= 32) { // a long chain of nested siblings: the literal scanner settles it
+            if (tid == 0) S.flags |= FL;
+            __syncthreads();
+            return;
+        }
+    }
+    // ---- N8: output of the accepted borders
+    for (int e = tid; e < ncand; e += T)
+        if (S.kacc[e]) {
+            const int off = atomicAdd(&S.cursor, S.klen[e]);
+            if (off + S.klen[e] > max_points) atomicOr(&S.flags, FL);
+            S.koff[e] = off;
+        }
+    __syncthreads();
+    if (S.flags & FL) return;
     for (int i = tid; i < nn; i += T) {
         const int ks = jp[mn[i]];
-        if (ks == 0xFFFF) continue; // a hole border
+        if (ks == 0xFFFF || !S.kacc[ks]) continue;
         const uint32_t p = pxy[i];
-        const int x = (int)(p & 0xFFFu), y = (int)((p >> 12) & 0xFFFu);
         rmcv_point q;
-        q.x = x;
-        q.y = y;
+        q.x = (int)(p & 0xFFFu);
+        q.y = (int)((p >> 12) & 0xFFFu);
         const int len = S.klen[ks], pos = dist[i] ? len - dist[i] : 0;
         if (pos >= 0 && pos < len) pts[S.koff[ks] + pos] = q; // (always, for a consistent plane)
-        const int slot = LS.slot(y, x >> 6);
-        atomicOr(&S.lab[slot], 1ull << (x & 63));
-        if ((p >> 27) & 1u) atomicOr(&S.neg[slot], 1ull << (x & 63));
     }
     __syncthreads();
+    { // the kept list = the accepted candidates (order is irrelevant, the caller ranks them by key); the node tables are free
+        uint32_t* const t_key = reinterpret_cast<uint32_t*>(S.n_a);
+        int32_t* const t_off = reinterpret_cast<int32_t*>(S.n_b);
+        int32_t* const t_len = reinterpret_cast<int32_t*>(S.n_d);
+        if (tid == 0) S.nkept = 0;
+        __syncthreads();
+        for (int e = tid; e < ncand; e += T)
+            if (S.kacc[e]) {
+                const int o = atomicAdd(&S.nkept, 1);
+                t_key[o] = S.kkey[e];
+                t_off[o] = S.koff[e];
+                t_len[o] = S.klen[e];
+            }
+        __syncthreads();
+        for (int e = tid; e < S.nkept; e += T) {
+            S.kkey[e] = t_key[e];
+            S.koff[e] = t_off[e];
+            S.klen[e] = t_len[e];
+        }
+        __syncthreads();
+    }
 #ifdef RMCV_PROFILE
     CSTAMP();
     if (tid == 0 && (blockIdx.x == 100))

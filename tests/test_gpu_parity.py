@@ -337,18 +337,27 @@ def test_sparse_kernel_with_four_wavefronts(oracle):
             blobs, _ = c.blobs(f)
             assert blobs.tobytes() == ref["blobs"].tobytes(), f
             assert arm[aoffs[f]:aoffs[f + 1]].tobytes() == ref["armours"].tobytes(), f
-    # nested shapes: the literal fallback inside the 4-wavefront workgroup
-    img = np.zeros((1, 256, 256, 3), np.uint8)
+    # nested shapes (a blob inside a hole is dropped by RETR_EXTERNAL) stay on the cycle path; a 'Y' of 1-px lines (a pixel visited
+    # three times) takes the literal fallback inside the 4-wavefront workgroup
+    img = np.zeros((2, 256, 256, 3), np.uint8)
     img[0, 40:200, 40:200] = (255, 0, 0)
     img[0, 80:160, 80:160] = 0
     img[0, 100:140, 100:140] = (255, 0, 0)
+    for i in range(1, 12):
+        img[1, 60 - i, 60 - i] = img[1, 60 - i, 60 + i] = img[1, 60 + i, 60] = (255, 0, 0)
+    img[1, 60, 60] = (255, 0, 0)
     c.upload(img)
-    c.run(default_params(), STAGE_ALL)
+    p_none = default_params()
+    p_none.morph = MORPH_NONE
+    c.run(p_none, STAGE_ALL)
     c.sync()
-    ref = oracle.detect_frame(img[0], oracle.default_params())
-    pts, offs = c.contours(0)
-    assert np.array_equal(offs, ref["offs"]) and np.array_equal(pts, ref["pts"])
-    assert c.counts()["status"][0] & 16
+    for f in range(2):
+        rb = oracle.extract_binary(img[f], CAMP_BLUE, 80, MORPH_NONE)
+        rp, ro = oracle.find_contours(rb)
+        pts, offs = c.contours(f)
+        assert np.array_equal(offs, ro) and np.array_equal(pts, rp), f
+    st = c.counts()["status"]
+    assert st[0] == 0 and (st[1] & 16) and len(c.contours(0)[1]) - 1 == 1
     c.close()
 
 
@@ -470,4 +479,33 @@ def test_cycle_formulation_paths(oracle):
     e[::3, ::3] = 255                                      # 10 000 isolated pixels again, but > SLOT capacity as well
     st, n, _ = run(e)
     assert n == 10000
+    c.close()
+
+
+def test_nested_components_on_the_cycle_path(oracle):
+    """RETR_EXTERNAL drops every component that lies in a hole of a traced one.  The cycle path settles this by a fixed-point
+    iteration on the labels (siblings inside one hole need a second round, chains of them more); results equal the oracle and the
+    frames do not fall back to the literal scanner (status 0)"""
+    from rmcv_amd import Context
+    c = Context(device=0, max_frames=1, max_width=512, max_height=512)
+    a = np.zeros((200, 260), np.uint8)                      # (about 3000 border visits: below the 4096 the cycle path holds)
+    a[10:190, 10:250] = 255
+    a[25:175, 25:235] = 0                                   # a big ring ...
+    for k in range(5):
+        a[35:55, 35 + 40 * k:55 + 40 * k] = 255             # ... five siblings in a row inside its hole (each sees its left neighbour's labels)
+    a[80:160, 50:200] = 255
+    a[95:145, 65:185] = 0                                   # a ring inside the hole ...
+    a[110:130, 80:100] = 255                                # ... with something inside ITS hole (depth 3)
+    a[2:7, 5:250:27] = 255                                  # top-level specks above the ring
+    a[193:198, 10:60] = 255                                 # and a top-level bar below
+    n, npts = _check_contours(c, a, oracle)
+    assert int(c.counts()["status"][0]) == 0
+    assert n == len(range(5, 250, 27)) + 2                  # the specks, the big ring, the bar: nothing from inside
+    # a U-shaped cavity is not a hole: the blob in it is kept
+    b = np.zeros((200, 200), np.uint8)
+    b[20:180, 20:180] = 255
+    b[20:150, 50:150] = 0
+    b[60:100, 80:120] = 255
+    n, _ = _check_contours(c, b, oracle)
+    assert int(c.counts()["status"][0]) == 0 and n == 2
     c.close()
