@@ -509,3 +509,25 @@ def test_nested_components_on_the_cycle_path(oracle):
     n, _ = _check_contours(c, b, oracle)
     assert int(c.counts()["status"][0]) == 0 and n == 2
     c.close()
+
+
+def test_contours_fuzz_random_scenes(oracle):
+    """300 random compositions of bars, discs, rings, elliptic rings, thin lines, salt and pepper (tools/fuzz_contours.py): nested
+    and touching shapes of every kind; contours equal the oracle, and most scenes stay on the cycle path"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_contours", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                             "tools", "fuzz_contours.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from rmcv_amd import Context
+    rng = np.random.default_rng(2024)
+    c = Context(device=0, max_frames=1, max_width=512, max_height=512, max_contours=8192, max_points=1 << 17)
+    fast = 0
+    for t in range(300):
+        h, w = int(rng.integers(8, 300)), int(rng.integers(8, 400))
+        canvas = fz.random_scene(rng, h, w)
+        _check_contours(c, canvas, oracle)
+        fast += int(c.counts()["status"][0]) == 0
+    assert fast > 200
+    c.close()
