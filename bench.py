@@ -120,6 +120,7 @@ def main():
     cap = n * 16
     head, _ = rdist.record_layout(n, cap)
     recs_buf = [rdist.new_record(n, cap, dev) for _ in range(ns)]
+    gather_out = [rdist.new_gather_list(r) if use_dist else None for r in recs_buf]   # rank 0's receive buffers, one set per stream
     # one stream per batch in flight (priorities alternate; with GPU_MAX_HW_QUEUES = 6 every stream has its own hardware queue, which is
     # what lets kernels of two steps actually run concurrently
     prios = [int(x) for x in os.environ.get("RMCV_BENCH_PRIOS", "").split(",") if x] or [0, -1]
@@ -145,7 +146,7 @@ def main():
             with torch.cuda.stream(streams[k]):
                 run_path(ctxs[k], cur_stages[0], streams[k].cuda_stream)
                 ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
-                return rdist.gather_records(recs_buf[k]) if use_dist else [recs_buf[k]]
+                return rdist.gather_records(recs_buf[k], out=gather_out[k]) if use_dist else [recs_buf[k]]
         with torch.cuda.stream(sA):
             if not first_use:
                 sA.wait_event(ev_done[k])
@@ -156,7 +157,7 @@ def main():
             sB.wait_event(ev_bin[k])
             run_path(ctxs[k], sparse_stages, sB.cuda_stream)
             ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), sB.cuda_stream)
-            out = rdist.gather_records(recs_buf[k]) if use_dist else [recs_buf[k]]
+            out = rdist.gather_records(recs_buf[k], out=gather_out[k]) if use_dist else [recs_buf[k]]
             ev_done[k].record(sB)
             return out
 

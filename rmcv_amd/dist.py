@@ -48,12 +48,19 @@ def fill_record(rec, n_local, cap, frame_offs, armours_u8):
     return rec
 
 
-def gather_records(rec, group=None, dst=0):
-    """the one collective of the path; returns the list of records on dst, None elsewhere"""
+def new_gather_list(rec, group=None, dst=0):
+    """receive buffers for gather_records on dst (None elsewhere), to be allocated once and reused every step"""
+    if not dist.is_initialized():
+        return None
+    return [torch.empty_like(rec) for _ in range(dist.get_world_size(group))] if dist.get_rank(group) == dst else None
+
+
+def gather_records(rec, group=None, dst=0, out=None):
+    """the one collective of the path; returns the list of records on dst, None elsewhere.  `out`: a list from new_gather_list"""
     if not dist.is_initialized():
         return [rec]
     rank = dist.get_rank(group)
-    recs = [torch.empty_like(rec) for _ in range(dist.get_world_size(group))] if rank == dst else None
+    recs = (out if out is not None else [torch.empty_like(rec) for _ in range(dist.get_world_size(group))]) if rank == dst else None
     dist.gather(rec, recs, dst=dst, group=group)
     return recs
 
