@@ -218,8 +218,8 @@ struct LabelStore {
 // Frames beyond a capacity take the literal path (tests/test_gpu_parity.py covers each limit).
 static constexpr int KEPT_CAP = 512;
 static constexpr int SLOT_CAP = 1024;  // non-empty words of a frame the LDS label store can hold
-// Workgroup size is a template parameter: 8 wavefronts walk and fit the bars of a frame concurrently (lowest latency for one
-// batch), 4 wavefronts leave room on every CU for the pixel kernels of the next batches AND the sparse kernel of the previous
+// Workgroup size is a build parameter (k_contours_kernel.inc): 8 wavefronts build the borders and fit the bars of a frame (lowest
+// latency for one batch), 4 wavefronts leave room on every CU for the pixel kernels of the next batches AND the sparse kernel of the previous
 // one (VGPR budget per SIMD: 2 x 160 for this kernel at 8 wavefronts, 2 x 80 per pixel kernel, 512 in all) -- the better choice
 // when several batches are in flight (886 k against 800 k frames/s with three batches; 0.57 against 0.475 ms for a lone batch).
 static constexpr int CT_THREADS_MAX = 512;
@@ -321,7 +321,8 @@ __device__ __forceinline__ uint32_t ring_of(int b, uint64_t ul, uint64_t uc, uin
 }
 
 // findContours of one frame by the whole workgroup (T threads); on return S.kkey/koff/klen/nkept/cursor describe the kept contours
-// exactly as the walk-based S phase leaves them, the points are written and the labels are in the LDS label store.
+// (in any order; the caller ranks them by key), the points are written and the labels of the accepted borders are in the LDS
+// label store.
 // FL (= FL_COMPLEX) is OR-ed into S.flags when a capacity is exceeded or a pixel is visited three times.
 template <int T>
 __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int prow, int h, int ww, int nrows, int tid,
