@@ -7,7 +7,7 @@
 // Bit-exactness contract: double/float IEEE arithmetic in a FIXED operation order -- sequential
 // accumulation over the contour points in contour order, no FMA contraction (-ffp-contract=off),
 // correctly rounded div/sqrt, transcendentals from pinned_math.h.  Integer-valued sums (area) could be
-// reduced in any order; the scaled moment sums cannot, so one lane walks one contour.
+// reduced in any order; the scaled moment sums cannot: each is a sequential chain in contour order (one lane per chain, wave_detect.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
