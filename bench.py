@@ -117,7 +117,7 @@ def main():
             c.run_legacy(legacy, params, st, hs)
         else:
             c.run(params, st, hs)
-    cap = n * 16
+    cap = n * 8                                                   # armours per rank in the gather record (the synthetic stream has ~3 per frame)
     head, _ = rdist.record_layout(n, cap)
     recs_buf = [rdist.new_record(n, cap, dev) for _ in range(ns)]
     gather_out = [rdist.new_gather_list(r) if use_dist else None for r in recs_buf]   # rank 0's receive buffers, one set per stream
