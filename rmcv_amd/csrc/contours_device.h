@@ -223,6 +223,7 @@ static constexpr int SLOT_CAP = 1024;  // non-empty words of a frame the LDS lab
 // one (VGPR budget per SIMD: 2 x 160 for this kernel at 8 wavefronts, 2 x 80 per pixel kernel, 512 in all) -- the better choice
 // when several batches are in flight (886 k against 800 k frames/s with three batches; 0.57 against 0.475 ms for a lone batch).
 static constexpr int CT_THREADS_MAX = 512;
+static constexpr int MULTI_CAP = 32;    // pixels of a frame visited 3 or 4 times (junctions of 1-pixel lines) the cycle formulation lists
 static constexpr int NN_CAP = VISIT_CAP;    // border visits (nodes) of a frame the cycle formulation holds in LDS
 static constexpr int CT_MAXH = 2048;   // rows covered by the LDS row tables (taller/wider frames take the literal path)
 
@@ -239,6 +240,8 @@ struct ContoursLds {
     uint16_t n_a[NN_CAP], n_b[NN_CAP], n_d[NN_CAP];
     uint32_t ringtab[256];
     int nnodes, nkept, cursor, flags, nrows, nslots, nelig, lit[3];
+    uint32_t multi[MULTI_CAP]; // cycles_frame: pixels the border visits 3 or 4 times: slot:16 | bit:6 << 16 | count << 24
+    int nmulti;
     uint8_t kacc[KEPT_CAP]; // cycles_frame: outer border e is (still) accepted by the RETR_EXTERNAL rule
     int revoked;            // ... some acceptance was revoked in this round
     int wnext;    // fused tail: next entry of the sorted work list
@@ -320,6 +323,23 @@ __device__ __forceinline__ uint32_t ring_of(int b, uint64_t ul, uint64_t uc, uin
            (((d >> 1) & 1u) << 6) | (((d >> 2) & 1u) << 7);
 }
 
+// nodes beyond two of the listed 3-/4-visit pixels of `slot` below bit position `bit` (64: the whole word), and the count of the
+// pixel at `bit` itself (0 if it is not listed)
+__device__ __forceinline__ int multi_extra(const ContoursLds& S, int slot, int bit, int* own)
+{
+    int extra = 0;
+    *own = 0;
+    const int nm = S.nmulti < MULTI_CAP ? S.nmulti : MULTI_CAP;
+    for (int m = 0; m < nm; m++) {
+        const uint32_t e = S.multi[m];
+        if ((int)(e & 0xFFFFu) != slot) continue;
+        const int b = (int)((e >> 16) & 63u), c = (int)(e >> 24);
+        if (b < bit) extra += c - 2;
+        else if (b == bit) *own = c;
+    }
+    return extra;
+}
+
 // findContours of one frame by the whole workgroup (T threads); on return S.kkey/koff/klen/nkept/cursor describe the kept contours
 // (in any order; the caller ranks them by key), the points are written and the labels of the accepted borders are in the LDS
 // label store.
@@ -341,7 +361,7 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
 #endif
     CSTAMP();
     for (int i = tid; i < 256; i += T) S.ringtab[i] = RINGTAB.v[i];
-    if (tid == 0) S.nnodes = 0;
+    if (tid == 0) { S.nnodes = 0; S.nmulti = 0; }
     __syncthreads();
     CSTAMP();
     // slot -> (row, word): y | k << 11
@@ -368,16 +388,22 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
         const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
         const uint64_t left = (mc << 1) | (ml >> 63), right = (mc >> 1) | (mr << 63);
         uint64_t B = mc & ~(uc & dc & left & right), E2 = 0, rem = B;
+        int extra = 0;
         while (rem) {
             const int b = __ffsll((long long)rem) - 1;
             rem &= rem - 1;
             const uint32_t cnt = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)] & 7u;
-            if (cnt == 2) E2 |= 1ull << b;
-            else if (cnt != 1) atomicOr(&S.flags, FL);
+            if (cnt >= 2) E2 |= 1ull << b;
+            if (cnt >= 3) { // a junction of 1-pixel lines: listed on the side
+                const int m = atomicAdd(&S.nmulti, 1);
+                if (m < MULTI_CAP) S.multi[m] = (uint32_t)slot | ((uint32_t)b << 16) | (cnt << 24);
+                else atomicOr(&S.flags, FL);
+                extra += (int)cnt - 2;
+            }
         }
         S.bmask[slot] = B;
         S.e2mask[slot] = E2;
-        S.nbase[slot] = (uint16_t)(__popcll(B) + __popcll(E2));
+        S.nbase[slot] = (uint16_t)(__popcll(B) + __popcll(E2) + extra);
     }
     __syncthreads();
     { // exclusive prefix of the node counts over the slots (raster order): node ids ascend in raster order
@@ -431,7 +457,7 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
             const uint32_t e = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)];
             const int cnt = (int)(e & 7u);
             const uint32_t xy = (uint32_t)(k * 64 + b) | ((uint32_t)y << 12);
-            for (int a = 0; a < cnt && a < 2; a++) {
+            for (int a = 0; a < cnt && a < 4; a++) {
                 const uint32_t back = (e >> (3 + 3 * a)) & 7u, nextd = (e >> (15 + 3 * a)) & 7u, ng = (e >> (28 + a)) & 1u;
                 const uint32_t west = a == 0 ? (e >> 27) & 1u : 0u;
                 if (id < NN_CAP) pxy[id] = xy | (back << 24) | (ng << 27) | (west << 28) | (nextd << 29);
@@ -456,10 +482,17 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
         }
         if (ok) {
             const uint64_t below = (1ull << bs) - 1;
-            const int id0 = S.nbase[slot2] + __popcll(S.bmask[slot2] & below) + __popcll(S.e2mask[slot2] & below);
-            const int two = (int)((S.e2mask[slot2] >> bs) & 1ull);
+            int id0 = S.nbase[slot2] + __popcll(S.bmask[slot2] & below) + __popcll(S.e2mask[slot2] & below);
+            int cnt2 = 1 + (int)((S.e2mask[slot2] >> bs) & 1ull);
+            if (S.nmulti) {
+                int own;
+                id0 += multi_extra(S, slot2, bs, &own);
+                if (own) cnt2 = own;
+            }
             const uint32_t back2 = (uint32_t)((nd + 4) & 7);
-            succ = id0 + ((two && ((pxy[id0] >> 24) & 7u) != back2) ? 1 : 0);
+            succ = id0; // the visit of the successor pixel whose back direction points here
+            for (int a = 1; a < cnt2; a++)
+                if (((pxy[id0 + a] >> 24) & 7u) == back2) succ = id0 + a;
         }
         // an isolated pixel has no foreground neighbour at all: its "next" leads to background -> it stays (ok == false, succ == i);
         // for any other node a missing successor would contradict the bijection: flagged

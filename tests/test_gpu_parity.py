@@ -337,15 +337,14 @@ def test_sparse_kernel_with_four_wavefronts(oracle):
             blobs, _ = c.blobs(f)
             assert blobs.tobytes() == ref["blobs"].tobytes(), f
             assert arm[aoffs[f]:aoffs[f + 1]].tobytes() == ref["armours"].tobytes(), f
-    # nested shapes (a blob inside a hole is dropped by RETR_EXTERNAL) stay on the cycle path; a 'Y' of 1-px lines (a pixel visited
-    # three times) takes the literal fallback inside the 4-wavefront workgroup
+    # nested shapes (a blob inside a hole is dropped by RETR_EXTERNAL) stay on the cycle path; 23 1-px lines of 100 pixels (more
+    # than 4096 border visits) take the literal fallback inside the 4-wavefront workgroup
     img = np.zeros((2, 256, 256, 3), np.uint8)
     img[0, 40:200, 40:200] = (255, 0, 0)
     img[0, 80:160, 80:160] = 0
     img[0, 100:140, 100:140] = (255, 0, 0)
-    for i in range(1, 12):
-        img[1, 60 - i, 60 - i] = img[1, 60 - i, 60 + i] = img[1, 60 + i, 60] = (255, 0, 0)
-    img[1, 60, 60] = (255, 0, 0)
+    for r in range(23):
+        img[1, 4 + 3 * r, 10:110] = (255, 0, 0)
     c.upload(img)
     p_none = default_params()
     p_none.morph = MORPH_NONE
@@ -436,8 +435,7 @@ def test_c5_geometry_every_frame(oracle):
 
 
 def test_cycle_formulation_paths(oracle):
-    """which path findContours takes: thin lines / diagonals / spurs (pixels visited twice) stay on the cycle path (status 0), a
-    pixel visited three times (the centre of a 'Y' of 1-px lines) or a frame with more than 4096 border visits goes to the
+    """which path findContours takes: thin lines / diagonals / spurs (pixels visited twice or -- up to 32 per frame -- three times) stay on the cycle path (status 0); more such junctions or a frame with more than 4096 border visits goes to the
     literal scanner (status bit 16); the results are equal either way"""
     from rmcv_amd import Context
     c = Context(device=0, max_frames=1, max_width=512, max_height=512, max_contours=16384, max_points=1 << 17)
@@ -464,9 +462,17 @@ def test_cycle_formulation_paths(oracle):
     b = np.zeros((64, 64), np.uint8)
     for i in range(1, 12):
         b[30 - i, 30 - i] = b[30 - i, 30 + i] = b[30 + i, 30] = 255
-    b[30, 30] = 255                                       # 'Y' of 1-px lines: the centre is visited three times
+    b[30, 30] = 255                                       # 'Y' of 1-px lines: the centre is visited three times (side table)
     st, n, _ = run(b)
-    assert st & 16 and n == 1
+    assert st == 0 and n == 1
+    b = np.zeros((200, 400), np.uint8)
+    for j in range(40):                                    # 40 such junctions: more than the side table lists -> literal scanner
+        cx, cy = 10 + 9 * j, 100
+        for i in range(1, 4):
+            b[cy - i, cx - i] = b[cy - i, cx + i] = b[cy + i, cx] = 255
+        b[cy, cx] = 255
+    st, n, _ = run(b)
+    assert st & 16 and n == 40
     d = np.zeros((300, 300), np.uint8)
     for r in range(22):
         d[4 + 3 * r, 10:110] = 255                         # 22 lines of 100 pixels = 22 x 198 = 4356 visits: more than 4096
