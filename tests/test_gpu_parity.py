@@ -537,3 +537,18 @@ def test_contours_fuzz_random_scenes(oracle):
         fast += int(c.counts()["status"][0]) == 0
     assert fast > 200
     c.close()
+
+
+@pytest.mark.parametrize("loose", [0, 1])
+def test_full_path_fuzz_random_scenes(oracle, loose):
+    """320 random scenes (tools/fuzz_path.py) through the whole path, default gates and every gate wide open (each contour with
+    >= 6 points fitted -- discs, rings, lines, blobs of noise -- and nearly every pair of blobs built into an armour)"""
+    import importlib.util
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys.path.insert(0, tools)
+    spec = importlib.util.spec_from_file_location("fuzz_path", os.path.join(tools, "fuzz_path.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.main(10, 100 + loose, loose) == 0
