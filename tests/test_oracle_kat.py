@@ -233,6 +233,26 @@ def test_golden_vectors():
         assert got == rec["armour_vertices_hex"]
 
 
+def test_golden_vectors_next_rows():
+    """identities, legacy light blobs and poses of the SURVEY 8f rows on the frozen frames (tests/golden/make_golden.py)"""
+    import numpy as np
+    g = json.load(open(os.path.join(GOLD, "synthetic_next_rows.json")))
+    from rmcv_amd import synth
+    svm = synth.svm_weights()
+    for rec in g["frames"]:
+        f = synth.frame(rec["index"], g["width"], g["height"], g["camp"], rec["variant"])
+        r = O.detect_frame(f)
+        ident, _, icons = O.classify_armours(f, r["armours"], svm)
+        assert [int(v) for v in ident] == rec["identities"]
+        assert [int(ic.astype(np.int64).sum()) for ic in icons] == rec["icon_sums"]
+        lb, src, boxes = O.find_lightblobs(f, r["pts"], r["offs"], 1.5, 80, 70, 10, 99999, False)
+        assert [int(v) for v in src] == rec["legacy_src"] and [int(b["target"]) for b in lb] == rec["legacy_targets"]
+        assert [[float.hex(float(b[k])) for k in ("cx", "cy", "w", "h", "angle")] for b in boxes] == rec["legacy_boxes_hex"]
+        rv, tv, pos = O.locate_armours(r["armours"])
+        assert [[float.hex(float(v)) for v in t] for t in tv] == rec["tvec_hex"]
+        assert [[float.hex(float(v)) for v in q] for q in pos] == rec["position_hex"]
+
+
 def test_libm_mode_agrees_on_vertices():
     """oracle with the host libm (what the reference links) vs oracle with pinned_math.h (the GPU contract):
     the armour vertex lists must be identical on the test stream"""
