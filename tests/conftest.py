@@ -8,7 +8,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+def _build_if_missing():
+    """a fresh checkout has no librmcv_hip.so (build products are not in git): build it, as __graft_entry__.build() does"""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "rmcv_amd", "lib", "librmcv_hip.so")):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "rmcv_amd", "csrc"), "-j", str(min(8, os.cpu_count() or 1))], check=True)
+
+
 def pytest_sessionstart(session):
+    _build_if_missing()
     """torch bundles its own HIP runtime; when librmcv_hip.so (system ROCm) initialises the GPU first, a later
     torch.cuda initialisation in the same process reports "No HIP GPUs".  Tests that hand torch tensors to the
     library need both, so torch gets the device first (as bench.py does by construction)."""
