@@ -37,11 +37,15 @@ WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200),   # BASELINE.json configs[2
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="the timed region (exactly --steps steps between two barriers) is repeated this many times; value = median")
+    ap.add_argument("--warmup-seconds", type=float, default=0.4,
+                    help="besides --warmup steps: untimed steps for at least this long, so the clocks have ramped before the timed region")
     ap.add_argument("--frames", type=int, default=FRAMES, help="frames per GPU per step")
     ap.add_argument("--variant", type=int, default=0, help="0 plain stream, 1 stress stream")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames per pass of the CPU-baseline sample (0 = skip)")
@@ -56,7 +60,69 @@ def main():
     ap.add_argument("--mode", choices=("pipeline", "alternate"), default="alternate",
                     help="alternate (default): whole steps on streams of alternating priority; pipeline: all pixel kernels on "
                          "one stream, the sparse stages on higher-priority streams, chained by events (measured 5-10 % slower)")
-    args = ap.parse_args()
+    ap.add_argument("--gather", choices=("torch", "abi"), default="torch",
+                    help="the armour-list gather of a launched run: torch.distributed.gather (default) or rmcv_gather, the C-ABI "
+                         "entry point that calls RCCL itself (what a C++ host uses)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, script=None, timeout=None, extra_env=None):
+    """`python bench.py --gpus N` run directly (no WORLD_SIZE in the environment): start the N ranks as fresh child processes --
+    the command the driver itself uses for N > 1 -- and relay rank 0's JSON line.  The parent never touches the GPU (no HIP
+    call, no librmcv_hip load), so the children are ordinary first users of their devices.  Returns (exit code, last stdout
+    line that parses as JSON or None)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.update(extra_env or {})
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=timeout)
+    line = None
+    for ln in p.stdout.decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                json.loads(ln)
+                line = ln
+            except ValueError:
+                pass
+    return p.returncode, line
+
+
+def resolve_world(args, environ):
+    """(world, rank, local_rank, launched) from the environment torch.distributed.run sets; --gpus must agree with it.
+    Raises SystemExit when they differ: `--gpus N` never runs on another number of GPUs than it reports."""
+    launched = "RANK" in environ and "WORLD_SIZE" in environ
+    world = int(environ.get("WORLD_SIZE", "1")) if launched else 1
+    if launched and args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    return world, int(environ.get("RANK", "0")) if launched else 0, int(environ.get("LOCAL_RANK", "0")) if launched else 0, launched
+
+
+def main():
+    args = parse_args()
+    world, rank, local_rank, launched = resolve_world(args, os.environ)
+    if args.gpus > 1 and not launched:
+        import torch                                             # device_count() does not initialise the GPU
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have))
+        rc, line = launch_ranks(args.gpus, sys.argv[1:])
+        if line:
+            print(line, flush=True)
+        if rc == 0 and (not line or json.loads(line).get("n_gpus") != args.gpus):
+            raise SystemExit("bench.py: the %d ranks did not report n_gpus=%d" % (args.gpus, args.gpus))
+        raise SystemExit(rc)
 
     W, H = WORKLOADS[args.workload]
     BYTES_PER_FRAME = 4 * W * H      # SURVEY 8(d): 3 B/px BGR read + 1 B/px binary written
@@ -67,16 +133,11 @@ def main():
                           STAGE_IDENTITY, STAGE_NO_IMAGE, STAGE_POSE, OPT_PIXEL_GROUPS, OPT_SPARSE_WAVES, Context, LegacyParams, default_params, synth)
     from rmcv_amd import dist as rdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the detection path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    use_dist = launched                                           # started by torch.distributed.run (by the driver or by launch_ranks)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -170,18 +231,37 @@ def main():
         for k in range(ns):
             ctxs[k].run(params, STAGE_ALL, streams[k].cuda_stream)
         torch.cuda.synchronize()
+    def agree_max(x):
+        """the same number on every rank (MAX): ranks must take the same decisions, a step contains a collective"""
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         recs = step()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        recs = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # warm-up by time as well: a GPU that idled while the frames were generated has to ramp its clocks; 5 steps are 1.5 ms
+    # (round 1: the driver's 20-step run read 822 k frames/s where 100-step runs read 905-950 k)
+    tw, warm_steps = time.perf_counter(), 0
+    while agree_max(time.perf_counter() - tw) < args.warmup_seconds:
+        for _ in range(max(1, args.steps)):
+            recs = step()
+        warm_steps += max(1, args.steps)
+        barrier()
+    # the timed region: EXACTLY --steps steps between two (barrier + synchronize), MAX over ranks; repeated --repeats times,
+    # value = the median repeat (SURVEY 8d: median and min over the passes)
+    rep_dt = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            recs = step()
+        barrier()
+        rep_dt.append(agree_max(time.perf_counter() - t0))
+    srt = sorted(rep_dt)
+    dt = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     ms_per_step = dt / args.steps * 1e3
     value = world * n * args.steps / dt
 
@@ -268,6 +348,10 @@ def main():
     out = {
         "metric": "frames/sec (%dx%d BGR) armour detect" % (W, H), "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "timed_region": {"repeats": len(rep_dt), "ms_per_step_each": [round(d / args.steps * 1e3, 4) for d in rep_dt],
+                         "ms_per_step_median": round(ms_per_step, 4), "ms_per_step_min": round(srt[0] / args.steps * 1e3, 4),
+                         "value_at_min": round(world * n * args.steps / srt[0], 1), "warmup_steps_by_time": warm_steps,
+                         "note": "each repeat = exactly `steps` steps between barrier+synchronize pairs; value/ms_per_step = the median repeat"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%s: batch=%d/GPU %dx%d BGR, blue lb=80, close3x3 + findContours + lightblob fit + armour "
                                "pairing%s%s" % (args.workload.upper(), n, W, H,
@@ -277,7 +361,8 @@ def main():
                                                 " + RCCL gather of armour lists (C4)" if world > 1 else ""),
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
                    "double_buffered_steps": ns, "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "pixel_groups_per_cu": 2 if ns >= 2 else 4, "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
-                   "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad},
+                   "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad,
+                   "rccl_ranks": (dist.get_world_size() if use_dist else None), "gather": (args.gather if use_dist else None)},
         "lone_batch_ms": {"median": round(lone[len(lone) // 2], 4), "min": round(lone[0], 4), "passes": len(lone),
                           "note": "one batch at a time on one stream, events around detect + compaction (latency, not the metric)"},
         "path_hbm_frac": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),

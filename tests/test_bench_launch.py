@@ -1,0 +1,67 @@
+"""`python bench.py --gpus N` must itself start N ranks (or fail loudly) -- never run one GPU and call it N.
+CPU tests of the launcher: world 2, gloo, the oracle standing in for the per-rank detector."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_resolve_world_refuses_a_mismatch():
+    a = types.SimpleNamespace(gpus=8)
+    assert bench.resolve_world(a, {}) == (1, 0, 0, False)            # plain invocation: main() goes on to launch_ranks
+    with pytest.raises(SystemExit) as e:
+        bench.resolve_world(a, {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    assert "WORLD_SIZE=2" in str(e.value)
+    with pytest.raises(SystemExit):                                   # and the other way round: launched as 2, asked for 1
+        bench.resolve_world(types.SimpleNamespace(gpus=1), {"RANK": "1", "WORLD_SIZE": "2", "LOCAL_RANK": "1"})
+    assert bench.resolve_world(types.SimpleNamespace(gpus=2), {"RANK": "1", "WORLD_SIZE": "2", "LOCAL_RANK": "1"}) == (2, 1, 1, True)
+
+
+def test_plain_gpus_n_without_n_gpus_fails_loudly():
+    """this container has no GPU: `bench.py --gpus 2` must exit non-zero and say why (round 1 ran one GPU and printed n_gpus 1)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU box: the launch would really happen")
+    assert p.returncode != 0
+    assert b"--gpus 2 but only" in p.stderr and b"n_gpus" not in p.stdout
+
+
+def test_launch_ranks_world2_equals_single_process():
+    """the launcher starts 2 ranks; the list gathered through the bench's record path equals the concatenation of the
+    single-process lists of the two shards, byte for byte (the property C4 needs at 8 x 256 frames)"""
+    import oracle_lib as O
+    from rmcv_amd import synth
+    O.set_math_mode(0)
+    frames = 3
+    rc, line = bench.launch_ranks(2, ["--gpus", "2", "--frames", str(frames)], script=os.path.join(HERE, "_bench_stub_worker.py"),
+                                  timeout=600)
+    assert rc == 0 and line
+    out = json.loads(line)
+    assert out["n_gpus"] == 2
+    arms, offs = [], [0]
+    for i in range(2 * frames):
+        a = O.detect_frame(synth.frame(i, 640, 512))["armours"]
+        arms.append(a)
+        offs.append(offs[-1] + len(a))
+    whole = np.concatenate(arms).view(np.uint8)
+    assert out["armours_gathered"] == offs[-1] > 0
+    assert out["frame_offs"] == offs
+    assert out["sha256"] == hashlib.sha256(whole.tobytes()).hexdigest()
+
+
+def test_launch_ranks_reports_a_failing_rank():
+    rc, line = bench.launch_ranks(2, ["--gpus", "3"], script=os.path.join(HERE, "_bench_stub_worker.py"), timeout=600)
+    assert rc != 0 and line is None
