@@ -129,6 +129,12 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
 /* RMCV_OPT_PIXEL_GROUPS: persistent workgroups per CU of the pixel kernel, 1..8 -- 4 (default): fastest for a lone batch; 2: leaves
  * wave slots and registers on every CU to the kernels of the other batches in flight.  Results are identical. */
 #define RMCV_OPT_PIXEL_GROUPS 2
+/* RMCV_OPT_FRAME_UPLOAD: how rmcv_extract_color brings the caller's host frame to the device -- 1 (default): through the
+ * context's pinned staging buffer; 0: the HIP runtime's pageable copy; 2: the caller's buffer is pinned in place on first sight
+ * (hipHostRegister, kept for the context's lifetime, at most 16 buffers) and read by DMA with no CPU copy -- for camera SDKs that
+ * hand out a fixed ring of frame buffers (the reference's cameras do, hardware/src/daheng.cpp:83); the buffers must stay mapped
+ * while the context lives.  Results are identical. */
+#define RMCV_OPT_FRAME_UPLOAD 3
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 
 /* ---- single frame, host buffers: one call per reference function ---------------------- */

@@ -719,37 +719,113 @@ static void jacobi_sym(double* A, int k, double* lam, double* V)
     for (int i = 0; i < k; i++) lam[i] = A[i * k + i];
 }
 
-/* least squares through normal equations G x = g, G = A^T A: pseudo-inverse by Jacobi;
- * wmax/wmin receive the extreme singular values of A (sqrt of G's eigenvalues). */
-static void normal_solve(const double* G, const double* g, int k, double* x, double* wmax, double* wmin)
+/* Least squares min |A x - b| for an n x k design matrix (k <= 5) that is never stored: rows are produced on demand.
+ * BUILD-DEFINED (see jacobi_sym): OpenCV runs a Jacobi SVD on the n x k matrix; here
+ *   1. G = A^T A and g = A^T b by sequential sums in point order (the caller), x0 = pinv(G) g through the Jacobi
+ *      eigen-decomposition G = V diag(lam) V^T  (normal_factor / normal_apply);
+ *   2. two steps of iterative refinement  x += pinv(G) A^T (b - A x)  with the residual taken from the rows themselves.
+ * Step 1 alone squares the condition number: on thin bars (aspect > 30, exactly the contours that reach this fallback, and
+ * rm::filter_lightblobs admits ratios up to 80) cond(A) is 1e4..1e6 and x0 is good to 1e-8..1e-5 only, which moved one
+ * float32 output in fifty by an ulp against an SVD solve.  Every refinement step multiplies the error by cond^2 * eps, so
+ * two steps land on the accuracy of a backward-stable solver (1e-12..1e-16, tests/test_oracle_general_fit_svd.py compares
+ * with LAPACK's SVD least squares).  The refinement sums are order dependent and defined wave-shaped, the way the device
+ * computes them: 64 partial sums over the points i = l, l + 64, ... in increasing i, reduced by a butterfly (strides
+ * 32, 16, 8, 4, 2, 1; v[l] += v[l ^ stride]). */
+typedef struct { int k; double lam[5], V[25], w[5], thr, wmax, wmin; } normal_fac;
+
+static void normal_factor(const double* G, int k, normal_fac* F)
 {
-    double A[25], lam[5], V[25], w[5];
+    double A[25];
     memcpy(A, G, sizeof(double) * k * k);
-    jacobi_sym(A, k, lam, V);
+    F->k = k;
+    jacobi_sym(A, k, F->lam, F->V);
     double wsum = 0, mx = 0, mn = 0;
     for (int i = 0; i < k; i++) {
-        w[i] = lam[i] > 0 ? sqrt(lam[i]) : 0.0;
-        wsum += w[i];
-        if (i == 0 || w[i] > mx) mx = w[i];
-        if (i == 0 || w[i] < mn) mn = w[i];
+        F->w[i] = F->lam[i] > 0 ? sqrt(F->lam[i]) : 0.0;
+        wsum += F->w[i];
+        if (i == 0 || F->w[i] > mx) mx = F->w[i];
+        if (i == 0 || F->w[i] < mn) mn = F->w[i];
     }
-    double thr = 2.0 * DBL_EPSILON * wsum; /* [OCV] SVBackSubst threshold */
+    F->thr = 2.0 * DBL_EPSILON * wsum; /* [OCV] SVBackSubst threshold */
+    F->wmax = mx; /* extreme singular values of A (sqrt of G's eigenvalues) */
+    F->wmin = mn;
+}
+
+static void normal_apply(const normal_fac* F, const double* g, double* x)
+{
+    const int k = F->k;
     for (int i = 0; i < k; i++) x[i] = 0.0;
     for (int c = 0; c < k; c++) {
-        if (!(w[c] > thr)) continue;
+        if (!(F->w[c] > F->thr)) continue;
         double dot = 0.0;
-        for (int r = 0; r < k; r++) dot += V[r * k + c] * g[r];
-        dot = dot / lam[c];
-        for (int r = 0; r < k; r++) x[r] += dot * V[r * k + c];
+        for (int r = 0; r < k; r++) dot += F->V[r * k + c] * g[r];
+        dot = dot / F->lam[c];
+        for (int r = 0; r < k; r++) x[r] += dot * F->V[r * k + c];
     }
-    if (wmax) *wmax = mx;
-    if (wmin) *wmin = mn;
+}
+
+static double butterfly64(double v[64])
+{
+    for (int d = 32; d >= 1; d >>= 1) {
+        double t[64];
+        for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ d];
+        memcpy(v, t, sizeof(t));
+    }
+    return v[0];
+}
+
+typedef void (*row_fn)(const void* ctx, int i, double* row);
+#define NORMAL_REFINE_STEPS 2
+static void normal_refine(const normal_fac* F, row_fn make_row, const void* ctx, int n, double bconst, double* x)
+{
+    const int k = F->k;
+    for (int step = 0; step < NORMAL_REFINE_STEPS; step++) {
+        double part[5][64];
+        memset(part, 0, sizeof(part));
+        for (int l = 0; l < 64; l++)
+            for (int i = l; i < n; i += 64) {
+                double row[5];
+                make_row(ctx, i, row);
+                double t = row[0] * x[0];
+                for (int a = 1; a < k; a++) t += row[a] * x[a];
+                const double r = bconst - t;
+                for (int a = 0; a < k; a++) part[a][l] += row[a] * r;
+            }
+        double h[5], dx[5];
+        for (int a = 0; a < k; a++) h[a] = butterfly64(part[a]);
+        normal_apply(F, h, dx);
+        for (int a = 0; a < k; a++) x[a] += dx[a];
+    }
 }
 
 static void get_ofs(int i, float eps, float* ox, float* oy)
 { /* [OCV] getOfs */
     *ox = (float)(((i & 1) * 2 - 1)) * eps;
     *oy = (float)(((i & 2) - 1)) * eps;
+}
+
+/* design-matrix rows of the general fit (the n x 5 and n x 3 matrices of [OCV] fitEllipseNoDirect), produced on demand */
+typedef struct { const orc_point* pts; float cx, cy; double scale; float eps; double r0, r1; } gen_rows;
+static void gen_pxy(const gen_rows* R, int i, double* px, double* py)
+{
+    float ox = 0, oy = 0;
+    if (R->eps != 0.0f) get_ofs(i, R->eps, &ox, &oy);
+    const float fx = ((float)R->pts[i].x + ox) - R->cx, fy = ((float)R->pts[i].y + oy) - R->cy;
+    *px = fx * R->scale;
+    *py = fy * R->scale;
+}
+static void gen_row5(const void* ctx, int i, double* row)
+{
+    double px, py;
+    gen_pxy((const gen_rows*)ctx, i, &px, &py);
+    row[0] = -px * px; row[1] = -py * py; row[2] = -px * py; row[3] = px; row[4] = py;
+}
+static void gen_row3(const void* ctx, int i, double* row)
+{
+    const gen_rows* R = (const gen_rows*)ctx;
+    double px, py;
+    gen_pxy(R, i, &px, &py);
+    row[0] = (px - R->r0) * (px - R->r0); row[1] = (py - R->r1) * (py - R->r1); row[2] = (px - R->r0) * (py - R->r1);
 }
 
 /* [OCV] fitEllipseNoDirect (general "LIN" conic fit, D. Weiss): structure restated, the two
@@ -772,16 +848,16 @@ static void fit_ellipse_general(const orc_point* pts, int n, orc_rrect* box)
     double scale = 100.0 / (s > FLT_EPSILON ? s : (double)FLT_EPSILON);
     double gfp[5], rp[5] = {0, 0, 0, 0, 0};
     float eps = 0.0f;
+    gen_rows R = {pts, cx, cy, scale, 0.0f, 0.0, 0.0};
     for (int iter = 0; iter < 2; iter++) {
-        double G[25], g[5], wmax, wmin;
+        double G[25], g[5];
+        normal_fac F;
         memset(G, 0, sizeof(G));
         memset(g, 0, sizeof(g));
+        R.eps = iter ? eps : 0.0f;
         for (int i = 0; i < n; i++) {
-            float ox = 0, oy = 0;
-            if (iter) get_ofs(i, eps, &ox, &oy);
-            float fx = ((float)pts[i].x + ox) - cx, fy = ((float)pts[i].y + oy) - cy;
-            double px = fx * scale, py = fy * scale;
-            double row[5] = {-px * px, -py * py, -px * py, px, py};
+            double row[5];
+            gen_row5(&R, i, row);
             for (int a = 0; a < 5; a++) {
                 for (int b = a; b < 5; b++) G[a * 5 + b] += row[a] * row[b];
                 g[a] += row[a] * 10000.0;
@@ -789,11 +865,13 @@ static void fit_ellipse_general(const orc_point* pts, int n, orc_rrect* box)
         }
         for (int a = 0; a < 5; a++)
             for (int b = 0; b < a; b++) G[a * 5 + b] = G[b * 5 + a];
-        normal_solve(G, g, 5, gfp, &wmax, &wmin);
-        if (iter == 0 && wmax * FLT_EPSILON > wmin) {
+        normal_factor(G, 5, &F);
+        if (iter == 0 && F.wmax * FLT_EPSILON > F.wmin) {
             eps = (float)(s / (n * 2) * 1e-3);
             continue;
         }
+        normal_apply(&F, g, gfp);
+        normal_refine(&F, gen_row5, &R, n, 10000.0, gfp);
         break;
     }
     /* centre: differentiate the general form */
@@ -808,14 +886,15 @@ static void fit_ellipse_general(const orc_point* pts, int n, orc_rrect* box)
     /* re-fit A..C with that centre */
     {
         double G[9], g[3];
+        normal_fac F;
         memset(G, 0, sizeof(G));
         memset(g, 0, sizeof(g));
+        R.eps = eps;
+        R.r0 = rp[0];
+        R.r1 = rp[1];
         for (int i = 0; i < n; i++) {
-            float ox = 0, oy = 0;
-            if (eps != 0.0f) get_ofs(i, eps, &ox, &oy);
-            float fx = ((float)pts[i].x + ox) - cx, fy = ((float)pts[i].y + oy) - cy;
-            double px = fx * scale, py = fy * scale;
-            double row[3] = {(px - rp[0]) * (px - rp[0]), (py - rp[1]) * (py - rp[1]), (px - rp[0]) * (py - rp[1])};
+            double row[5];
+            gen_row3(&R, i, row);
             for (int a = 0; a < 3; a++) {
                 for (int b = a; b < 3; b++) G[a * 3 + b] += row[a] * row[b];
                 g[a] += row[a] * 1.0;
@@ -823,7 +902,9 @@ static void fit_ellipse_general(const orc_point* pts, int n, orc_rrect* box)
         }
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < a; b++) G[a * 3 + b] = G[b * 3 + a];
-        normal_solve(G, g, 3, gfp, 0, 0);
+        normal_factor(G, 3, &F);
+        normal_apply(&F, g, gfp);
+        normal_refine(&F, gen_row3, &R, n, 1.0, gfp);
     }
     double t;
     rp[4] = -0.5 * m_atan2(gfp[2], gfp[1] - gfp[0]);

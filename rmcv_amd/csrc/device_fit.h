@@ -495,33 +495,54 @@ __device__ inline void jacobi_sym(LaneVec& A, int k, LaneVec& lam, LaneVec& V)
     for (int i = 0; i < k; i++) lam[i] = (double)A[i * k + i];
 }
 
-// least squares through the normal equations: A (k x k, lanes 0..k*k-1, destroyed) x = g (lanes 0..k-1)
-__device__ inline void normal_solve(LaneVec& A, LaneVec& g, int k, double* x /* k <= 5 */, double* wmax, double* wmin, int lane)
+// Least squares through the normal equations, device twin of oracle/rmcv_oracle.c normal_factor / normal_apply: the Jacobi
+// eigen-decomposition G = V diag(lam) V^T is kept (across lanes) so that the pseudo-inverse can be applied again to the
+// right-hand sides of the refinement steps (wave_detect.h normal_refine).
+struct NormalFac {
+    LaneVec lam, V;
+    int k, use; // use: bit c set <=> singular value c is above the SVBackSubst threshold
+    __device__ __forceinline__ explicit NormalFac(int lane) : lam(lane), V(lane), k(0), use(0) {}
+};
+
+// A: k x k in lanes 0..k*k-1 (destroyed); wmax / wmin: the extreme singular values of the design matrix
+__device__ inline void normal_factor(LaneVec& A, int k, NormalFac& F, double* wmax, double* wmin)
 {
-    LaneVec lam(lane), V(lane), w(lane), xs(lane);
-    jacobi_sym(A, k, lam, V);
+    F.k = k;
+    jacobi_sym(A, k, F.lam, F.V);
     double wsum = 0, mx = 0, mn = 0;
     for (int i = 0; i < k; i++) {
-        const double li = lam[i];
+        const double li = F.lam[i];
         const double wi = li > 0 ? dsqrt(li) : 0.0;
-        w[i] = wi;
         wsum += wi;
         if (i == 0 || wi > mx) mx = wi;
         if (i == 0 || wi < mn) mn = wi;
     }
     const double thr = 2.0 * DBL_EPSILON * wsum;
+    F.use = 0;
+    for (int i = 0; i < k; i++) {
+        const double li = F.lam[i];
+        const double wi = li > 0 ? dsqrt(li) : 0.0;
+        F.use |= (wi > thr ? 1 : 0) << i;
+    }
+    *wmax = mx;
+    *wmin = mn;
+}
+
+// x (k <= 5 entries, the rest 0) = pinv(G) g;  g in lanes 0..k-1 of g.reg
+__device__ inline void normal_apply(NormalFac& F, LaneVec& g, double* x, int lane)
+{
+    const int k = F.k;
+    LaneVec xs(lane);
     for (int i = 0; i < k; i++) xs[i] = 0.0;
     for (int c = 0; c < k; c++) {
-        if (!((double)w[c] > thr)) continue;
+        if (!((F.use >> c) & 1)) continue;
         double dot = 0.0;
-        for (int r = 0; r < k; r++) dot += (double)V[r * k + c] * (double)g[r];
-        dot = dot / (double)lam[c];
-        for (int r = 0; r < k; r++) xs[r] += dot * (double)V[r * k + c];
+        for (int r = 0; r < k; r++) dot += (double)F.V[r * k + c] * (double)g[r];
+        dot = dot / (double)F.lam[c];
+        for (int r = 0; r < k; r++) xs[r] += dot * (double)F.V[r * k + c];
     }
 #pragma unroll
     for (int i = 0; i < 5; i++) x[i] = i < k ? xs.get(i) : 0.0;
-    if (wmax) *wmax = mx;
-    if (wmin) *wmin = mn;
 }
 
 __device__ __forceinline__ void get_ofs(int i, float eps, float* ox, float* oy)

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
-                                                 int* __restrict__ strip_ctr, uint32_t strip_base, int taper_head, int taper_tail)
+                                                 int* __restrict__ strip_ctr, int taper_head, int taper_tail)
 {
     extern __shared__ uint64_t smem[];
     const int halo = morph; // NONE 0, DILATE 1, CLOSE 2
@@ -123,15 +123,14 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
     __syncthreads(); // also: the LDS planes of the previous strip are free
-    // The queue heads run free (no reset between launches): every workgroup of a launch draws until its first index
-    // >= n_queue, so one launch advances each head by exactly n_queue + gridDim.x/8 and the host knows the value the
-    // next launch starts from (strip_base, modulo 2^32).
+    // Every launch finds the heads at 0: the workgroup that leaves last zeroes them (below), so there is no memset per step
+    // and no host-side mirror of device state that a failed or foreign launch could put out of step.
     // Tapered queue: the first taper_head and the last taper_tail strips of an XCD's range are handed out as four 8-row
     // pieces each, so the kernel's ramp (nothing is stored before a first strip is complete) and its tail (workgroups
     // finish up to one strip apart) are a quarter as long.
     const int n_mid = per_xcd - taper_head - taper_tail;
     const int n_queue = 4 * taper_head + n_mid + 4 * taper_tail;
-    if (tid == 0) s_next = (int)((uint32_t)atomicAdd(&strip_ctr[xcd], 1) - strip_base);
+    if (tid == 0) s_next = atomicAdd(&strip_ctr[xcd], 1);
     __syncthreads();
     const int j = s_next;
     if ((uint32_t)j >= (uint32_t)n_queue) break;
@@ -350,6 +349,15 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
         }
     }
     } // strip loop
+    // Leaving: this workgroup has drawn its last index.  strip_ctr[8] counts the leavers; the last one of the launch knows that
+    // nobody will draw again and zeroes the eight heads and the count for the next launch (launches of one context are ordered:
+    // rmcv_host.hip chains them with an event when the caller changes streams).
+    if (tid < 64) {
+        int left = 0;
+        if (tid == 0) left = atomicAdd(&strip_ctr[8], 1);
+        left = __builtin_amdgcn_readfirstlane(left);
+        if (left == (int)gridDim.x - 1 && tid < 9) atomicExch(&strip_ctr[tid], 0);
+    }
 }
 
 template <int CA, int CB>
@@ -371,33 +379,22 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     // the sparse kernel of the previous one on the same CU: with 3 batches in flight 930 k frames/s against 790 k with 4.
     static const int bpc_env = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 0;
     const int bpc = bpc_env > 0 ? bpc_env : groups;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    int grid = n_cu * (bpc > 0 ? bpc : 4);
+    int grid = (g.n_cu > 0 ? g.n_cu : 256) * (bpc > 0 ? bpc : 4); // n_cu: of the context's own device
     if (grid > ((n_blocks + 7) & ~7)) grid = (n_blocks + 7) & ~7;
     grid = (grid + 7) & ~7;
-    const uint32_t base = *b.strip_base; // launches of one context are stream-ordered
     // tapered queue (see the kernel): 16 strips at the head (one 8-row piece per workgroup of an XCD at 2 per CU) and 32 at the tail
     static const int taper_on = getenv("RMCV_K1_TAPER") ? atoi(getenv("RMCV_K1_TAPER")) : 1; // dev knob for A/B runs
     const int per_xcd = (n_blocks + 7) >> 3;
     int taper_head = 0, taper_tail = 0;
     if (taper_on && per_xcd >= 192) { taper_head = 16; taper_tail = 32; }
-    const int n_queue = 4 * taper_head + (per_xcd - taper_head - taper_tail) + 4 * taper_tail;
-#define RMCV_K1_LAUNCH(F, V, LDS)                                                                                       \
-    hipLaunchKernelGGL((k_binary<CA, CB, F, V>), dim3(grid), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, \
-                       g.h, g.ww, lb, all_pass, morph, image ? b.binary : nullptr, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr, base, taper_head, taper_tail)
-    if (coalesced) RMCV_K1_LAUNCH(true, 1, planes + 4 * 3072);
-    else if (fast) RMCV_K1_LAUNCH(true, 0, planes);
-    else RMCV_K1_LAUNCH(false, 0, planes);
+#define RMCV_K1_LAUNCH(F, V, LDS)                                                                                              \
+    launch(k_binary<CA, CB, F, V>, dim3(grid), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, g.h, g.ww, lb, all_pass, \
+           morph, image ? b.binary : nullptr, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr, taper_head,  \
+           taper_tail)
+    if (coalesced) return RMCV_K1_LAUNCH(true, 1, planes + 4 * 3072);
+    if (fast) return RMCV_K1_LAUNCH(true, 0, planes);
+    return RMCV_K1_LAUNCH(false, 0, planes);
 #undef RMCV_K1_LAUNCH
-    const hipError_t e = hipGetLastError();
-    if (e == hipSuccess) *b.strip_base = base + (uint32_t)n_queue + (uint32_t)(grid >> 3);
-    return e;
 }
 
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s)
@@ -431,9 +428,8 @@ hipError_t launch_pack_bits(const Geom& g, const Bufs& b, hipStream_t s)
     const int items = g.h * g.ww;
     hipError_t e = hipMemsetAsync(b.rowmask, 0, (size_t)g.n_frames * g.h * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_pack_bits, dim3((items + 255) / 256, g.n_frames), dim3(256), 0, s, b.binary, g.w, g.h, g.ww, b.bits,
+    return launch(k_pack_bits, dim3((items + 255) / 256, g.n_frames), dim3(256), 0, s, b.binary, g.w, g.h, g.ww, b.bits,
                        g.prow, g.plane_pitch, b.rowmask);
-    return hipGetLastError();
 }
 
 } // namespace rmcv

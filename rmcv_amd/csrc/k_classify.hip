@@ -239,9 +239,8 @@ __global__ __launch_bounds__(256) void k_classify(const uint8_t* __restrict__ fr
 
 hipError_t launch_classify(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_classify, dim3(g.n_frames), dim3(256), 0, s, b.frames, g.frame_pitch, g.stride, g.w, g.h, b.armours,
+    return launch(k_classify, dim3(g.n_frames), dim3(256), 0, s, b.frames, g.frame_pitch, g.stride, g.w, g.h, b.armours,
                        b.n_armours, lim.max_armours, b.svm_w, b.svm_rho, b.svm_labels, b.svm_classes, b.identity, b.icons);
-    return hipGetLastError();
 }
 
 } // namespace rmcv

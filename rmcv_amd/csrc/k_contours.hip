@@ -41,18 +41,17 @@ static_assert(sizeof(ContoursLds) >= (CT_THREADS_MAX / 64) * sizeof(WaveLds), "t
 static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int waves, hipStream_t s)
 {
     static const int force_literal = getenv("RMCV_CONTOURS_LITERAL") ? atoi(getenv("RMCV_CONTOURS_LITERAL")) : 0; // dev/test knob
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[MAX_DEVICES] = {}; // hipFuncSetAttribute applies to the current device only (a process may drive several)
+    if (!attr_set[g.device]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_w8), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(ContoursLds));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[g.device] = true;
     }
     if (waves == 4) return launch_contours_w4(g, b, lim, X, force_literal, s);
-    hipLaunchKernelGGL(k_contours_w8, dim3(g.n_frames), dim3(512), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
+    return launch(k_contours_w8, dim3(g.n_frames), dim3(512), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
                        g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
                        lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy);
-    return hipGetLastError();
 }
 
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)
@@ -93,7 +92,8 @@ hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const 
 // contours of every frame as CSR in findContours order (reverse discovery), for download
 __global__ void k_pack_contours(const rmcv_point* __restrict__ points, const int32_t* __restrict__ cont_start,
                                 const int32_t* __restrict__ cont_len, const int32_t* __restrict__ n_contours, int max_contours,
-                                int max_points, rmcv_point* __restrict__ pts_out, int32_t* __restrict__ offs_out)
+                                int max_points, rmcv_point* __restrict__ pts_out, int32_t* __restrict__ offs_out,
+                                int32_t* __restrict__ hdr_out, const int32_t* __restrict__ status)
 {
     const int f = blockIdx.x;
     const int n = n_contours[f];
@@ -111,6 +111,11 @@ __global__ void k_pack_contours(const rmcv_point* __restrict__ points, const int
         }
         offs[n] = o;
         s_off = o;
+        if (hdr_out && f == 0) { // the per-frame path reads sizes and status with one small copy
+            hdr_out[0] = n;
+            hdr_out[1] = o;
+            hdr_out[2] = status[0];
+        }
     }
     __syncthreads();
     for (int i = 0; i < n; i++) {
@@ -122,12 +127,24 @@ __global__ void k_pack_contours(const rmcv_point* __restrict__ points, const int
     }
 }
 
-hipError_t launch_pack_contours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_point* d_pts_out, int32_t* d_offs_out,
-                                hipStream_t s)
+__global__ void k_gather3(const int32_t* __restrict__ a, const int32_t* __restrict__ b, const int32_t* __restrict__ c,
+                          int32_t* __restrict__ out)
 {
-    hipLaunchKernelGGL(k_pack_contours, dim3(g.n_frames), dim3(256), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
-                       lim.max_contours, lim.max_points, d_pts_out, d_offs_out);
-    return hipGetLastError();
+    if (threadIdx.x == 0) out[0] = *a;
+    if (threadIdx.x == 1) out[1] = *b;
+    if (threadIdx.x == 2) out[2] = *c;
+}
+
+hipError_t launch_gather3(const int32_t* a, const int32_t* b, const int32_t* c, int32_t* d_out, hipStream_t s)
+{
+    return launch(k_gather3, dim3(1), dim3(64), 0, s, a, b, c, d_out);
+}
+
+hipError_t launch_pack_contours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_point* d_pts_out, int32_t* d_offs_out,
+                                int32_t* d_hdr, hipStream_t s)
+{
+    return launch(k_pack_contours, dim3(g.n_frames), dim3(256), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
+                       lim.max_contours, lim.max_points, d_pts_out, d_offs_out, d_hdr, b.status);
 }
 
 } // namespace rmcv

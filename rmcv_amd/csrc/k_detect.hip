@@ -211,12 +211,22 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
     if (tid == 0) frame_offs[n_frames] = s_base;
 }
 
+__global__ void k_status_clear(int32_t* __restrict__ status, int n, int mask)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n) status[f] &= ~mask;
+}
+
+hipError_t launch_status_clear(const Geom& g, const Bufs& b, int mask, hipStream_t s)
+{
+    return launch(k_status_clear, dim3((g.n_frames + 255) / 256), dim3(256), 0, s, b.status, g.n_frames, mask);
+}
+
 hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
                                   int32_t* d_frame_offs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_compact_armours, dim3(1), dim3(256), 0, s, b.armours, b.n_armours, g.n_frames, lim.max_armours, d_out,
+    return launch(k_compact_armours, dim3(1), dim3(256), 0, s, b.armours, b.n_armours, g.n_frames, lim.max_armours, d_out,
                        cap, d_frame_offs);
-    return hipGetLastError();
 }
 
 static hipError_t launch_pairs_tail(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s)
@@ -238,16 +248,14 @@ static hipError_t launch_pairs_tail(const Geom& g, const Bufs& b, const Limits& 
     T.angle_diff_max = p.angle_diff_max;
     T.shear_max = p.shear_max;
     T.length_ratio_max = p.length_ratio_max;
-    hipLaunchKernelGGL(k_pairs, dim3(g.n_frames), dim3(64), 0, s, b.slot_kind, b.slot_ell, b.n_contours, lim.max_contours, T);
-    return hipGetLastError();
+    return launch(k_pairs, dim3(g.n_frames), dim3(64), 0, s, b.slot_kind, b.slot_ell, b.n_contours, lim.max_contours, T);
 }
 
 static hipError_t launch_fit(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fit, dim3(g.n_frames, FIT_CHUNKS), dim3(256), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
+    hipError_t e = launch(k_fit, dim3(g.n_frames, FIT_CHUNKS), dim3(256), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
                        lim.max_contours, lim.max_points, p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi, b.slot_kind,
                        b.slot_ell, b.elig, b.n_elig);
-    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_pairs_tail(g, b, lim, p, pairs, s);
 }
@@ -279,15 +287,15 @@ hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const r
         A.hcap = !hull ? 1 : full ? HULL_CAP : 128;
         A.ccap = !hull ? 1 : full ? HULL_CHAIN_CAP : 64;
         const size_t lds = sizeof(WaveLds) + hull_lds_bytes(A.wcap, A.hcap, A.ccap);
-        static size_t lds_set = 0;
+        static size_t lds_set_dev[MAX_DEVICES] = {}; // per device, like the attribute itself
+        size_t& lds_set = lds_set_dev[g.device];
         if (lds > lds_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             lds_set = lds;
         }
-        hipLaunchKernelGGL(k_match, dim3(g.n_frames, pass ? 2 : MATCH_CHUNKS), dim3(64), lds, s, b.points, b.cont_start, b.cont_len,
+        hipError_t e = launch(k_match, dim3(g.n_frames, pass ? 2 : MATCH_CHUNKS), dim3(64), lds, s, b.points, b.cont_start, b.cont_len,
                            b.n_contours, lim.max_contours, lim.max_points, A, b.slot_kind, b.slot_ell, b.elig, b.n_elig, b.status);
-        hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return launch_pairs_tail(g, b, lim, p, pairs, s);
@@ -306,9 +314,8 @@ hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim,
 
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_armours, dim3(g.n_frames), dim3(64), 0, s, b.blobs, b.n_blobs, lim.max_blobs, p.angle_diff_max,
+    return launch(k_armours, dim3(g.n_frames), dim3(64), 0, s, b.blobs, b.n_blobs, lim.max_blobs, p.angle_diff_max,
                        p.shear_max, p.length_ratio_max, p.camp, b.armours, b.n_armours, b.status, lim.max_armours);
-    return hipGetLastError();
 }
 
 } // namespace rmcv

@@ -256,9 +256,8 @@ __global__ __launch_bounds__(64) void k_pnp(const rmcv_armour* __restrict__ armo
 
 hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pnp, dim3(g.n_frames), dim3(64), 0, s, b.armours, b.n_armours, lim.max_armours, b.pnp_cfg, b.base2gripper,
+    return launch(k_pnp, dim3(g.n_frames), dim3(64), 0, s, b.armours, b.n_armours, lim.max_armours, b.pnp_cfg, b.base2gripper,
                        b.poses);
-    return hipGetLastError();
 }
 
 } // namespace rmcv

@@ -29,7 +29,27 @@ struct rmcv_ctx {
     int32_t* pack_offs = nullptr;
     hipStream_t last_stream = nullptr;
     int geom_w = -1, geom_h = -1; // geometry the planes were zeroed for
-    uint32_t k1_base = 0;         // see Bufs::strip_base
+    hipEvent_t ev_order = nullptr; // recorded behind the work enqueued last: a call on ANOTHER stream first waits for it
+    bool order_pending = false;
+    // ---- per-frame drop-in path (rmcv_extract_color -> rmcv_filter_lightblobs -> rmcv_filter_armours, executable/main.cpp:172-176)
+    int frame_upload = 1;          // RMCV_OPT_FRAME_UPLOAD
+    struct Reg { const void* p; size_t bytes; };
+    std::vector<Reg> registered;   // caller buffers pinned by hipHostRegister (RMCV_OPT_FRAME_UPLOAD = 2)
+    uint8_t* h_frame = nullptr;    // pinned staging (lazy): the BGR frame on its way up ...
+    size_t h_frame_bytes = 0;
+    uint8_t* h_binary = nullptr;   // ... and every result on its way down
+    int32_t* h_hdr = nullptr;      // [8]
+    rmcv_point* h_pts = nullptr;   // [max_points]      the CSR the last rmcv_extract_color returned
+    int32_t* h_offs = nullptr;     // [max_contours + 1]
+    rmcv_lightblob* h_blobs = nullptr; // [max_blobs]   the positive list the last rmcv_filter_lightblobs returned
+    int32_t* h_blob_src = nullptr; // [max_blobs]
+    int32_t* h_neg = nullptr;      // [max_contours]
+    rmcv_armour* h_armours = nullptr; // [max_armours]
+    int32_t* d_hdr = nullptr;      // device [8]
+    // Device-resident hand-over: what frame slot 0 of the device buffers holds right now.  When the next call of the chain is
+    // handed exactly these bytes back (the usual case: the reference passes the results straight on), nothing is re-uploaded.
+    int res_nc = -1, res_total = 0; // contours (+ the fit stage's work list) = h_pts / h_offs; -1: not resident
+    int res_nb = -1;                // light blobs = h_blobs; -1: not resident
     int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
     int pixel_groups = 4;         // RMCV_OPT_PIXEL_GROUPS
     char err[256] = {0};
@@ -104,8 +124,13 @@ void rmcv_ctx_destroy(rmcv_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) hipFree(p);
     if (c->own_frames) hipFree(c->own_frames);
+    for (auto& r : c->registered) hipHostUnregister(const_cast<void*>(r.p));
+    for (void* h : {(void*)c->h_frame, (void*)c->h_binary, (void*)c->h_hdr, (void*)c->h_pts, (void*)c->h_offs, (void*)c->h_blobs,
+                    (void*)c->h_blob_src, (void*)c->h_neg, (void*)c->h_armours})
+        if (h) hipHostFree(h);
     for (auto& e : c->ev)
         if (e) hipEventDestroy(e);
+    if (c->ev_order) hipEventDestroy(c->ev_order);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -134,13 +159,20 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        c->geom.device = device;
+        c->geom.n_cu = (device < MAX_DEVICES && hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
+        if (device >= MAX_DEVICES) e = hipErrorInvalidDevice;
+    }
     const size_t F = (size_t)d.max_frames;
     const size_t plane = (size_t)(d.max_height + 2) * ((d.max_width + 63) / 64 + 2);
     Bufs& b = c->bufs;
     if (e == hipSuccess) e = dalloc(c, &b.binary, F * d.max_width * d.max_height);
     if (e == hipSuccess) e = dalloc(c, &b.bits, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.rowmask, F * d.max_height);
-    if (e == hipSuccess) e = dalloc(c, &b.strip_ctr, 8);
+    if (e == hipSuccess) e = dalloc(c, &b.strip_ctr, 16);
     if (e == hipSuccess) e = dalloc(c, &b.lab, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.neg, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.points, F * d.max_points);
@@ -165,8 +197,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.n_armours, F);
     if (e == hipSuccess) e = dalloc(c, &b.status, F);
     if (e == hipSuccess) {
-        b.strip_base = &c->k1_base;
-        hipMemset(b.strip_ctr, 0, 8 * sizeof(int));
+        hipMemset(b.strip_ctr, 0, 16 * sizeof(int));
         hipMemset(b.n_contours, 0, F * 4);
         hipMemset(b.n_points, 0, F * 4);
         hipMemset(b.n_blobs, 0, F * 4);
@@ -184,6 +215,40 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
 }
 
 } // extern "C"
+
+// frame slot 0 of the device buffers no longer holds what the per-frame chain returned last (see rmcv_ctx::res_nc)
+static void resident_none(rmcv_ctx* c) { c->res_nc = c->res_nb = -1; }
+
+static int ensure_own_frames(rmcv_ctx* c, size_t need)
+{
+    if (need <= c->own_frames_bytes) return RMCV_OK;
+    if (c->own_frames) hipFree(c->own_frames);
+    c->own_frames = nullptr;
+    c->own_frames_bytes = 0;
+    size_t cap = (size_t)((3 * c->lim.max_width + 15) & ~15) * c->lim.max_height * c->lim.max_frames;
+    if (cap < need) cap = need;
+    HIPCHK(c, hipMalloc((void**)&c->own_frames, cap), "hipMalloc frames");
+    c->own_frames_bytes = cap;
+    return RMCV_OK;
+}
+
+// pinned host staging + the device header word of the per-frame path (lazy: batch users never pay for it)
+static int ensure_staging(rmcv_ctx* c)
+{
+    if (c->h_hdr) return RMCV_OK;
+    const Limits& L = c->lim;
+    hipError_t e = hipHostMalloc((void**)&c->h_hdr, 8 * sizeof(int32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_binary, (size_t)L.max_width * L.max_height, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_pts, (size_t)L.max_points * sizeof(rmcv_point), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_offs, (size_t)(L.max_contours + 1) * 4, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_blobs, (size_t)L.max_blobs * sizeof(rmcv_lightblob), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_blob_src, (size_t)L.max_blobs * 4, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_neg, (size_t)L.max_contours * 4, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_armours, (size_t)L.max_armours * sizeof(rmcv_armour), hipHostMallocDefault);
+    if (e == hipSuccess) e = dalloc(c, &c->d_hdr, 8);
+    if (e != hipSuccess) return fail(c, RMCV_ERR_NOMEM, "pinned staging", e);
+    return RMCV_OK;
+}
 
 // bind a geometry; zero the padded planes when it changes (their pads must read 0)
 static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t frame_pitch)
@@ -212,15 +277,39 @@ static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t
     return RMCV_OK;
 }
 
+// Work of one context is ordered, whatever streams the caller hands in: every launch shares the context's buffers (and
+// k_binary's strip queue).  An event is recorded behind the work enqueued last; a call on ANOTHER stream first waits for it,
+// so two streams on one context interleave correctly instead of racing (a context still has ONE owner thread).
+static int order_begin(rmcv_ctx* c, hipStream_t s)
+{
+    if (c->order_pending && c->last_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->ev_order, 0), "order: wait for the previous stream");
+    return RMCV_OK;
+}
+static int order_end(rmcv_ctx* c, hipStream_t s)
+{
+    c->last_stream = s;
+    HIPCHK(c, hipEventRecord(c->ev_order, s), "order: record");
+    c->order_pending = true;
+    return RMCV_OK;
+}
+
 static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t s, bool timed,
                       const rmcv_legacy_params* lp = nullptr)
 {
     const Geom& g = c->geom;
     const Bufs& b = c->bufs;
     int k = 0;
+    resident_none(c);
+    int rc = order_begin(c, s);
+    if (rc) return rc;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
-    // k_contours writes every frame's status word; without that stage the word is cleared here
-    if (!(stages & RMCV_STAGE_CONTOURS)) HIPCHK(c, hipMemsetAsync(b.status, 0, (size_t)g.n_frames * 4, s), "memset status");
+    // Status bits belong to the stage that sets them: k_contours rewrites the whole word; a run that starts at a later stage
+    // clears only the bits of the stages it runs, so OVF_CONTOURS / OVF_POINTS / SLOW_PATH of the contour run it builds on survive.
+    if (!(stages & RMCV_STAGE_CONTOURS)) {
+        const int own = ((stages & RMCV_STAGE_BLOBS) ? (RMCV_FRAME_OVF_BLOBS | RMCV_FRAME_HULL) : 0) |
+                        ((stages & RMCV_STAGE_ARMOURS) ? RMCV_FRAME_OVF_ARMOURS : 0);
+        if (own) HIPCHK(c, launch_status_clear(g, b, own, s), "k_status_clear");
+    }
     if (stages & RMCV_STAGE_BINARY) HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, s), "k_binary");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     // findContours + filter_lightblobs (+ filter_armours) as ONE per-frame kernel when the stages are asked for together;
@@ -246,8 +335,7 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
         HIPCHK(c, launch_pnp(g, b, c->lim, s), "k_pnp");
     }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
-    c->last_stream = s;
-    return RMCV_OK;
+    return order_end(c, s);
 }
 
 static int check_params(rmcv_ctx* c, const rmcv_params* p, int stages)
@@ -268,21 +356,17 @@ int rmcv_batch_upload(rmcv_ctx* c, const uint8_t* frames, int n_frames, int w, i
 {
     if (!c || !frames) return RMCV_ERR_BAD_ARG;
     hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c); // the buffer about to be overwritten may still be read by a batch in flight
+    if (rc) return rc;
+    resident_none(c);
     // device layout: tightly packed rows (stride 3*w rounded up to 16 bytes), frames back to back
     const int dstride = (3 * w + 15) & ~15;
     const int64_t dpitch = (int64_t)dstride * h;
-    int rc = set_geom(c, n_frames, w, h, dstride, dpitch);
+    rc = set_geom(c, n_frames, w, h, dstride, dpitch);
     if (rc) return rc;
     const size_t need = (size_t)dpitch * n_frames;
-    if (need > c->own_frames_bytes) {
-        if (c->own_frames) hipFree(c->own_frames);
-        c->own_frames = nullptr;
-        c->own_frames_bytes = 0;
-        size_t cap = (size_t)((3 * c->lim.max_width + 15) & ~15) * c->lim.max_height * c->lim.max_frames;
-        if (cap < need) cap = need;
-        HIPCHK(c, hipMalloc((void**)&c->own_frames, cap), "hipMalloc frames");
-        c->own_frames_bytes = cap;
-    }
+    rc = ensure_own_frames(c, need);
+    if (rc) return rc;
     if (stride == dstride && frame_pitch == dpitch) {
         HIPCHK(c, hipMemcpyAsync(c->own_frames, frames, need, hipMemcpyHostToDevice, c->stream), "H2D frames");
     } else {
@@ -301,6 +385,7 @@ int rmcv_batch_set_device_frames(rmcv_ctx* c, const void* d_frames, int n_frames
 {
     if (!c || !d_frames) return RMCV_ERR_BAD_ARG;
     hipSetDevice(c->device);
+    resident_none(c);
     int rc = set_geom(c, n_frames, w, h, stride, frame_pitch);
     if (rc) return rc;
     c->bufs.frames = (const uint8_t*)d_frames;
@@ -331,6 +416,10 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         c->sparse_waves = value;
         return RMCV_OK;
     }
+    if (option == RMCV_OPT_FRAME_UPLOAD && value >= 0 && value <= 2) {
+        c->frame_upload = value;
+        return RMCV_OK;
+    }
     if (option == RMCV_OPT_PIXEL_GROUPS && value >= 1 && value <= 8) {
         c->pixel_groups = value;
         return RMCV_OK;
@@ -342,7 +431,9 @@ int rmcv_batch_sync(rmcv_ctx* c)
 {
     if (!c) return RMCV_ERR_BAD_ARG;
     hipSetDevice(c->device);
-    HIPCHK(c, hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream), "sync");
+    // the event sits behind everything this context enqueued, on whichever stream (a stream handle of the caller may be gone by now)
+    if (c->order_pending) HIPCHK(c, hipEventSynchronize(c->ev_order), "sync");
+    HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
     return RMCV_OK;
 }
 
@@ -404,7 +495,7 @@ int rmcv_batch_get_contours(rmcv_ctx* c, int frame, rmcv_point* pts_out, int pts
     b1.cont_start += (size_t)frame * c->lim.max_contours;
     b1.cont_len += (size_t)frame * c->lim.max_contours;
     b1.n_contours += frame;
-    HIPCHK(c, launch_pack_contours(g1, b1, c->lim, c->pack_pts, c->pack_offs, s), "k_pack_contours");
+    HIPCHK(c, launch_pack_contours(g1, b1, c->lim, c->pack_pts, c->pack_offs, nullptr, s), "k_pack_contours");
     int32_t nc = 0, st = 0;
     HIPCHK(c, hipMemcpyAsync(&nc, c->bufs.n_contours + frame, 4, hipMemcpyDeviceToHost, s), "D2H");
     HIPCHK(c, hipMemcpyAsync(&st, c->bufs.status + frame, 4, hipMemcpyDeviceToHost, s), "D2H");
@@ -487,9 +578,10 @@ int rmcv_batch_compact_armours(rmcv_ctx* c, void* d_armours_out, int cap, void* 
     if (!c || !d_armours_out || !d_frame_offs || cap < 0) return RMCV_ERR_BAD_ARG;
     hipSetDevice(c->device);
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    int rc = order_begin(c, s);
+    if (rc) return rc;
     HIPCHK(c, launch_compact_armours(c->geom, c->bufs, c->lim, (rmcv_armour*)d_armours_out, cap, (int32_t*)d_frame_offs, s), "k_compact_armours");
-    c->last_stream = s;
-    return RMCV_OK;
+    return order_end(c, s);
 }
 
 int rmcv_svm_load(rmcv_ctx* c, const float* weights, const double* rho, const int32_t* labels, int n_class)
@@ -555,7 +647,7 @@ int rmcv_classify_armours(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int str
     if (!c || !bgr || (n > 0 && (!armours || !identity_out)) || n < 0) return RMCV_ERR_BAD_ARG;
     if (!c->bufs.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "rmcv_svm_load first");
     if (n > c->lim.max_armours) return fail(c, RMCV_ERR_CAPACITY, "too many armours for this context");
-    int rc = rmcv_batch_upload(c, bgr, 1, w, h, stride, (int64_t)stride * h);
+    int rc = rmcv_batch_upload(c, bgr, 1, w, h, stride, (int64_t)stride * h); // syncs the context first
     if (rc) return rc;
     if (n == 0) return RMCV_OK;
     HIPCHK(c, hipMemcpy(c->bufs.armours, armours, (size_t)n * sizeof(rmcv_armour), hipMemcpyHostToDevice), "H2D armours");
@@ -568,32 +660,114 @@ int rmcv_classify_armours(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int str
     return RMCV_OK;
 }
 
-/* ---------------- single-frame, host-buffer entry points ---------------- */
+/* ---------------- single-frame, host-buffer entry points ----------------
+ * The chain an unchanged executable/main.cpp:172-176 runs on every camera frame.  Each call is ONE stream sequence with ONE
+ * synchronisation: upload (pinned staging) -> kernels -> a header word + fixed windows of the results copied back
+ * speculatively (a frame has ~1000 contour points, ~10 blobs, ~3 armours; what does not fit a window is fetched by a second
+ * copy).  Results stay on the device: when the next call is handed exactly the bytes the previous one returned, it runs on the
+ * resident buffers instead of uploading them again. */
+static constexpr int SF_OFFS_WIN = 1024, SF_PTS_WIN = 8192, SF_BLOB_WIN = 64, SF_NEG_WIN = 1024, SF_ARM_WIN = 32;
+
+// bring one BGR frame into own_frames (frame slot 0) on the context's stream; RMCV_OPT_FRAME_UPLOAD selects how
+static int upload_one(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride, int dstride)
+{
+    const size_t dpitch = (size_t)dstride * h;
+    hipStream_t s = c->stream;
+    if (c->frame_upload == 2) { // pin the caller's buffer once (camera SDKs hand out a small ring of frame buffers) and DMA from it
+        const size_t span = (size_t)stride * (h - 1) + (size_t)3 * w;
+        bool known = false;
+        for (auto& r : c->registered) known |= (r.p == bgr && r.bytes >= span);
+        if (!known) {
+            if (c->registered.size() >= 16) { // a ring larger than this is not a ring: forget the oldest
+                hipHostUnregister(const_cast<void*>(c->registered.front().p));
+                c->registered.erase(c->registered.begin());
+            }
+            if (hipHostRegister(const_cast<uint8_t*>(bgr), span, hipHostRegisterDefault) == hipSuccess) {
+                c->registered.push_back({bgr, span});
+                known = true;
+            } else {
+                (void)hipGetLastError(); // e.g. already registered by the application: plain copy below
+            }
+        }
+        HIPCHK(c, hipMemcpy2DAsync(c->own_frames, dstride, bgr, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, s), "H2D frame");
+        return RMCV_OK;
+    }
+    if (c->frame_upload == 0) { // the runtime's own pageable path
+        HIPCHK(c, hipMemcpy2DAsync(c->own_frames, dstride, bgr, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, s), "H2D frame");
+        return RMCV_OK;
+    }
+    if (dpitch > c->h_frame_bytes) {
+        if (c->h_frame) hipHostFree(c->h_frame);
+        c->h_frame = nullptr;
+        c->h_frame_bytes = 0;
+        size_t cap = (size_t)((3 * c->lim.max_width + 15) & ~15) * c->lim.max_height;
+        if (cap < dpitch) cap = dpitch;
+        HIPCHK(c, hipHostMalloc((void**)&c->h_frame, cap, hipHostMallocDefault), "pinned frame staging");
+        c->h_frame_bytes = cap;
+    }
+    // two halves: the DMA of the first runs while the CPU copies the second
+    const int h0 = h / 2;
+    for (int part = 0; part < 2; part++) {
+        const int y0 = part ? h0 : 0, y1 = part ? h : h0;
+        if (y1 <= y0) continue;
+        if (stride == dstride) memcpy(c->h_frame + (size_t)y0 * dstride, bgr + (size_t)y0 * stride, (size_t)(y1 - y0) * dstride);
+        else
+            for (int y = y0; y < y1; y++) memcpy(c->h_frame + (size_t)y * dstride, bgr + (size_t)y * stride, (size_t)3 * w);
+        HIPCHK(c, hipMemcpyAsync(c->own_frames + (size_t)y0 * dstride, c->h_frame + (size_t)y0 * dstride, (size_t)(y1 - y0) * dstride,
+                                 hipMemcpyHostToDevice, s), "H2D frame");
+    }
+    return RMCV_OK;
+}
 
 int rmcv_extract_color(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride, int camp, int lower_bound, int morph,
                        uint8_t* binary_out, rmcv_point* pts_out, int pts_cap, int32_t* offs_out, int contours_cap,
                        int32_t* n_contours, int32_t* n_points)
 {
     if (!c || !bgr) return RMCV_ERR_BAD_ARG;
-    int rc = rmcv_batch_upload(c, bgr, 1, w, h, stride, (int64_t)stride * h);
+    if (morph < RMCV_MORPH_NONE || morph > RMCV_MORPH_CLOSE) return fail(c, RMCV_ERR_BAD_ARG, "bad morph");
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
     if (rc) return rc;
-    rmcv_params p;
-    rmcv_default_params(&p);
-    p.camp = camp;
-    p.lower_bound = lower_bound;
-    p.morph = morph;
-    rc = rmcv_batch_run(c, &p, RMCV_STAGE_BINARY | RMCV_STAGE_CONTOURS, nullptr);
-    if (rc) return rc;
-    if (binary_out) {
-        rc = rmcv_batch_get_binary(c, 0, binary_out);
-        if (rc) return rc;
-    }
-    return rmcv_batch_get_contours(c, 0, pts_out, pts_cap, offs_out, contours_cap, n_contours, n_points);
+    resident_none(c);
+    if ((rc = ensure_staging(c))) return rc;
+    const int dstride = (3 * w + 15) & ~15;
+    if ((rc = set_geom(c, 1, w, h, dstride, (int64_t)dstride * h))) return rc;
+    if (stride < 3 * w) return fail(c, RMCV_ERR_BAD_ARG, "bad stride");
+    if ((rc = ensure_own_frames(c, (size_t)dstride * h))) return rc;
+    if ((rc = upload_one(c, bgr, w, h, stride, dstride))) return rc;
+    c->bufs.frames = c->own_frames;
+    const Geom& g = c->geom;
+    const Bufs& b = c->bufs;
+    hipStream_t s = c->stream;
+    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, s), "k_binary");
+    HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
+    HIPCHK(c, launch_pack_contours(g, b, c->lim, c->pack_pts, c->pack_offs, c->d_hdr, s), "k_pack_contours");
+    HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
+    HIPCHK(c, hipMemcpyAsync(c->h_offs, c->pack_offs, (size_t)(std::min(SF_OFFS_WIN, c->lim.max_contours) + 1) * 4, hipMemcpyDeviceToHost, s), "D2H offs");
+    HIPCHK(c, hipMemcpyAsync(c->h_pts, c->pack_pts, (size_t)std::min(SF_PTS_WIN, c->lim.max_points) * sizeof(rmcv_point), hipMemcpyDeviceToHost, s), "D2H pts");
+    if (binary_out) HIPCHK(c, hipMemcpyAsync(c->h_binary, b.binary, (size_t)w * h, hipMemcpyDeviceToHost, s), "D2H binary");
+    HIPCHK(c, hipStreamSynchronize(s), "sync");
+    const int32_t nc = c->h_hdr[0], total = c->h_hdr[1], st = c->h_hdr[2];
+    if (n_contours) *n_contours = nc;
+    if (n_points) *n_points = total;
+    if (st & (RMCV_FRAME_OVF_CONTOURS | RMCV_FRAME_OVF_POINTS)) return fail(c, RMCV_ERR_CAPACITY, "context limits exceeded (max_contours/max_points)");
+    if (nc > SF_OFFS_WIN) HIPCHK(c, hipMemcpy(c->h_offs + SF_OFFS_WIN + 1, c->pack_offs + SF_OFFS_WIN + 1, (size_t)(nc - SF_OFFS_WIN) * 4, hipMemcpyDeviceToHost), "D2H offs");
+    if (total > SF_PTS_WIN) HIPCHK(c, hipMemcpy(c->h_pts + SF_PTS_WIN, c->pack_pts + SF_PTS_WIN, (size_t)(total - SF_PTS_WIN) * sizeof(rmcv_point), hipMemcpyDeviceToHost), "D2H pts");
+    c->res_nc = nc; // the device holds these contours (discovery order + the fit work list) and h_pts / h_offs their CSR
+    c->res_total = total;
+    if (binary_out) memcpy(binary_out, c->h_binary, (size_t)w * h);
+    if (nc > contours_cap || total > pts_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    if (offs_out) memcpy(offs_out, c->h_offs, (size_t)(nc + 1) * 4);
+    if (pts_out && total) memcpy(pts_out, c->h_pts, (size_t)total * sizeof(rmcv_point));
+    return RMCV_OK;
 }
 
 // load host CSR contours (findContours order) into frame slot 0 (stored in discovery order = reversed)
 static int load_contours(rmcv_ctx* c, const rmcv_point* pts, const int32_t* offs, int n)
 {
+    int rc = rmcv_batch_sync(c); // frame slot 0 may belong to a batch in flight on a caller stream
+    if (rc) return rc;
+    resident_none(c);
     if (n < 0 || n > c->lim.max_contours) return fail(c, RMCV_ERR_CAPACITY, "too many contours for this context");
     const int total = n ? offs[n] : 0;
     if (total > c->lim.max_points) return fail(c, RMCV_ERR_CAPACITY, "too many points for this context");
@@ -628,10 +802,19 @@ int rmcv_filter_lightblobs(rmcv_ctx* c, const rmcv_point* pts, const int32_t* of
                            rmcv_lightblob* blobs_out, int blobs_cap, int32_t* n_blobs, int32_t* blob_src,
                            int32_t* neg_idx_out, int32_t* n_neg)
 {
-    if (!c || (n_contours > 0 && (!pts || !offs))) return RMCV_ERR_BAD_ARG;
+    if (!c || n_contours < 0 || (n_contours > 0 && (!pts || !offs))) return RMCV_ERR_BAD_ARG;
     hipSetDevice(c->device);
-    int rc = load_contours(c, pts, offs, n_contours);
+    int rc = ensure_staging(c);
     if (rc) return rc;
+    // handed exactly what rmcv_extract_color returned last?  then the contours (and the fit work list) are already on the device
+    const bool resident = c->res_nc >= 0 && n_contours == c->res_nc &&
+                          (n_contours == 0 || (offs[n_contours] == c->res_total && memcmp(offs, c->h_offs, (size_t)(n_contours + 1) * 4) == 0 &&
+                                               memcmp(pts, c->h_pts, (size_t)c->res_total * sizeof(rmcv_point)) == 0));
+    if (!resident) {
+        rc = load_contours(c, pts, offs, n_contours);
+        if (rc) return rc;
+    }
+    c->res_nb = -1;
     rmcv_params p;
     rmcv_default_params(&p);
     p.tilt_max = tilt_max;
@@ -642,16 +825,32 @@ int rmcv_filter_lightblobs(rmcv_ctx* c, const rmcv_point* pts, const int32_t* of
     p.camp = enemy;
     Geom g1 = c->geom;
     g1.n_frames = 1;
-    HIPCHK(c, launch_blobs(g1, c->bufs, c->lim, p, c->stream), "k_blobs");
-    c->last_stream = c->stream;
-    const int saved = c->geom.n_frames;
-    c->geom.n_frames = saved < 1 ? 1 : saved;
-    rc = rmcv_batch_get_blobs(c, 0, blobs_out, blobs_cap, n_blobs, blob_src);
-    if (rc) return rc;
-    int32_t nn = 0;
-    HIPCHK(c, hipMemcpy(&nn, c->bufs.n_neg, 4, hipMemcpyDeviceToHost), "D2H");
+    if (c->geom.n_frames < 1) c->geom.n_frames = 1;
+    const Bufs& b = c->bufs;
+    hipStream_t s = c->stream;
+    if (resident) HIPCHK(c, launch_status_clear(g1, b, RMCV_FRAME_OVF_BLOBS | RMCV_FRAME_OVF_ARMOURS | RMCV_FRAME_HULL, s), "k_status_clear");
+    HIPCHK(c, launch_blobs(g1, b, c->lim, p, s), "k_blobs");
+    HIPCHK(c, launch_gather3(b.n_blobs, b.n_neg, b.status, c->d_hdr, s), "k_gather3");
+    HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
+    const int bw = std::min(SF_BLOB_WIN, c->lim.max_blobs), nw = std::min(SF_NEG_WIN, c->lim.max_contours);
+    HIPCHK(c, hipMemcpyAsync(c->h_blobs, b.blobs, (size_t)bw * sizeof(rmcv_lightblob), hipMemcpyDeviceToHost, s), "D2H blobs");
+    if (blob_src) HIPCHK(c, hipMemcpyAsync(c->h_blob_src, b.blob_src, (size_t)bw * 4, hipMemcpyDeviceToHost, s), "D2H blob_src");
+    if (neg_idx_out) HIPCHK(c, hipMemcpyAsync(c->h_neg, b.neg_idx, (size_t)nw * 4, hipMemcpyDeviceToHost, s), "D2H neg");
+    HIPCHK(c, hipStreamSynchronize(s), "sync");
+    const int32_t nb = c->h_hdr[0], nn = c->h_hdr[1], st = c->h_hdr[2];
+    if (n_blobs) *n_blobs = nb;
     if (n_neg) *n_neg = nn;
-    if (neg_idx_out && nn) HIPCHK(c, hipMemcpy(neg_idx_out, c->bufs.neg_idx, (size_t)nn * 4, hipMemcpyDeviceToHost), "D2H neg");
+    if (st & RMCV_FRAME_OVF_BLOBS) return fail(c, RMCV_ERR_CAPACITY, "context limit exceeded (max_blobs)");
+    if (nb > bw) {
+        HIPCHK(c, hipMemcpy(c->h_blobs + bw, b.blobs + bw, (size_t)(nb - bw) * sizeof(rmcv_lightblob), hipMemcpyDeviceToHost), "D2H blobs");
+        if (blob_src) HIPCHK(c, hipMemcpy(c->h_blob_src + bw, b.blob_src + bw, (size_t)(nb - bw) * 4, hipMemcpyDeviceToHost), "D2H blob_src");
+    }
+    if (neg_idx_out && nn > nw) HIPCHK(c, hipMemcpy(c->h_neg + nw, b.neg_idx + nw, (size_t)(nn - nw) * 4, hipMemcpyDeviceToHost), "D2H neg");
+    c->res_nb = nb; // the device holds this positive list, h_blobs its bytes
+    if (nb > blobs_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    if (blobs_out && nb) memcpy(blobs_out, c->h_blobs, (size_t)nb * sizeof(rmcv_lightblob));
+    if (blob_src && nb) memcpy(blob_src, c->h_blob_src, (size_t)nb * 4);
+    if (neg_idx_out && nn) memcpy(neg_idx_out, c->h_neg, (size_t)nn * 4);
     return RMCV_OK;
 }
 
@@ -661,10 +860,22 @@ int rmcv_filter_armours(rmcv_ctx* c, const rmcv_lightblob* blobs, int n_blobs, f
     if (!c || (n_blobs > 0 && !blobs) || n_blobs < 0) return RMCV_ERR_BAD_ARG;
     if (n_blobs > c->lim.max_blobs) return fail(c, RMCV_ERR_CAPACITY, "too many blobs for this context");
     hipSetDevice(c->device);
-    int32_t z = 0;
-    if (n_blobs) HIPCHK(c, hipMemcpy(c->bufs.blobs, blobs, (size_t)n_blobs * sizeof(rmcv_lightblob), hipMemcpyHostToDevice), "H2D blobs");
-    HIPCHK(c, hipMemcpy(c->bufs.n_blobs, &n_blobs, 4, hipMemcpyHostToDevice), "H2D");
-    HIPCHK(c, hipMemcpy(c->bufs.status, &z, 4, hipMemcpyHostToDevice), "H2D");
+    int rc = ensure_staging(c);
+    if (rc) return rc;
+    const Bufs& b = c->bufs;
+    hipStream_t s = c->stream;
+    // handed exactly the positive list rmcv_filter_lightblobs returned last?  then it is already on the device
+    const bool resident = c->res_nb >= 0 && n_blobs == c->res_nb &&
+                          (n_blobs == 0 || memcmp(blobs, c->h_blobs, (size_t)n_blobs * sizeof(rmcv_lightblob)) == 0);
+    if (!resident) {
+        rc = rmcv_batch_sync(c);
+        if (rc) return rc;
+        resident_none(c);
+        int32_t z = 0;
+        if (n_blobs) HIPCHK(c, hipMemcpy(b.blobs, blobs, (size_t)n_blobs * sizeof(rmcv_lightblob), hipMemcpyHostToDevice), "H2D blobs");
+        HIPCHK(c, hipMemcpy(b.n_blobs, &n_blobs, 4, hipMemcpyHostToDevice), "H2D");
+        HIPCHK(c, hipMemcpy(b.status, &z, 4, hipMemcpyHostToDevice), "H2D");
+    }
     rmcv_params p;
     rmcv_default_params(&p);
     p.angle_diff_max = angle_diff_max;
@@ -673,15 +884,19 @@ int rmcv_filter_armours(rmcv_ctx* c, const rmcv_lightblob* blobs, int n_blobs, f
     p.camp = enemy;
     Geom g1 = c->geom;
     g1.n_frames = 1;
-    HIPCHK(c, launch_armours(g1, c->bufs, c->lim, p, c->stream), "k_armours");
-    HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
-    int32_t na = 0, st = 0;
-    HIPCHK(c, hipMemcpy(&na, c->bufs.n_armours, 4, hipMemcpyDeviceToHost), "D2H");
-    HIPCHK(c, hipMemcpy(&st, c->bufs.status, 4, hipMemcpyDeviceToHost), "D2H");
+    if (resident) HIPCHK(c, launch_status_clear(g1, b, RMCV_FRAME_OVF_ARMOURS, s), "k_status_clear");
+    HIPCHK(c, launch_armours(g1, b, c->lim, p, s), "k_armours");
+    HIPCHK(c, launch_gather3(b.n_armours, b.status, b.status, c->d_hdr, s), "k_gather3");
+    HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
+    const int aw = std::min(SF_ARM_WIN, c->lim.max_armours);
+    HIPCHK(c, hipMemcpyAsync(c->h_armours, b.armours, (size_t)aw * sizeof(rmcv_armour), hipMemcpyDeviceToHost, s), "D2H armours");
+    HIPCHK(c, hipStreamSynchronize(s), "sync");
+    const int32_t na = c->h_hdr[0], st = c->h_hdr[1];
     if (n_armours) *n_armours = na;
     if (st & RMCV_FRAME_OVF_ARMOURS) return fail(c, RMCV_ERR_CAPACITY, "context limit exceeded (max_armours)");
+    if (na > aw) HIPCHK(c, hipMemcpy(c->h_armours + aw, b.armours + aw, (size_t)(na - aw) * sizeof(rmcv_armour), hipMemcpyDeviceToHost), "D2H armours");
     if (na > armours_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
-    if (armours_out && na) HIPCHK(c, hipMemcpy(armours_out, c->bufs.armours, (size_t)na * sizeof(rmcv_armour), hipMemcpyDeviceToHost), "D2H armours");
+    if (armours_out && na) memcpy(armours_out, c->h_armours, (size_t)na * sizeof(rmcv_armour));
     return RMCV_OK;
 }
 
@@ -802,6 +1017,7 @@ int rmcv_locate_armours(rmcv_ctx* c, const rmcv_armour* armours, int n, const do
     hipSetDevice(c->device);
     int rc = rmcv_batch_sync(c);
     if (rc) return rc;
+    resident_none(c);
     static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     HIPCHK(c, hipMemcpy(c->bufs.armours, armours, (size_t)n * sizeof(rmcv_armour), hipMemcpyHostToDevice), "H2D armours");
     HIPCHK(c, hipMemcpy(c->bufs.n_armours, &n, 4, hipMemcpyHostToDevice), "H2D");
@@ -937,7 +1153,6 @@ int rmcv_find_lightblobs(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stri
     rmcv_params p;
     rmcv_default_params(&p);
     HIPCHK(c, launch_match(c->geom, c->bufs, c->lim, p, *lp, 0, true, false, c->stream), "k_match");
-    c->last_stream = c->stream;
     int32_t nb = 0;
     rc = rmcv_batch_get_blobs(c, 0, blobs_out, blobs_cap, &nb, blob_src);
     if (rc) return rc;

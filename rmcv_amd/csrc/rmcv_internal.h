@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <tuple>
+#include <utility>
+
 #include "../../include/rmcv_abi.h"
 
 namespace rmcv {
@@ -13,6 +16,8 @@ namespace rmcv {
 // every row and one zero row above and below the image, so a 3x3 neighbourhood never needs a
 // bounds check:  word(y, k) lives at (y + 1) * prow + (k + 1).
 struct Geom {
+    int device;          // HIP device of the owning context: per-device launch state (function attributes) is indexed by it
+    int n_cu;            // compute units of that device (sizes the persistent grid of k_binary)
     int n_frames;
     int w, h;
     int stride;          // bytes between rows of the BGR input
@@ -33,8 +38,8 @@ struct Bufs {
     const uint8_t* frames; // BGR input (owned upload buffer or borrowed)
     uint8_t* binary;       // [frame][h][w]          0/255           (imgproc.cpp:74 returns it)
     uint64_t* bits;        // [frame] padded plane F (closed binary as bits)
-    int* strip_ctr;        // [8] per-XCD strip queue heads of k_binary (free-running, never reset)
-    uint32_t* strip_base;  // HOST word owned by the context: value every queue head has when the next k_binary launch starts
+    int* strip_ctr;        // [8] per-XCD strip queue heads of k_binary + [8] = workgroups of the launch that have drawn their
+                           // last strip; the last one to leave zeroes all nine, so every launch starts from 0 with no host mirror
     uint32_t* rowmask;     // [frame][h]  bit k: word k of row y of F is non-zero (rows are h apart; k_binary writes them)
     uint64_t* lab;         // [frame] padded plane: pixel was visited by a border trace
     uint64_t* neg;         // [frame] padded plane: ... and got the negative ("right exit") label
@@ -72,6 +77,26 @@ struct Bufs {
     double* poses;         // [frame][max_armours][9]  rvec | tvec | world position
 };
 
+static constexpr int MAX_DEVICES = 64; // per-device launch state (hipFuncSetAttribute is per device) is kept in arrays of this size
+
+// Launch a kernel and return the status of THIS launch.  hipLaunchKernelGGL reports errors only through the calling thread's
+// sticky last-error slot, which may still hold the error of an unrelated earlier HIP call of the host application (one it
+// handled by return code): reading that slot after a launch would turn a launch that ran into a reported failure.
+template <typename... P, size_t... I>
+inline hipError_t launch_tuple(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t s, std::tuple<P...>& vals,
+                               std::index_sequence<I...>)
+{
+    void* ptrs[] = {static_cast<void*>(const_cast<typename std::remove_const<P>::type*>(&std::get<I>(vals)))...};
+    return hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, s);
+}
+template <typename... P, typename... A>
+inline hipError_t launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t s, A&&... a)
+{
+    static_assert(sizeof...(P) == sizeof...(A), "argument count differs from the kernel's parameter list");
+    std::tuple<P...> vals{static_cast<P>(a)...};
+    return launch_tuple(kernel, grid, block, lds, s, vals, std::index_sequence_for<P...>{});
+}
+
 // kernel launchers (each enqueues on `s` and returns the launch error)
 hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, const rmcv_legacy_params& lp,
                         int mode, bool with_frames, bool pairs, hipStream_t s);
@@ -84,11 +109,13 @@ hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const
 hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
                                   int32_t* d_frame_offs, hipStream_t s);
+hipError_t launch_status_clear(const Geom& g, const Bufs& b, int mask, hipStream_t s); // status[f] &= ~mask
 hipError_t launch_classify(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 // stage-wise helpers: binary (host-supplied 0/255 image) -> bit plane
 hipError_t launch_pack_bits(const Geom& g, const Bufs& b, hipStream_t s);
 // contours in findContours order as CSR (for download); d_offs has max_contours+1 entries per frame
 hipError_t launch_pack_contours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_point* d_pts_out, int32_t* d_offs_out,
-                                hipStream_t s);
+                                int32_t* d_hdr /* nullable: frame 0's {n_contours, n_points, status} */, hipStream_t s);
+hipError_t launch_gather3(const int32_t* a, const int32_t* b, const int32_t* c, int32_t* d_out, hipStream_t s); // d_out[0..2] = *a, *b, *c
 
 } // namespace rmcv

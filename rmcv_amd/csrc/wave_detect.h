@@ -90,6 +90,50 @@ __device__ __forceinline__ void tri_index(int e, int k, int* a, int* b)
     *b = r + rem;
 }
 
+// Two steps of iterative refinement x += pinv(G) A^T (b - A x) of a normal-equation solution (oracle/rmcv_oracle.c
+// normal_refine): the n x K design matrix is never stored, every lane makes the rows of ITS points (i = lane, lane + 64, ...,
+// in increasing i), forms their residuals against the wave-uniform x and accumulates K partial sums; the partial sums are
+// reduced by the butterfly of wave_sum_f64 (strides 32 .. 1) -- the oracle adds in exactly this shape.
+template <int K, typename F>
+__device__ __forceinline__ void normal_refine(NormalFac& Fac, int n, int lane, double bconst, double* x /* [5] */, F make_row)
+{
+    LaneVec xv(lane); // x across the lanes of one register: inside the point loop its entries are scalar operands (v_readlane)
+#pragma unroll
+    for (int a = 0; a < K; a++) xv.reg = lane == a ? x[a] : xv.reg;
+    for (int step = 0; step < 2; step++) {
+        double xs[K];
+#pragma unroll
+        for (int a = 0; a < K; a++) xs[a] = xv.get(a);
+        // one accumulator at a time (the rows are cheap to make again, registers are not: the sparse kernel's budget is 160)
+        LaneVec h(lane);
+#pragma unroll 1
+        for (int a = 0; a < K; a++) {
+            double acc = 0.0;
+#pragma unroll 1
+            for (int i = lane; i < n; i += 64) {
+                double row[K];
+                make_row(i, row);
+                double t = row[0] * xs[0];
+#pragma unroll
+                for (int b = 1; b < K; b++) t += row[b] * xs[b];
+                const double r = bconst - t;
+                double ra = row[0];
+#pragma unroll
+                for (int b = 1; b < K; b++) ra = a == b ? row[b] : ra;
+                acc += ra * r;
+            }
+            const double ha = wave_sum_f64(acc);
+            h.reg = lane == a ? ha : h.reg;
+        }
+        double dx[5];
+        normal_apply(Fac, h, dx, lane);
+#pragma unroll
+        for (int a = 0; a < K; a++) xv.reg = lane == a ? xs[a] + dx[a] : xv.reg;
+    }
+#pragma unroll
+    for (int a = 0; a < K; a++) x[a] = xv.get(a);
+}
+
 // cv::fitEllipseDirect (objdetect.cpp:68) for one contour, by one wavefront.  sumx/sumy = integer coordinate sums.
 // returns 0 = direct solution, 1 = general fit.  All results are wave-uniform.
 #ifdef RMCV_PROFILE
@@ -168,16 +212,16 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
         if (lane < 15) tri_index(lane, 5, &la, &lb);
         else { la = lane < 20 ? lane - 15 : 0; lb = -1; }
         for (int iter = 0; iter < 2; iter++) {
-            const double acc = seq_sum_products<5>(n, lane, L, 20, la, lb, 10000.0, [&](int i, double* r) {
+            auto row5 = [&](int i, double* r) {
                 float ox = 0, oy = 0;
                 if (iter) get_ofs(i, eps, &ox, &oy);
                 const float fx = ((float)pts[i].x + ox) - cx, fy = ((float)pts[i].y + oy) - cy;
                 const double px = fx * scale, py = fy * scale;
                 r[0] = -px * px; r[1] = -py * py; r[2] = -px * py; r[3] = px; r[4] = py;
-            });
+            };
+            const double acc = seq_sum_products<5>(n, lane, L, 20, la, lb, 10000.0, row5);
             if (lane < 20) L.dm[lane] = acc;
             __builtin_amdgcn_wave_barrier();
-            double wmax, wmin;
             LaneVec G(lane), g(lane);
             { // lane a*5+b takes G(a,b) = G(b,a) from the upper-triangle sums; lane a takes g(a)
                 const int a = lane / 5, b = lane - 5 * a;
@@ -187,11 +231,15 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
                 g.reg = lane < 5 ? L.dm[15 + lane] : 0.0;
             }
             __builtin_amdgcn_wave_barrier();
-            normal_solve(G, g, 5, gfp, &wmax, &wmin, lane);
+            NormalFac Fac(lane);
+            double wmax, wmin;
+            normal_factor(G, 5, Fac, &wmax, &wmin);
             if (iter == 0 && wmax * FLT_EPSILON > wmin) {
                 eps = (float)(s / (n * 2) * 1e-3);
                 continue;
             }
+            normal_apply(Fac, g, gfp, lane);
+            normal_refine<5>(Fac, n, lane, 10000.0, gfp, row5);
             break;
         }
         FSTAMP(4);
@@ -199,13 +247,14 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
         if (lane < 6) tri_index(lane, 3, &la, &lb);
         else { la = lane < 9 ? lane - 6 : 0; lb = -1; }
         const double r0 = rp[0], r1 = rp[1];
-        const double acc = seq_sum_products<3>(n, lane, L, 9, la, lb, 1.0, [&](int i, double* r) {
+        auto row3 = [&](int i, double* r) {
             float ox = 0, oy = 0;
             if (eps != 0.0f) get_ofs(i, eps, &ox, &oy);
             const float fx = ((float)pts[i].x + ox) - cx, fy = ((float)pts[i].y + oy) - cy;
             const double px = fx * scale, py = fy * scale;
             r[0] = (px - r0) * (px - r0); r[1] = (py - r1) * (py - r1); r[2] = (px - r0) * (py - r1);
-        });
+        };
+        const double acc = seq_sum_products<3>(n, lane, L, 9, la, lb, 1.0, row3);
         if (lane < 9) L.dm[lane] = acc;
         __builtin_amdgcn_wave_barrier();
         LaneVec G(lane), g(lane);
@@ -218,7 +267,11 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
         }
         __builtin_amdgcn_wave_barrier();
         FSTAMP(5);
-        normal_solve(G, g, 3, gfp, 0, 0, lane);
+        NormalFac Fac(lane);
+        double wmax3, wmin3;
+        normal_factor(G, 3, Fac, &wmax3, &wmin3);
+        normal_apply(Fac, g, gfp, lane);
+        normal_refine<3>(Fac, n, lane, 1.0, gfp, row3);
         general_finish(gfp, rp, scale, cx, cy, box);
         FSTAMP(6);
     }

@@ -254,20 +254,35 @@ def test_golden_vectors_next_rows():
 
 
 def test_libm_mode_agrees_on_vertices():
-    """oracle with the host libm (what the reference links) vs oracle with pinned_math.h (the GPU contract):
-    the armour vertex lists must be identical on the test stream"""
+    """oracle with the host libm (what the reference links) vs oracle with pinned_math.h (the GPU contract) on 512 stream frames
+    (both variants): light blobs and the armour vertex lists -- the deliverable -- must be IDENTICAL.  `icon` / `bounding_box` go
+    through the float overloads sinf / cosf / atan2f (src/core.cpp:335-337), whose last bit is the platform libm's business
+    (glibc's are not correctly rounded; pinned_math.h rounds a double evaluation): there the two modes may differ, by one
+    float ulp at most and in well under 1 % of the coordinates -- asserted, so that a defect in pinned_math.h (shared by the
+    oracle and the kernels, i.e. common-mode for every GPU test) cannot hide behind this test."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from rmcv_amd import synth
-    n_arm = icon_diff = 0
-    for i in range(24):
-        f = synth.frame(5000 + i, 1280, 1024, O.CAMP_BLUE, i % 2)
-        O.set_math_mode(0)
-        a = O.detect_frame(f)
-        O.set_math_mode(1)
-        b = O.detect_frame(f)
-        O.set_math_mode(0)
+    n = 512
+    with ThreadPoolExecutor(8) as ex:
+        frames = list(ex.map(lambda i: synth.frame(5000 + i, 1280, 1024, O.CAMP_BLUE, i % 2), range(n)))
+    O.set_math_mode(0)
+    A = [O.detect_frame(f) for f in frames]
+    O.set_math_mode(1)
+    B = [O.detect_frame(f) for f in frames]
+    O.set_math_mode(0)
+    n_arm = n_val = n_diff = 0
+    for a, b in zip(A, B):
         assert a["blobs"].tobytes() == b["blobs"].tobytes()
         assert a["armours"]["vertices"].tobytes() == b["armours"]["vertices"].tobytes()
+        assert np.array_equal(a["armours"]["blob_i"], b["armours"]["blob_i"]) and np.array_equal(a["armours"]["blob_j"], b["armours"]["blob_j"])
         n_arm += len(a["armours"])
-        icon_diff += int(np.count_nonzero(a["armours"]["icon"] != b["armours"]["icon"]))
-    assert n_arm > 20
-    print("icon coordinates differing between libm and pinned math: %d of %d" % (icon_diff, n_arm * 8))
+        for key in ("icon", "bbox"):
+            x, y = a["armours"][key].ravel(), b["armours"][key].ravel()
+            n_val += x.size
+            d = x != y
+            n_diff += int(d.sum())
+            if d.any():      # never more than one float ulp apart
+                assert np.all((np.nextafter(x[d], y[d]) == y[d])), (key, x[d], y[d])
+    assert n_arm > 1000
+    assert n_diff * 100 < n_val, (n_diff, n_val)
