@@ -410,6 +410,54 @@ def main():
                                            "hbm_frac": round(n * 3 * W * H / d3 / 1e9 / HBM_PEAK_GBS, 4),
                                            "note": "same armour lists; the 0/255 image is not materialised"}
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- the per-frame drop-in path (outside the timed region): the three C-ABI calls exactly as include/rmcv_shim.hpp issues
+        # them for an unchanged executable/main.cpp:172-176, on ONE host frame at a time (pageable memory, as a cv::Mat is)
+        import ctypes as C
+        from rmcv_amd import OPT_FRAME_UPLOAD
+        from rmcv_amd.abi import ARMOUR, LIGHTBLOB, POINT, lib, ptr
+        L = lib()
+        sf = {}
+        c1 = Context(device=local_rank, max_frames=1, max_width=W, max_height=H)
+        img = np.ascontiguousarray(host[0])
+        binary = np.empty((H, W), np.uint8)
+        pts, offs = np.empty(c1.limits.max_points, POINT), np.empty(c1.limits.max_contours + 1, np.int32)
+        blobs, neg = np.empty(c1.limits.max_blobs, LIGHTBLOB), np.empty(c1.limits.max_contours, np.int32)
+        arms = np.empty(c1.limits.max_armours, ARMOUR)
+        nc, npt, nb, nn, na = (C.c_int32(0) for _ in range(5))
+
+        def one_frame(want_binary=True):
+            t = [time.perf_counter()]
+            rc = L.rmcv_extract_color(c1._h, ptr(img), W, H, 3 * W, CAMP_BLUE, 80, MORPH_CLOSE, ptr(binary) if want_binary else None,
+                                      ptr(pts), len(pts), ptr(offs), len(offs) - 1, C.byref(nc), C.byref(npt))
+            t.append(time.perf_counter())
+            rc |= L.rmcv_filter_lightblobs(c1._h, ptr(pts), ptr(offs), nc.value, C.c_float(70.0), C.c_float(1.5), C.c_float(80.0),
+                                           C.c_double(10.0), C.c_double(99999.0), CAMP_BLUE, ptr(blobs), len(blobs), C.byref(nb), None,
+                                           ptr(neg), C.byref(nn))
+            t.append(time.perf_counter())
+            rc |= L.rmcv_filter_armours(c1._h, ptr(blobs), nb.value, C.c_float(12.0), C.c_float(22.0), C.c_float(0.4), CAMP_BLUE,
+                                        ptr(arms), len(arms), C.byref(na))
+            t.append(time.perf_counter())
+            assert rc == 0
+            return [(t[i + 1] - t[i]) * 1e3 for i in range(3)]
+        for mode, name in ((1, "pinned_staging"), (0, "runtime_pageable"), (2, "registered_in_place")):
+            c1.set_option(OPT_FRAME_UPLOAD, mode)
+            for _ in range(5):
+                one_frame()
+            m = np.array([one_frame() for _ in range(60)])
+            tot = np.sort(m.sum(1))
+            sf[name] = {"median_ms": round(float(tot[len(tot) // 2]), 4), "min_ms": round(float(tot[0]), 4),
+                        "extract_color_ms": round(float(np.median(m[:, 0])), 4), "filter_lightblobs_ms": round(float(np.median(m[:, 1])), 4),
+                        "filter_armours_ms": round(float(np.median(m[:, 2])), 4)}
+        c1.set_option(OPT_FRAME_UPLOAD, 1)
+        m = np.array([one_frame(False) for _ in range(60)])
+        sf["pinned_staging_without_binary_image"] = {"median_ms": round(float(np.median(m.sum(1))), 4)}
+        sf["armours"] = int(na.value)
+        sf["note"] = ("one %dx%d host frame per call chain, results copied back to host after every call (what rm::extract_color / "
+                      "filter_lightblobs / filter_armours return); 60 chains per mode; PCIe-inclusive, never `value`" % (W, H))
+        c1.close()
+        out["single_frame_ms"] = sf
+
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O                                   # checker/baseline only, never the product path
@@ -436,6 +484,13 @@ def main():
                 tot += len(cpu_frame(f))
             passes += 1
         dc = time.perf_counter() - t0
+        if "single_frame_ms" in out:
+            ts = []
+            for _ in range(30):
+                t1 = time.perf_counter()
+                cpu_frame(0)
+                ts.append((time.perf_counter() - t1) * 1e3)
+            out["single_frame_ms"]["cpu_port_median_ms"] = round(float(np.median(ts)), 4)
         out["cpu_baseline"] = {"value": round(passes * m / dc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": "%d passes over the first %d frames of the same batch (%.1f s), oracle/ full path, 1 thread "
                                          "(the reference runs detection on one process_thread)" % (passes, m, dc),

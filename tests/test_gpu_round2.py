@@ -149,7 +149,7 @@ def test_per_frame_handover_only_when_bytes_match(ctx, oracle):
 def test_per_frame_results_beyond_the_copy_windows(oracle):
     """more contours / points / blobs / armours than the speculative download windows hold (1024 / 8192 / 64 / 32)"""
     c = Context(device=0, max_frames=1, max_width=1280, max_height=1024, max_contours=8192, max_points=1 << 18,
-                max_blobs=1024, max_armours=2048)
+                max_blobs=1024, max_armours=4096)
     rng = np.random.default_rng(5)
     img = rng.integers(0, 40, (1024, 1280, 3), dtype=np.uint8)
     img[rng.random((1024, 1280)) < 0.004] = (255, 200, 0)        # ~5000 specks: contours beyond the offs window
