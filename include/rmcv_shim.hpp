@@ -143,9 +143,11 @@ inline std::vector<armour> filter_armours(std::vector<lightblob>& lightblobs, co
     std::vector<armour> armours;
     armours.reserve(na);
     for (int k = 0; k < na; k++) {
-        // the reference's own constructor allocates the per-target Kalman state (core.cpp:21); the geometry
-        // members are then overwritten with the device results (identical bits, tests/test_gpu_parity.py)
-        armour a({lightblobs[out[k].blob_i], lightblobs[out[k].blob_j]});
+        // rm::armour has one constructor, armour(std::vector<lightblob>) (include/core.h:117): handed anything but two light
+        // blobs it returns right after allocating the per-target Kalman state (src/core.cpp:21-23) -- so an EMPTY list buys the
+        // object (with its own filter matrices, as every reference armour has) without running the geometry of
+        // src/core.cpp:25-48 on the CPU a second time; the device results are then stored into the public members.
+        armour a{std::vector<lightblob>{}};
         for (int i = 0; i < 4; i++) {
             a.icon[i] = {out[k].icon[i][0], out[k].icon[i][1]};
             a.vertices[i] = {out[k].vertices[i][0], out[k].vertices[i][1]};

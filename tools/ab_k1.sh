@@ -1,8 +1,16 @@
-timeout -k 10 200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "binary or full_path or geometry" 2>&1 | tail -1
-RMCV_K1_LOADV=0 timeout -k 10 200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "binary or full_path or geometry" 2>&1 | tail -1
-for lv in 0 1; do for v in librmcv_hip var_neither; do
-  RMCV_K1_LOADV=$lv RMCV_LIB_PATH=$PWD/rmcv_amd/lib/$v.so timeout -k 10 100 python bench.py --steps 10 --cpu-frames 0 --streams 1 > gpurun_out/ab.log 2>&1
-  python3 -c "
-import json
-j=json.loads(open('gpurun_out/ab.log').read().strip().splitlines()[-1]); print('LOADV$lv $v', j['stage_ms']['binary'], j['roofline']['achieved'], j['c2_binary_only'])"
-done; done
+# dev tool: same-box A/B of k_binary builds/knobs with tools/k1_bench.py
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/abk1
+{
+for rep in 1 2; do
+for g in 2 4; do
+echo "== base groups $g"; python tools/k1_bench.py $g
+echo "== LOADV=1 (coalesced through LDS) groups $g"; RMCV_K1_LOADV=1 python tools/k1_bench.py $g
+echo "== nt loads, strided, groups $g"; RMCV_LIB_PATH=$PWD/rmcv_amd/lib/var_ntl.so python tools/k1_bench.py $g
+echo "== nt loads + LOADV=1 groups $g"; RMCV_LIB_PATH=$PWD/rmcv_amd/lib/var_ntl.so RMCV_K1_LOADV=1 python tools/k1_bench.py $g
+done
+done
+echo "== nt loads + LOADV=1 groups 1"; RMCV_LIB_PATH=$PWD/rmcv_amd/lib/var_ntl.so RMCV_K1_LOADV=1 python tools/k1_bench.py 1
+echo "== nt loads + LOADV=1 groups 3"; RMCV_LIB_PATH=$PWD/rmcv_amd/lib/var_ntl.so RMCV_K1_LOADV=1 python tools/k1_bench.py 3
+echo "== nt loads + LOADV=1 groups 6"; RMCV_LIB_PATH=$PWD/rmcv_amd/lib/var_ntl.so RMCV_K1_LOADV=1 python tools/k1_bench.py 6
+} > gpurun_out/abk1/out.txt 2>&1
+grep -E "^==|k_binary|checksum" gpurun_out/abk1/out.txt
