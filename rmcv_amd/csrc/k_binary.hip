@@ -32,28 +32,6 @@ namespace rmcv {
 #endif
 static constexpr int SR = RMCV_SR; // strip rows per workgroup
 
-// streaming hints (dev knobs): frames are read once, `binary` is written once
-__device__ __forceinline__ uint4 ld_stream(const uint4* p)
-{
-#ifdef RMCV_NT_LOAD
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void st_stream(uint4* p, uint4 v)
-{
-#ifndef RMCV_NO_NT_STORE
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
-#else
-    *p = v;
-#endif
-}
-
 __device__ __forceinline__ uint32_t expand4(uint32_t nib)
 { // 4 mask bits -> 4 bytes of 0x00/0xFF
     return (((nib & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
@@ -93,11 +71,19 @@ __device__ __forceinline__ uint32_t thresh16(const uint32_t d[12], int lb)
 __device__ __forceinline__ int div_r(int n, uint32_t r) { return r ? (int)__umulhi((uint32_t)n, r) : n; }
 
 // lb is pre-clamped on the host to [1, 256]: lb <= 0 means "everything passes" (lb = -1 flag).
-// LOADV (FAST only): 0 = each lane loads its own 48 contiguous bytes (lane stride 48 B);
-//                    1 = wave-coalesced loads (lane stride 16 B, 3 x 1 KiB per wave) transposed through a
-//                        wave-private 3 KiB LDS buffer; needs contiguous rows (stride == 3*w)
-template <int CA, int CB, bool FAST, int LOADV>
-__global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride,
+// FAST (w a multiple of 64, 16-byte aligned rows, every extent below 4 GiB): the vector-memory instructions are UNCONDITIONAL
+// raw-buffer operations.  A lane (or item) that has nothing to move uses an offset beyond the buffer's extent: the hardware
+// answers such a load with zeros -- a row outside the image thresholds to 0 by itself -- and drops such a store.  Round 1 had
+// ordinary loads behind per-lane predicates: per 16-pixel item that was ~70 instructions of EXEC save/restore, branches and
+// register zeroing around the 60 that threshold (profiles/r02a_k_binary_ablations.txt: 0.14-0.18 ms of the 0.28 with the
+// loads compiled out).
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+static constexpr uint32_t OOB = 0xFFFFFF00u; // voffset of a lane that moves nothing (extents are checked below 4 GiB - 256)
+static constexpr int RSRC3 = 0x00020000;     // raw buffer descriptor word 3, gfx9 family
+
+template <int CA, int CB, bool FAST>
+__global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride, int n_frames,
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
@@ -146,84 +132,48 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     const uint8_t* frame = frames + (int64_t)f * frame_pitch;
 
     // ---------------- phase 1: load + threshold -> T
-    if (FAST && LOADV == 1) {
-        const int items = srh * wq;
-        const int lane = tid & 63;
-        uint8_t* wbuf = reinterpret_cast<uint8_t*>(smem + (size_t)2 * (SR + 4) * ww) + (tid >> 6) * 3072;
-        const int64_t frame_bytes = (int64_t)h * stride;
-        const int64_t strip_off = (int64_t)(y0 - halo) * stride;
-        int rr = tid / wq, q = tid - rr * wq;
-        const int dr = 256 / wq, dq = 256 - dr * wq;
-        for (int it = tid; it - lane < items; it += 256) {
-            const int64_t seg = strip_off + (int64_t)(it - lane) * 48 + lane * 16;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int64_t off = seg + k * 1024;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (off >= 0 && off < frame_bytes) v = ld_stream(reinterpret_cast<const uint4*>(frame + off));
-                *reinterpret_cast<uint4*>(wbuf + k * 1024 + lane * 16) = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-            const uint4* src = reinterpret_cast<const uint4*>(wbuf + lane * 48);
-            uint4 v0 = src[0], v1 = src[1], v2 = src[2];
-            __builtin_amdgcn_wave_barrier();
-            uint32_t d[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-            const int y = y0 - halo + rr;
-            uint32_t m = 0;
-            if (it < items && y >= 0 && y < h) m = all_pass ? 0xFFFFu : thresh16<CA, CB>(d, lb);
-            uint32_t v = m << (16 * (q & 1));
-            v |= __shfl_xor(v, 1);
-            uint32_t o = __shfl_xor(v, 2);
-            if (it < items && (q & 3) == 0) T[rr * ww + (q >> 2)] = ((uint64_t)o << 32) | v;
-            rr += dr;
-            q += dq;
-            if (q >= wq) { q -= wq; rr++; }
-        }
-    } else if (FAST) {
+    if (FAST) {
         // U items per thread per iteration: all 3*U loads are issued before the first threshold (memory-level
-        // parallelism per wave), then the items are reduced to bit masks and merged into LDS words
+        // parallelism per wave); every 16-bit mask goes straight to its place in the LDS plane (ds_write_b16)
         constexpr int U = RMCV_K1_UNROLL;
         const int items = srh * wq;
+        const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(frames), 0, (int)((int64_t)(n_frames - 1) * frame_pitch + (int64_t)(h - 1) * stride + 3 * w), RSRC3);
+        const uint32_t fbase = (uint32_t)((int64_t)f * frame_pitch);
         for (int it0 = tid; it0 < items; it0 += 256 * U) {
-            uint4 v[U][3];
-            int rr_[U], q_[U];
-            bool ok[U];
+            u32x4v v[U][3];
+            int rq_[U]; // row of the strip << 16 | 16-pixel group; -1: beyond the strip's items
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int it = it0 + 256 * u;
                 const int rq = div_r(it, r_wq);
-                q_[u] = it - rq * wq;
+                const int q = it - rq * wq;
                 // neighbouring strips share halo rows: odd strips sweep top->bottom, even strips bottom->top, so a
                 // shared row is requested by both workgroups at about the same time and one of them hits in L2
-                rr_[u] = (L & 1) ? rq : srh - 1 - rq;
-                if (it >= items) rr_[u] = 0;
-                const int y = y0 - halo + rr_[u];
-                ok[u] = it < items && y >= 0 && y < h;
+                const int rr = (L & 1) ? rq : srh - 1 - rq;
+                const int y = y0 - halo + rr;
+                const bool ok = it < items && y >= 0 && y < h;
+                rq_[u] = it < items ? (rr << 16) | q : -1;
 #ifdef RMCV_K1_NOLOAD
-                if (ok[u] && lb > 1000) {
+                const uint32_t off = OOB;
 #else
-                if (ok[u]) {
+                const uint32_t off = ok ? fbase + (uint32_t)y * (uint32_t)stride + (uint32_t)q * 48u : OOB;
 #endif
-                    const uint4* src = reinterpret_cast<const uint4*>(frame + (int64_t)y * stride + q_[u] * 48);
-                    v[u][0] = ld_stream(src);
-                    v[u][1] = ld_stream(src + 1);
-                    v[u][2] = ld_stream(src + 2);
-                } else {
-                    v[u][0] = v[u][1] = v[u][2] = make_uint4(0, 0, 0, 0);
-                }
+                v[u][0] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 0, 0);
+                v[u][1] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 16, 0);
+                v[u][2] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 32, 0);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t d[12] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w, v[u][1].x, v[u][1].y,
                                         v[u][1].z, v[u][1].w, v[u][2].x, v[u][2].y, v[u][2].z, v[u][2].w};
-                uint32_t m = 0;
-                if (ok[u]) m = all_pass ? 0xFFFFu : thresh16<CA, CB>(d, lb);
-                const int q = q_[u];
-                // merge the 4 lanes of a word (lanes are word-aligned: wq % 4 == 0, 256 % 4 == 0)
-                uint32_t x = m << (16 * (q & 1));
-                x |= __shfl_xor(x, 1);
-                const uint32_t o = __shfl_xor(x, 2);
-                if (it0 + 256 * u < items && (q & 3) == 0) T[rr_[u] * ww + (q >> 2)] = ((uint64_t)o << 32) | x;
+                const int rr = rq_[u] >> 16, q = rq_[u] & 0xFFFF;
+                uint32_t m = thresh16<CA, CB>(d, lb); // zeros (a row outside the image) give 0: lb >= 1
+                if (all_pass) {
+                    const int y = y0 - halo + rr;
+                    m = (y >= 0 && y < h) ? 0xFFFFu : 0u;
+                }
+                if (rq_[u] >= 0) reinterpret_cast<uint16_t*>(T + rr * ww)[q] = (uint16_t)m;
             }
         }
     } else {
@@ -313,7 +263,39 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
         rowmask[(int64_t)f * h + y0 + tid] = m;
     }
     // ---------------- phase 4: expand to bytes + bit plane
-    {
+    if (FAST) {
+        const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(binary, 0, binary ? (int)((int64_t)n_frames * w * h) : 0, RSRC3);
+        const __amdgpu_buffer_rsrc_t r_plane = __builtin_amdgcn_make_buffer_rsrc(bits, 0, (int)((int64_t)n_frames * plane_pitch * 8), RSRC3);
+        const uint32_t plane_base = (uint32_t)((int64_t)f * plane_pitch);
+        { // the strip's words -> the frame's bit plane (8 contiguous bytes per lane)
+            const int nw = sr * ww;
+            for (int it = tid; it - (tid & 63) < nw; it += 256) {
+                const int s_ = div_r(it, r_ww), k = it - s_ * ww, y = y0 + s_;
+                const bool ok = it < nw && y < h;
+                uint64_t word = 0;
+                if (ok) word = R[(s_ + halo) * ww + k];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane,
+                                                      ok ? (plane_base + (uint32_t)(y + 1) * (uint32_t)prow + 1u + (uint32_t)k) * 8u : OOB, 0, 0);
+            }
+        }
+        if (binary) { // RMCV_STAGE_NO_IMAGE: the 0/255 byte image is not wanted
+            const int items = sr * wq;
+            const uint32_t bin_base = (uint32_t)((int64_t)f * w * h);
+            for (int it = tid; it - (tid & 63) < items; it += 256) {
+                const int s_ = div_r(it, r_wq), q = it - s_ * wq, y = y0 + s_;
+                const bool ok = it < items && y < h;
+                uint32_t m = 0;
+                if (ok) m = reinterpret_cast<const uint16_t*>(R + (s_ + halo) * ww)[q];
+                const u32x4v o = {expand4(m), expand4(m >> 4), expand4(m >> 8), expand4(m >> 12)};
+#ifdef RMCV_K1_NOSTORE
+                const uint32_t off = OOB;
+#else
+                const uint32_t off = ok ? bin_base + (uint32_t)y * (uint32_t)w + (uint32_t)q * 16u : OOB;
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(o, r_bin, off, 0, 2 /* nt: written once, read by nobody here */);
+            }
+        }
+    } else {
         const int items = sr * wq;
         int s = tid / wq, q = tid - s * wq;
         const int dr = 256 / wq, dq = 256 - dr * wq;
@@ -324,18 +306,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
             if (y < h) {
                 const uint64_t word = R[(s + halo) * ww + (q >> 2)];
                 const uint32_t m = (uint32_t)(word >> (16 * (q & 3))) & 0xFFFFu;
-                if (!binary) { // RMCV_STAGE_NO_IMAGE: the 0/255 byte image is not wanted, only the bit plane below
-                } else if (FAST) {
-                    uint4 o;
-                    o.x = expand4(m);
-                    o.y = expand4(m >> 4);
-                    o.z = expand4(m >> 8);
-                    o.w = expand4(m >> 12);
-#ifdef RMCV_K1_NOSTORE
-                    if (lb > 1000)
-#endif
-                    st_stream(reinterpret_cast<uint4*>(bin + (int64_t)y * w + q * 16), o);
-                } else {
+                if (binary) { // RMCV_STAGE_NO_IMAGE: the 0/255 byte image is not wanted, only the bit plane below
                     for (int p = 0; p < 16; p++) {
                         int x = q * 16 + p;
                         if (x < w) bin[(int64_t)y * w + x] = ((m >> p) & 1) ? 255 : 0;
@@ -369,10 +340,10 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     if (lb <= 0) { all_pass = 1; lb = 1; }
     if (lb > 256) lb = 256;
     const size_t planes = (size_t)2 * (SR + 4) * g.ww * sizeof(uint64_t);
-    const bool fast = (g.w % 64 == 0) && (g.stride % 16 == 0) && (g.frame_pitch % 16 == 0) &&
-                      ((uintptr_t)b.frames % 16 == 0);
-    static const int forced = getenv("RMCV_K1_LOADV") ? atoi(getenv("RMCV_K1_LOADV")) : -1; // dev knob for A/B runs
-    const bool coalesced = fast && g.stride == 3 * g.w && forced == 1; // A/B on MI355X: no faster than per-lane 48 B loads
+    const int64_t lim = 0xFFFFFF00ll; // 32-bit buffer offsets
+    const bool fast = (g.w % 64 == 0) && (g.stride % 16 == 0) && (g.frame_pitch % 16 == 0) && ((uintptr_t)b.frames % 16 == 0) &&
+                      (int64_t)g.n_frames * g.frame_pitch < lim && (int64_t)g.n_frames * g.plane_pitch * 8 < lim &&
+                      (int64_t)g.n_frames * g.w * g.h < lim;
     // persistent grid: `groups` workgroups per CU (RMCV_OPT_PIXEL_GROUPS; RMCV_K1_BPC overrides for A/B runs).  Measured on
     // MI355X: alone the kernel is fastest with 4 (0.257-0.262 ms; 0.277-0.285 with 2, 0.42 with 1) -- the default, for a lone
     // batch.  2 (= 2 of the 8 wave slots and 2 x 80 VGPRs of every SIMD) leaves room for the pixel kernel of the next batch AND
@@ -387,13 +358,12 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     const int per_xcd = (n_blocks + 7) >> 3;
     int taper_head = 0, taper_tail = 0;
     if (taper_on && per_xcd >= 192) { taper_head = 16; taper_tail = 32; }
-#define RMCV_K1_LAUNCH(F, V, LDS)                                                                                              \
-    launch(k_binary<CA, CB, F, V>, dim3(grid), dim3(256), LDS, s, b.frames, g.frame_pitch, g.stride, g.w, g.h, g.ww, lb, all_pass, \
-           morph, image ? b.binary : nullptr, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr, taper_head,  \
-           taper_tail)
-    if (coalesced) return RMCV_K1_LAUNCH(true, 1, planes + 4 * 3072);
-    if (fast) return RMCV_K1_LAUNCH(true, 0, planes);
-    return RMCV_K1_LAUNCH(false, 0, planes);
+#define RMCV_K1_LAUNCH(F)                                                                                                       \
+    launch(k_binary<CA, CB, F>, dim3(grid), dim3(256), planes, s, b.frames, g.frame_pitch, g.stride, g.n_frames, g.w, g.h, g.ww, lb, \
+           all_pass, morph, image ? b.binary : nullptr, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr,      \
+           taper_head, taper_tail)
+    if (fast) return RMCV_K1_LAUNCH(true);
+    return RMCV_K1_LAUNCH(false);
 #undef RMCV_K1_LAUNCH
 }
 
