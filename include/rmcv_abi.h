@@ -261,16 +261,46 @@ int  rmcv_batch_set_base2gripper(rmcv_ctx* ctx, const double* mats, int n_frames
 /* batch: poses in the order of rmcv_batch_get_armours (after a run that included RMCV_STAGE_POSE) */
 int  rmcv_batch_get_poses(rmcv_ctx* ctx, double* rvecs, double* tvecs, double* positions, int cap, int32_t* n_total);
 
-/* ---- tracker bookkeeping: the "next" row SURVEY 8f-4 (src/core.cpp:124-162) -------------------------------------------
- * Host-side predicates over caller memory: the tracker is sequential per target by nature (executable/main.cpp:57-88) and works
- * on a handful of armours.  Only what the reference can observe is provided: the Kalman state of rm::armour::reset / update
- * (src/core.cpp:51-122) is private and never read anywhere in the reference. */
+/* ---- tracker: the "next" row SURVEY 8f-4 (src/core.cpp:51-162, executable/main.cpp:57-88) --------------------------------
+ * Host-side functions over caller memory: the tracker is sequential per target by nature and works on a handful of armours. */
 /* rm::armour::max_IoU (src/core.cpp:144-162): *index = the armour of `list` with the largest IoU of bounding boxes with `self`
  * (first on ties, -1 when none overlaps), *iou = that IoU */
 int rmcv_max_iou(const rmcv_armour* self, const rmcv_armour* list, int n, int32_t* index, float* iou);
 /* rm::armour::identity_max (src/core.cpp:124-142): soft-max vote over an identity histogram; ids ascending (the reference keeps a
  * std::map<int,int>); *max_id = -1 for an empty histogram */
 int rmcv_identity_max(const int32_t* ids, const int32_t* counts, int n, int32_t* max_id, double* prob);
+
+/* rm::armour as the tracking thread holds it, with every field readable (include/core.h:101-129).  The filter is
+ * cv::KalmanFilter(6, 6, 0, CV_64F) (src/core.cpp:21): state [x y z vx vy vz], matrices row-major 6x6 doubles. */
+#define RMCV_TRACK_IDS 32
+typedef struct {
+    rmcv_armour armour;      /* icon / vertices / bounding_box of the observation the target was created from (update() never refreshes them) */
+    int64_t timestamp;       /* ticks of the last observation (core.h:114) */
+    int32_t lost_count;      /* core.h:115 */
+    int32_t identity;        /* core.h:117 */
+    double  position[3];     /* core.h:116 */
+    int32_t initialized;     /* core.h:107 */
+    int32_t n_ids;           /* identity_history (core.h:103): ids ascending, as a std::map iterates */
+    int32_t ids[RMCV_TRACK_IDS], counts[RMCV_TRACK_IDS];
+    double  measurement[6];  /* core.h:106 */
+    double  state_pre[6], state_post[6];
+    double  transition[36], measurement_matrix[36], process_noise_cov[36], measurement_noise_cov[36];
+    double  error_cov_pre[36], error_cov_post[36], gain[36];
+} rmcv_track;
+/* a freshly detected armour as executable/main.cpp:178-194 leaves it: constructor (filter initialised, src/core.cpp:21) +
+ * identity, position, timestamp assigned; call rmcv_track_reset next, as main.cpp:195 does */
+void rmcv_track_init(rmcv_track* t, const rmcv_armour* a, int32_t identity, int64_t timestamp, const double position[3]);
+/* rm::armour::reset (src/core.cpp:51-72); the process loop uses (5e-5, 0.5, 0.05) */
+void rmcv_track_reset(rmcv_track* t, double process_noise, double measurement_noise, double error);
+/* rm::armour::update(const armour& new_observation) (src/core.cpp:74-108).  tick_frequency = cv::getTickFrequency() */
+int  rmcv_track_update(rmcv_track* t, const rmcv_track* observation, double tick_frequency);
+/* rm::armour::update(int64 new_timestamp) (src/core.cpp:110-122) */
+int  rmcv_track_predict(rmcv_track* t, int64_t new_timestamp, double tick_frequency);
+/* one pass of the tracking thread (executable/main.cpp:60-85) over this frame's observations: targets whose bounding box
+ * overlaps an observation by IoU > 0.5 take it (and it leaves the list), the others age (dropped after 26 misses -- with
+ * the reference's skip of the target behind an erased one) or coast; what is left of the observations becomes new targets.
+ * *n_obs is 0 afterwards.  At most 64 observations. */
+int  rmcv_track_step(rmcv_track* tracking, int32_t* n_tracking, int cap, rmcv_track* observations, int32_t* n_obs, double tick_frequency);
 
 /* ---- synthetic stream: host generator, integer-only, bit-reproducible --- */
 int      rmcv_synth_frame(uint8_t* bgr, int w, int h, int stride, uint64_t frame_index, int camp, int variant);

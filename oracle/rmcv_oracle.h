@@ -163,6 +163,25 @@ void orc_locate_armours(const orc_armour* armours, int n, const orc_pnp_config* 
 void orc_max_iou(const orc_armour* self, const orc_armour* list, int n, int32_t* index, float* iou);
 void orc_identity_max(const int32_t* ids /* ascending */, const int32_t* counts, int n, int32_t* max_id, double* prob);
 
+/* tracker state, layout identical to rmcv_track (include/rmcv_abi.h) */
+#define ORC_TRACK_IDS 32
+typedef struct {
+    orc_armour armour;
+    int64_t timestamp;
+    int32_t lost_count, identity;
+    double  position[3];
+    int32_t initialized, n_ids;
+    int32_t ids[ORC_TRACK_IDS], counts[ORC_TRACK_IDS];
+    double  measurement[6], state_pre[6], state_post[6];
+    double  transition[36], measurement_matrix[36], process_noise_cov[36], measurement_noise_cov[36];
+    double  error_cov_pre[36], error_cov_post[36], gain[36];
+} orc_track;
+void orc_track_init(orc_track* t, const orc_armour* a, int32_t identity, int64_t timestamp, const double position[3]);
+void orc_track_reset(orc_track* t, double process_noise, double measurement_noise, double error);
+int  orc_track_update(orc_track* t, const orc_track* observation, double tick_frequency);
+int  orc_track_predict(orc_track* t, int64_t new_timestamp, double tick_frequency);
+int  orc_track_step(orc_track* tracking, int32_t* n_tracking, int cap, orc_track* observations, int32_t* n_obs, double tick_frequency);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,14 @@ LIGHTBLOB = np.dtype([("angle", "<f4"), ("target", "<i4"), ("center", "<f4", (2,
                       ("vertices", "<f4", (4, 2)), ("size", "<f4", (2,))])
 ARMOUR = np.dtype([("icon", "<f4", (4, 2)), ("vertices", "<f4", (4, 2)), ("bbox", "<f4", (4,)),
                    ("blob_i", "<i4"), ("blob_j", "<i4")])
-assert POINT.itemsize == 8 and LIGHTBLOB.itemsize == 56 and ARMOUR.itemsize == 88
+TRACK_IDS = 32
+TRACK = np.dtype([("armour", ARMOUR), ("timestamp", "<i8"), ("lost_count", "<i4"), ("identity", "<i4"), ("position", "<f8", (3,)),
+                  ("initialized", "<i4"), ("n_ids", "<i4"), ("ids", "<i4", (TRACK_IDS,)), ("counts", "<i4", (TRACK_IDS,)),
+                  ("measurement", "<f8", (6,)), ("state_pre", "<f8", (6,)), ("state_post", "<f8", (6,)),
+                  ("transition", "<f8", (6, 6)), ("measurement_matrix", "<f8", (6, 6)), ("process_noise_cov", "<f8", (6, 6)),
+                  ("measurement_noise_cov", "<f8", (6, 6)), ("error_cov_pre", "<f8", (6, 6)), ("error_cov_post", "<f8", (6, 6)),
+                  ("gain", "<f8", (6, 6))])  # rmcv_track
+assert POINT.itemsize == 8 and LIGHTBLOB.itemsize == 56 and ARMOUR.itemsize == 88 and TRACK.itemsize == 2552
 
 OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 CAMP_RED, CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL = 0, 1, 2, -1
@@ -37,7 +44,7 @@ EXPORTS = [
     "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_batch_compact_armours", "rmcv_synth_frame", "rmcv_synth_checksum",
     "rmcv_svm_load", "rmcv_classify_armours", "rmcv_batch_get_identities", "rmcv_batch_get_icons",
     "rmcv_default_pnp_config", "rmcv_pnp_load", "rmcv_locate_armours", "rmcv_batch_set_base2gripper", "rmcv_batch_get_poses",
-    "rmcv_max_iou", "rmcv_identity_max", "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
+    "rmcv_max_iou", "rmcv_identity_max", "rmcv_track_init", "rmcv_track_reset", "rmcv_track_update", "rmcv_track_predict", "rmcv_track_step", "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
 ]
 
 

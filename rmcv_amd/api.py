@@ -204,6 +204,52 @@ class Context:
             raise RmcvError(rc, "rmcv_identity_max")
         return mid.value, pr.value
 
+    # ---------------------------------------------------------------- tracker state (src/core.cpp:51-122, main.cpp:57-88)
+    @staticmethod
+    def track_new(armour, identity, timestamp, position, noise=(5e-5, 0.5, 0.05)):
+        """a detected armour as the process loop hands it to the tracking thread (main.cpp:178-195): constructed, identity /
+        position / timestamp assigned, reset(5e-5, 0.5, 0.05) -> abi.TRACK record"""
+        t = np.zeros(1, abi.TRACK)
+        a = np.ascontiguousarray(armour, ARMOUR).reshape(1)
+        pos = np.ascontiguousarray(position, np.float64)
+        lib().rmcv_track_init(ptr(t), ptr(a), int(identity), C.c_int64(int(timestamp)), ptr(pos))
+        if noise is not None:
+            lib().rmcv_track_reset(ptr(t), C.c_double(noise[0]), C.c_double(noise[1]), C.c_double(noise[2]))
+        return t[0]
+
+    @staticmethod
+    def track_update(track, observation, tick_frequency=1e9):
+        """rm::armour::update(const armour&): returns the updated abi.TRACK record"""
+        t = np.array([track], abi.TRACK)
+        o = np.array([observation], abi.TRACK)
+        rc = lib().rmcv_track_update(ptr(t), ptr(o), C.c_double(tick_frequency))
+        if rc:
+            raise RmcvError(rc, "rmcv_track_update")
+        return t[0]
+
+    @staticmethod
+    def track_predict(track, new_timestamp, tick_frequency=1e9):
+        """rm::armour::update(int64)"""
+        t = np.array([track], abi.TRACK)
+        rc = lib().rmcv_track_predict(ptr(t), C.c_int64(int(new_timestamp)), C.c_double(tick_frequency))
+        if rc:
+            raise RmcvError(rc, "rmcv_track_predict")
+        return t[0]
+
+    @staticmethod
+    def track_step(tracking, observations, cap=64, tick_frequency=1e9):
+        """one pass of the tracking thread's loop (main.cpp:60-85): returns the new tracking list"""
+        buf = np.zeros(cap, abi.TRACK)
+        nt = C.c_int32(len(tracking))
+        if len(tracking):
+            buf[:len(tracking)] = tracking
+        obs = np.array(observations, abi.TRACK).copy() if len(observations) else np.zeros(1, abi.TRACK)
+        no = C.c_int32(len(observations))
+        rc = lib().rmcv_track_step(ptr(buf), C.byref(nt), cap, ptr(obs), C.byref(no), C.c_double(tick_frequency))
+        if rc:
+            raise RmcvError(rc, "rmcv_track_step")
+        return buf[:nt.value].copy()
+
     def run_legacy(self, legacy, params=None, stages=STAGE_ALL, stream=None):
         """batch path with rm::FindLightBlobs (legacy: LegacyParams) in place of rm::filter_lightblobs"""
         self._params = params or default_params()

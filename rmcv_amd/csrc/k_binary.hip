@@ -30,6 +30,9 @@ namespace rmcv {
 #ifndef RMCV_K1_UNROLL
 #define RMCV_K1_UNROLL 4
 #endif
+#ifndef RMCV_K1_LDAUX
+#define RMCV_K1_LDAUX 0 // cache-policy bits of the frame loads (dev knob; 2 = nt)
+#endif
 static constexpr int SR = RMCV_SR; // strip rows per workgroup
 
 __device__ __forceinline__ uint32_t expand4(uint32_t nib)
@@ -159,9 +162,9 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
 #else
                 const uint32_t off = ok ? fbase + (uint32_t)y * (uint32_t)stride + (uint32_t)q * 48u : OOB;
 #endif
-                v[u][0] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 0, 0);
-                v[u][1] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 16, 0);
-                v[u][2] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 32, 0);
+                v[u][0] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 0, RMCV_K1_LDAUX);
+                v[u][1] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 16, RMCV_K1_LDAUX);
+                v[u][2] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 32, RMCV_K1_LDAUX);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {

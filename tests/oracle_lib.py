@@ -302,3 +302,43 @@ def identity_max(history):
     mid, pr = C.c_int32(0), C.c_double(0)
     lib().orc_identity_max(_p(ids), _p(cnt), len(ids), C.byref(mid), C.byref(pr))
     return mid.value, pr.value
+
+
+# ---- tracker state: the oracle's twin of rmcv_track_* ----------------------------------------------------------
+def _track_dtype():
+    from rmcv_amd import abi
+    return abi.TRACK
+
+
+def track_new(armour, identity, timestamp, position, noise=(5e-5, 0.5, 0.05)):
+    t = np.zeros(1, _track_dtype())
+    a = np.ascontiguousarray(armour, ARMOUR).reshape(1)
+    pos = np.ascontiguousarray(position, np.float64)
+    lib().orc_track_init(_p(t), _p(a), int(identity), C.c_int64(int(timestamp)), _p(pos))
+    if noise is not None:
+        lib().orc_track_reset(_p(t), C.c_double(noise[0]), C.c_double(noise[1]), C.c_double(noise[2]))
+    return t[0]
+
+
+def track_update(track, observation, tick_frequency=1e9):
+    t = np.array([track], _track_dtype())
+    o = np.array([observation], _track_dtype())
+    assert lib().orc_track_update(_p(t), _p(o), C.c_double(tick_frequency)) == 0
+    return t[0]
+
+
+def track_predict(track, new_timestamp, tick_frequency=1e9):
+    t = np.array([track], _track_dtype())
+    assert lib().orc_track_predict(_p(t), C.c_int64(int(new_timestamp)), C.c_double(tick_frequency)) == 0
+    return t[0]
+
+
+def track_step(tracking, observations, cap=64, tick_frequency=1e9):
+    buf = np.zeros(cap, _track_dtype())
+    nt = C.c_int32(len(tracking))
+    if len(tracking):
+        buf[:len(tracking)] = tracking
+    obs = np.array(observations, _track_dtype()).copy() if len(observations) else np.zeros(1, _track_dtype())
+    no = C.c_int32(len(observations))
+    assert lib().orc_track_step(_p(buf), C.byref(nt), cap, _p(obs), C.byref(no), C.c_double(tick_frequency)) == 0
+    return buf[:nt.value].copy()

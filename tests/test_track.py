@@ -1,5 +1,6 @@
-"""SURVEY 8f-4, the observable part of the tracker: rm::armour::max_IoU and identity_max (src/core.cpp:124-162).  Host-side
-functions of the C-ABI (no device work), checked against the oracle and against hand-computed answers."""
+"""SURVEY 8f-4, the tracker: rm::armour::max_IoU / identity_max (src/core.cpp:124-162), the filter state of reset / update
+(src/core.cpp:51-122) and the association loop of the tracking thread (executable/main.cpp:57-88).  Host-side functions of the
+C-ABI (no device work), checked against the oracle, against an independent numpy Kalman step and against known answers."""
 import math
 
 import numpy as np
@@ -49,3 +50,141 @@ def test_identity_max():
         assert mid == 2
     hist = {int(k): int(v) for k, v in zip(range(0, 14, 2), [3, 1, 4, 1, 5, 9, 2])}
     assert O.identity_max(hist) == Context.identity_max(hist)
+
+
+# ---------------------------------------------------------------- filter state: reset / update / predict
+TICK = 1e9
+
+
+def obs_at(pos, stamp, identity=3, box=(100, 100, 40, 40), f=Context.track_new):
+    return f(arm(*box), identity, stamp, pos)
+
+
+def test_reset_and_first_update_are_the_references():
+    for new, upd in ((Context.track_new, Context.track_update), (O.track_new, O.track_update)):
+        t = obs_at((1.0, 2.0, 3.0), 1000, f=new)
+        assert np.array_equal(t["measurement_matrix"], np.eye(6)) and np.array_equal(t["error_cov_post"], 0.05 * np.eye(6))
+        assert np.array_equal(t["process_noise_cov"], 5e-5 * np.eye(6)) and np.array_equal(t["measurement_noise_cov"], 0.5 * np.eye(6))
+        A = np.eye(6)
+        A[0, 3] = A[1, 4] = A[2, 5] = 1.0
+        assert np.array_equal(t["transition"], A) and t["initialized"] == 0 and not t["error_cov_pre"].any()
+        # first observation (src/core.cpp:98-106): a correction WITHOUT a prediction -- errorCovPre is still zero, so the gain is
+        # zero, the state stays zero and errorCovPost becomes zero: mirrored, not "fixed"
+        u = upd(t, obs_at((1.0, 2.0, 3.0), 2000, f=new), TICK)
+        assert u["initialized"] == 1 and u["timestamp"] == 2000 and not u["state_post"].any() and not u["error_cov_post"].any()
+        assert u["measurement"].tolist() == [1.0, 2.0, 3.0, 0, 0, 0] and u["n_ids"] == 1 and u["ids"][0] == 3 and u["counts"][0] == 1
+
+
+def test_constant_velocity_target_recovers_position_and_velocity():
+    v = np.array([0.8, -0.3, 0.05])                  # units per second
+    p0 = np.array([10.0, 5.0, 2.0])
+    dt_ticks = 10_000_000                            # 10 ms at 1e9 ticks/s
+    for new, upd in ((Context.track_new, Context.track_update), (O.track_new, O.track_update)):
+        # the reference's first update zeroes the state AND its covariance (see above), so the filter starts out trusting a zero
+        # state and only the process noise (5e-5) lets it move: it needs ~1000 observations to lock on -- then it is exact
+        t = obs_at(p0, 0, f=new)
+        n = 2000
+        for k in range(1, n + 1):
+            t = upd(t, obs_at(p0 + v * (k * dt_ticks / TICK), k * dt_ticks, identity=3 if k % 7 else 5, f=new), TICK)
+        pos = p0 + v * (n * dt_ticks / TICK)
+        assert np.allclose(t["state_post"][:3], pos, atol=1e-6), (t["state_post"], pos)
+        assert np.allclose(t["state_post"][3:], v, atol=1e-6), t["state_post"]
+        assert t["n_ids"] == 2 and t["ids"][:2].tolist() == [3, 5] and t["counts"][:2].sum() == n
+        # src/core.cpp:127 sums exp(count): past 709 observations of one identity that is +inf, every probability NaN, and
+        # identity_max answers -1 -- the reference's behaviour, mirrored by product and oracle alike
+        hist = {int(i): int(c) for i, c in zip(t["ids"][:2], t["counts"][:2])}
+        assert hist[3] > 709 and Context.identity_max(hist)[0] == -1 and O.identity_max(hist)[0] == -1
+        assert Context.identity_max({3: 600, 5: 100})[0] == 3
+
+
+def test_update_equals_an_independent_numpy_kalman_step():
+    """predict + correct with numpy's own linear algebra (np.linalg.solve), to rounding"""
+    rng = np.random.default_rng(3)
+    t = obs_at((0.0, 0.0, 0.0), 0)
+    t = Context.track_update(t, obs_at((0.1, 0.2, 0.3), 5_000_000), TICK)
+    for k in range(2, 30):
+        z = rng.normal(size=3)
+        o = obs_at(z, k * 7_000_000)
+        n = Context.track_update(t, o, TICK)
+        dt = (int(o["timestamp"]) - int(t["timestamp"])) / TICK
+        A = t["transition"].copy()
+        A[0, 3] = A[1, 4] = A[2, 5] = dt
+        x_pre = A @ t["state_post"]
+        P_pre = A @ t["error_cov_post"] @ A.T + t["process_noise_cov"]
+        meas = np.concatenate([z, (z - t["measurement"][:3]) / dt])
+        H, R = t["measurement_matrix"], t["measurement_noise_cov"]
+        S = H @ P_pre @ H.T + R
+        Kg = np.linalg.solve(S, H @ P_pre).T
+        x_post = x_pre + Kg @ (meas - H @ x_pre)
+        P_post = P_pre - Kg @ (H @ P_pre)
+        assert np.allclose(n["state_post"], x_post, rtol=1e-10, atol=1e-12)
+        assert np.allclose(n["error_cov_post"], P_post, rtol=1e-9, atol=1e-13)
+        assert np.allclose(n["gain"], Kg, rtol=1e-9, atol=1e-13)
+        t = n
+
+
+def test_filter_state_product_equals_oracle_bit_for_bit():
+    rng = np.random.default_rng(9)
+    a = obs_at((1.0, 1.0, 1.0), 0, f=Context.track_new)
+    b = obs_at((1.0, 1.0, 1.0), 0, f=O.track_new)
+    assert a.tobytes() == b.tobytes()
+    stamp = 0
+    for k in range(200):
+        stamp += int(rng.integers(1_000_000, 30_000_000))
+        if rng.random() < 0.25:                      # a missed frame: coast
+            a, b = Context.track_predict(a, stamp, TICK), O.track_predict(b, stamp, TICK)
+        else:
+            pos, ident = rng.normal(size=3) * 3, int(rng.integers(0, 7))
+            a = Context.track_update(a, obs_at(pos, stamp, ident, f=Context.track_new), TICK)
+            b = O.track_update(b, obs_at(pos, stamp, ident, f=O.track_new), TICK)
+        assert a.tobytes() == b.tobytes(), k
+    assert a["n_ids"] >= 5 and np.isfinite(a["state_post"]).all()
+
+
+# ---------------------------------------------------------------- the tracking thread's loop (main.cpp:60-85)
+def test_association_loop_known_scenarios():
+    for step, new in ((Context.track_step, Context.track_new), (O.track_step, O.track_new)):
+        mk = lambda box, stamp, ident=1: new(arm(*box), ident, stamp, (0.0, 0.0, 1.0))
+        # empty tracking list: this frame's armours become the targets
+        tr = step([], [mk((100, 100, 40, 40), 10), mk((300, 100, 40, 40), 10)])
+        assert len(tr) == 2 and tr[0]["initialized"] == 0
+        # no observations: nothing happens (main.cpp:61 `continue`), not even ageing
+        assert step(tr, []).tobytes() == tr.tobytes()
+        # one target re-observed (IoU > 0.5), one missed, one new armour
+        tr2 = step(tr, [mk((104, 102, 40, 40), 20, ident=4), mk((600, 400, 30, 30), 20)])
+        assert len(tr2) == 3
+        assert tr2[0]["initialized"] == 1 and tr2[0]["timestamp"] == 20 and tr2[0]["lost_count"] == 0 and tr2[0]["ids"][0] == 4
+        assert tr2[0]["armour"]["bbox"].tolist() == [100, 100, 40, 40]          # the box is never refreshed (reference behaviour)
+        assert tr2[1]["lost_count"] == 1 and tr2[1]["timestamp"] == 10 and tr2[2]["armour"]["bbox"][0] == 600
+        # IoU exactly at the 0.5 boundary is NOT a match: boxes 40x40 shifted by 40/3 px overlap by (80/3*40) / (2*1600 - 80/3*40) = 0.5
+        # (not representable -> take a clear miss and a clear hit instead)
+        tr3 = step(tr, [mk((115, 100, 40, 40), 30)])                             # IoU = 25*40/(3200-1000) = 0.4545
+        assert len(tr3) == 3 and tr3[0]["lost_count"] == 1 and tr3[2]["armour"]["bbox"][0] == 115
+        # ageing: a target is dropped on its 27th miss, and the target BEHIND it in the list is skipped in that pass
+        tr = step([], [mk((100, 100, 40, 40), 0), mk((300, 100, 40, 40), 0), mk((500, 100, 40, 40), 0)])
+        far = lambda s: [mk((900, 700, 20, 20), s)]
+        for k in range(26):
+            tr = step(tr, far(k + 1))
+            tr = tr[:3]                                                           # drop the far armour again: keep the scenario small
+            assert [int(t["lost_count"]) for t in tr] == [k + 1] * 3
+        tr = step(tr, far(100))
+        # pass 27: target 0 has lost_count 26 > 25 -> erased; old target 1 moved to slot 0 and is skipped (not aged); old target 2, now
+        # in slot 1, is examined with i = 1: 26 > 25 -> erased too.  Left: the skipped one + the far armour
+        assert len(tr) == 2 and tr[0]["armour"]["bbox"][0] == 300 and tr[0]["lost_count"] == 26 and tr[1]["armour"]["bbox"][0] == 900
+
+
+def test_association_loop_product_equals_oracle_on_random_traffic():
+    rng = np.random.default_rng(21)
+    ta, tb = [], []
+    stamp = 0
+    for frame in range(120):
+        stamp += 8_000_000
+        obs_a, obs_b = [], []
+        for _ in range(int(rng.integers(0, 5))):
+            box = (float(rng.integers(0, 6)) * 120 + float(rng.integers(-12, 13)), 200 + float(rng.integers(-10, 11)), 60.0, 50.0)
+            pos, ident = rng.normal(size=3), int(rng.integers(0, 7))
+            obs_a.append(Context.track_new(arm(*box), ident, stamp, pos))
+            obs_b.append(O.track_new(arm(*box), ident, stamp, pos))
+        ta, tb = Context.track_step(ta, obs_a), O.track_step(tb, obs_b)
+        assert len(ta) == len(tb) and (len(ta) == 0 or ta.tobytes() == tb.tobytes()), frame
+    assert len(ta) > 0 and max(int(t["initialized"]) for t in ta) == 1
