@@ -182,6 +182,15 @@ def main():
     head, _ = rdist.record_layout(n, cap)
     recs_buf = [rdist.new_record(n, cap, dev) for _ in range(ns)]
     gather_out = [rdist.new_gather_list(r) if use_dist else None for r in recs_buf]   # rank 0's receive buffers, one set per stream
+    abi_gather = rdist.AbiGather(local_rank) if (use_dist and args.gather == "abi") else None   # RCCL called by librmcv_hip itself
+    abi_recv = [abi_gather.new_recv(r) for r in recs_buf] if abi_gather else None
+
+    def gather_step(k, hs):
+        if not use_dist:
+            return [recs_buf[k]]
+        if abi_gather:
+            return abi_gather.gather(recs_buf[k], abi_recv[k], hs)
+        return rdist.gather_records(recs_buf[k], out=gather_out[k])
     # one stream per batch in flight (priorities alternate; with GPU_MAX_HW_QUEUES = 6 every stream has its own hardware queue, which is
     # what lets kernels of two steps actually run concurrently
     prios = [int(x) for x in os.environ.get("RMCV_BENCH_PRIOS", "").split(",") if x] or [0, -1]
@@ -207,7 +216,7 @@ def main():
             with torch.cuda.stream(streams[k]):
                 run_path(ctxs[k], cur_stages[0], streams[k].cuda_stream)
                 ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
-                return rdist.gather_records(recs_buf[k], out=gather_out[k]) if use_dist else [recs_buf[k]]
+                return gather_step(k, streams[k].cuda_stream)
         with torch.cuda.stream(sA):
             if not first_use:
                 sA.wait_event(ev_done[k])
@@ -218,7 +227,7 @@ def main():
             sB.wait_event(ev_bin[k])
             run_path(ctxs[k], sparse_stages, sB.cuda_stream)
             ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), sB.cuda_stream)
-            out = rdist.gather_records(recs_buf[k], out=gather_out[k]) if use_dist else [recs_buf[k]]
+            out = gather_step(k, sB.cuda_stream)
             ev_done[k].record(sB)
             return out
 
@@ -515,6 +524,8 @@ def main():
                                          "armours": tot_all}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if abi_gather:
+        abi_gather.close()
     if use_dist:
         dist.destroy_process_group()
 

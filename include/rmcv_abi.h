@@ -35,6 +35,7 @@ extern "C" {
 #define RMCV_ERR_NOMEM (-3)
 #define RMCV_ERR_HIP (-4)       /* a HIP runtime call failed: see rmcv_last_error        */
 #define RMCV_ERR_NO_DEVICE (-5) /* no gfx950 device: this library has no CPU path        */
+#define RMCV_ERR_RCCL (-6)      /* librccl could not be loaded, or an RCCL call failed: see rmcv_comm_last_error */
 
 /* rm::camp -- include/core.h:20-23 */
 #define RMCV_CAMP_RED 0
@@ -212,6 +213,26 @@ int rmcv_batch_get_icons(rmcv_ctx* ctx, int frame, uint8_t* icons_out, int cap_a
  * for `cap` armours, d_frame_offs for n_frames+1 int32 (last entry = total, which may exceed cap: then only the
  * first `cap` were written).  Asynchronous on hip_stream.  This is the payload of the multi-GPU gather. */
 int rmcv_batch_compact_armours(rmcv_ctx* ctx, void* d_armours_out, int cap, void* d_frame_offs, void* hip_stream);
+
+/* ---- multi-GPU: the gather of the armour lists (BASELINE config 4) ------------------------------------------------
+ * One process per GPU; frames are independent, so there is no collective on the data path.  After rmcv_batch_run +
+ * rmcv_batch_compact_armours every rank holds a fixed-size record in HBM ([frame_offs : n_frames+1 int32, padded to 16 B |
+ * armours : cap x 88 B], the layout of rmcv_amd/dist.py); rmcv_gather moves the records of all ranks to the root with RCCL
+ * point-to-point transfers (each peer's own xGMI link to the root), asynchronously on the caller's stream.
+ * RCCL is loaded on first use (librccl.so.1); a single-GPU user never needs it.  The reference is single-process
+ * (executable/main.cpp:45-107): this is the north star's addition, not a reference interface. */
+#define RMCV_COMM_ID_BYTES 128
+typedef struct rmcv_comm rmcv_comm;
+/* rank 0: make the group's id; hand the 128 bytes to the other ranks by any means (file, socket, MPI, a launcher's store) */
+int  rmcv_comm_unique_id(uint8_t id_out[RMCV_COMM_ID_BYTES]);
+/* every rank, collectively: join the group of n_ranks on its own GPU `device` */
+int  rmcv_comm_create(const uint8_t id[RMCV_COMM_ID_BYTES], int n_ranks, int rank, int device, rmcv_comm** out);
+void rmcv_comm_destroy(rmcv_comm* comm);
+int  rmcv_comm_info(const rmcv_comm* comm, int32_t* n_ranks, int32_t* rank);
+const char* rmcv_comm_last_error(const rmcv_comm* comm /* NULL: the loader's message */);
+/* every rank, collectively: d_record (record_bytes, device memory) -> root's d_recv (n_ranks x record_bytes, rank order; ignored
+ * on the other ranks).  Enqueued on hip_stream; the root's buffer is complete when that stream reaches this point. */
+int  rmcv_gather(rmcv_comm* comm, const void* d_record, int64_t record_bytes, void* d_recv, int root, void* hip_stream);
 
 /* ---- legacy per-contour matcher: the "next" row SURVEY 8f-2 (src/objdetect.cpp:9-53, 89-112) ---------- */
 typedef struct {            /* the float arguments of rm::MatchLightBlob / rm::FindLightBlobs, include/objdetect.h:22-37 */

@@ -26,7 +26,8 @@ TRACK = np.dtype([("armour", ARMOUR), ("timestamp", "<i8"), ("lost_count", "<i4"
                   ("gain", "<f8", (6, 6))])  # rmcv_track
 assert POINT.itemsize == 8 and LIGHTBLOB.itemsize == 56 and ARMOUR.itemsize == 88 and TRACK.itemsize == 2552
 
-OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE, ERR_RCCL = 0, -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
 CAMP_RED, CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL = 0, 1, 2, -1
 MORPH_NONE, MORPH_DILATE, MORPH_CLOSE = 0, 1, 2
 OPT_SPARSE_WAVES = 1
@@ -44,7 +45,8 @@ EXPORTS = [
     "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_batch_compact_armours", "rmcv_synth_frame", "rmcv_synth_checksum",
     "rmcv_svm_load", "rmcv_classify_armours", "rmcv_batch_get_identities", "rmcv_batch_get_icons",
     "rmcv_default_pnp_config", "rmcv_pnp_load", "rmcv_locate_armours", "rmcv_batch_set_base2gripper", "rmcv_batch_get_poses",
-    "rmcv_max_iou", "rmcv_identity_max", "rmcv_track_init", "rmcv_track_reset", "rmcv_track_update", "rmcv_track_predict", "rmcv_track_step", "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
+    "rmcv_max_iou", "rmcv_identity_max", "rmcv_comm_unique_id", "rmcv_comm_create", "rmcv_comm_destroy", "rmcv_comm_info", "rmcv_comm_last_error", "rmcv_gather",
+    "rmcv_track_init", "rmcv_track_reset", "rmcv_track_update", "rmcv_track_predict", "rmcv_track_step", "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
 ]
 
 

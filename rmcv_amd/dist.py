@@ -15,6 +15,8 @@ i.e. every peer uses its own direct xGMI link to the root: the payload is O(100 
 and must not be pushed round a ring.  frame_offs[-1] is the rank's true armour count; a count above
 `cap` is detected by unpack_records (the caller then re-gathers with a larger cap).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -91,3 +93,55 @@ def gather_detections(frame_offs, armours_u8, cap, device="cpu", group=None, dst
     if recs is None:
         return None
     return unpack_records(recs, n_local, cap)
+
+
+class AbiGather:
+    """The same gather through the C-ABI (rmcv_comm_* / rmcv_gather in librmcv_hip.so): RCCL called by the library itself, which
+    is what a C++ host uses (include/rmcv_abi.h).  torch.distributed only carries the 128-byte group id from rank 0 to the
+    others here; the payload moves by ncclSend/ncclRecv on the caller's HIP stream."""
+
+    def __init__(self, device_index, group=None):
+        from .abi import COMM_ID_BYTES, RmcvError, lib
+        self._lib, self._err = lib(), RmcvError
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        idt = torch.zeros(COMM_ID_BYTES, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_uint8 * COMM_ID_BYTES)()
+            self._chk(self._lib.rmcv_comm_unique_id(buf), None)
+            idt = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+        dev = torch.device("cuda", device_index) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        idt = idt.to(dev)
+        dist.broadcast(idt, src=0, group=group)
+        raw = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(idt.cpu().numpy()))
+        h = C.c_void_p()
+        self._chk(self._lib.rmcv_comm_create(raw, self.world, self.rank, int(device_index), C.byref(h)), None)
+        self._h = h
+        n, r = C.c_int32(0), C.c_int32(0)
+        self._chk(self._lib.rmcv_comm_info(self._h, C.byref(n), C.byref(r)), self._h)
+        assert (n.value, r.value) == (self.world, self.rank)
+
+    def _chk(self, rc, h):
+        if rc != 0:
+            self._lib.rmcv_comm_last_error.restype = C.c_char_p
+            self._lib.rmcv_comm_last_error.argtypes = [C.c_void_p]
+            raise self._err(rc, self._lib.rmcv_comm_last_error(h).decode())
+
+    def new_recv(self, rec):
+        """root's receive buffer (world x record bytes, one tensor), None elsewhere"""
+        return torch.empty(self.world * rec.numel(), dtype=torch.uint8, device=rec.device) if self.rank == 0 else None
+
+    def gather(self, rec, recv, stream=None):
+        """enqueue on `stream` (a hipStream_t as int; None = the null stream); returns the list of per-rank records (views) on root"""
+        self._chk(self._lib.rmcv_gather(self._h, C.c_void_p(rec.data_ptr()), C.c_int64(rec.numel()),
+                                        C.c_void_p(recv.data_ptr() if recv is not None else 0), 0, C.c_void_p(stream or 0)), self._h)
+        if recv is None:
+            return None
+        n = rec.numel()
+        return [recv[r * n:(r + 1) * n] for r in range(self.world)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rmcv_comm_destroy.restype = None
+            self._lib.rmcv_comm_destroy.argtypes = [C.c_void_p]
+            self._lib.rmcv_comm_destroy(self._h)
+            self._h = None

@@ -68,3 +68,23 @@ def test_synth_is_deterministic():
     assert not np.array_equal(a, synth.frame(4, 320, 256))
     red = synth.frame(3, 320, 256, camp=0)
     assert np.array_equal(red[..., 0], a[..., 2]) and np.array_equal(red[..., 2], a[..., 0])   # the mirrored stream
+
+
+def test_gather_entry_points_check_their_arguments():
+    """rmcv_comm_* / rmcv_gather (the C-ABI form of the multi-GPU gather): argument checks, no GPU and no RCCL needed"""
+    from rmcv_amd import abi
+    L = abi.lib()
+    h = C.c_void_p()
+    idb = (C.c_uint8 * abi.COMM_ID_BYTES)()
+    assert L.rmcv_comm_unique_id(None) == abi.ERR_BAD_ARG
+    assert L.rmcv_comm_create(None, 2, 0, 0, C.byref(h)) == abi.ERR_BAD_ARG and not h.value
+    assert L.rmcv_comm_create(idb, 0, 0, 0, C.byref(h)) == abi.ERR_BAD_ARG
+    assert L.rmcv_comm_create(idb, 2, 2, 0, C.byref(h)) == abi.ERR_BAD_ARG        # rank out of range
+    assert L.rmcv_comm_create(idb, 2, 0, 0, None) == abi.ERR_BAD_ARG
+    import torch
+    if torch.cuda.device_count() == 0:
+        assert L.rmcv_comm_create(idb, 1, 0, 0, C.byref(h)) == abi.ERR_NO_DEVICE     # like rmcv_ctx_create: no CPU path
+    assert L.rmcv_comm_info(None, None, None) == abi.ERR_BAD_ARG
+    assert L.rmcv_gather(None, None, C.c_int64(16), None, 0, None) == abi.ERR_BAD_ARG
+    L.rmcv_comm_destroy.restype = None
+    L.rmcv_comm_destroy(None)                                                        # a no-op

@@ -217,6 +217,7 @@ def test_stale_hip_error_on_the_thread_does_not_fail_or_derail_a_run(ctx, oracle
             ref = oracle.detect_frame(frames[f])
             assert np.array_equal(ctx.binary(f), ref["binary"]), (rep, f)
             assert arm[offs[f]:offs[f + 1]].tobytes() == ref["armours"].tobytes(), (rep, f)
+    hip.hipGetLastError()   # reading the slot resets it: torch (same runtime, same thread) checks it after its own calls
 
 
 def test_bad_call_leaves_the_context_usable(ctx, oracle):
@@ -273,3 +274,44 @@ def test_oracle_against_real_opencv_if_present(oracle):
                 (mx, my), (mw, mh), ma = cv2.minAreaRect(cnt)
                 m = oracle.min_area_rect(mine)
                 assert np.allclose(sorted([mw, mh]), sorted([m["w"], m["h"]]), rtol=1e-5, atol=1e-4), (idx, i)
+
+
+# ---------------------------------------------------------------- the C-ABI gather (RCCL called by the library), one rank
+def test_abi_gather_single_rank_moves_the_record(oracle):
+    """rmcv_comm_* + rmcv_gather with a group of one (a one-GPU box): the root's record must arrive unchanged in slot 0 of the
+    receive buffer, asynchronously on the caller's stream -- and decode to the batch's armour list"""
+    import ctypes as C
+
+    import torch
+
+    from rmcv_amd import dist as rdist
+    from rmcv_amd.abi import COMM_ID_BYTES, lib
+    L = lib()
+    idb = (C.c_uint8 * COMM_ID_BYTES)()
+    assert L.rmcv_comm_unique_id(idb) == 0
+    h = C.c_void_p()
+    assert L.rmcv_comm_create(idb, 1, 0, 0, C.byref(h)) == 0
+    n, cap = 8, 64
+    c = Context(device=0, max_frames=n, max_width=1280, max_height=1024)
+    frames = synth.batch(4000, n, 1280, 1024, CAMP_BLUE, 1)
+    c.upload(frames)
+    s = torch.cuda.Stream()
+    head, total = rdist.record_layout(n, cap)
+    rec = rdist.new_record(n, cap, torch.device("cuda", 0))
+    recv = torch.full((total,), 0xEE, dtype=torch.uint8, device="cuda")
+    c.run(default_params(), STAGE_ALL, s.cuda_stream)
+    c.compact_armours_into(rec.data_ptr() + head, cap, rec.data_ptr(), s.cuda_stream)
+    assert L.rmcv_gather(h, C.c_void_p(rec.data_ptr()), C.c_int64(total), C.c_void_p(recv.data_ptr()), 0, C.c_void_p(s.cuda_stream)) == 0
+    s.synchronize()
+    assert torch.equal(recv, rec)
+    arm, offs = rdist.unpack_records([recv], n, cap)
+    ref = [oracle.detect_frame(frames[f])["armours"] for f in range(n)]
+    assert offs.tolist() == np.cumsum([0] + [len(r) for r in ref]).tolist()
+    assert arm.tobytes() == np.concatenate(ref).tobytes() and len(arm) > 0
+    # bad arguments on a live communicator
+    assert L.rmcv_gather(h, C.c_void_p(rec.data_ptr()), C.c_int64(total), None, 0, None) == -1      # root without a receive buffer
+    assert L.rmcv_gather(h, C.c_void_p(rec.data_ptr()), C.c_int64(total), C.c_void_p(recv.data_ptr()), 1, None) == -1   # no such root
+    L.rmcv_comm_destroy.restype = None
+    L.rmcv_comm_destroy.argtypes = [C.c_void_p]
+    L.rmcv_comm_destroy(h)
+    c.close()
