@@ -32,7 +32,7 @@ struct rmcv_ctx {
     hipEvent_t ev_order = nullptr; // recorded behind the work enqueued last: a call on ANOTHER stream first waits for it
     bool order_pending = false;
     // ---- per-frame drop-in path (rmcv_extract_color -> rmcv_filter_lightblobs -> rmcv_filter_armours, executable/main.cpp:172-176)
-    int frame_upload = 1;          // RMCV_OPT_FRAME_UPLOAD
+    int frame_upload = 0;          // RMCV_OPT_FRAME_UPLOAD
     struct Reg { const void* p; size_t bytes; };
     std::vector<Reg> registered;   // caller buffers pinned by hipHostRegister (RMCV_OPT_FRAME_UPLOAD = 2)
     uint8_t* h_frame = nullptr;    // pinned staging (lazy): the BGR frame on its way up ...
@@ -51,7 +51,7 @@ struct rmcv_ctx {
     int res_nc = -1, res_total = 0; // contours (+ the fit stage's work list) = h_pts / h_offs; -1: not resident
     int res_nb = -1;                // light blobs = h_blobs; -1: not resident
     int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
-    int pixel_groups = 4;         // RMCV_OPT_PIXEL_GROUPS
+    int pixel_groups = 3;         // RMCV_OPT_PIXEL_GROUPS
     char err[256] = {0};
     std::vector<void*> allocs;
 };
