@@ -829,7 +829,7 @@ static void gen_row3(const void* ctx, int i, double* row)
 }
 
 /* [OCV] fitEllipseNoDirect (general "LIN" conic fit, D. Weiss): structure restated, the two
- * least-squares sub-problems solved via normal_solve (BUILD-DEFINED, see jacobi_sym). */
+ * least-squares sub-problems solved via normal_factor / normal_apply / normal_refine (BUILD-DEFINED, see above). */
 static void fit_ellipse_general(const orc_point* pts, int n, orc_rrect* box)
 {
     const double min_eps = 1e-8;
