@@ -108,6 +108,15 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     const int xcd = blockIdx.x & 7; // gridDim.x is a multiple of 8
     const int per_xcd = (n_blocks + 7) >> 3;
     __shared__ int s_next;
+    // A thread's items of a strip are tid, tid + 256, ...: their (row, group) pairs are stepped, not divided -- integer multiplies
+    // (v_mul_lo/hi_u32) issue at a fraction of the rate of an add, and the FAST path is as much issue-bound as memory-bound
+    const int q_first = tid - (int)div_r(tid, r_wq) * wq, r_first = div_r(tid, r_wq); // item tid = (r_first, q_first)
+    const int q_step = 256 - (int)div_r(256, r_wq) * wq, r_step = div_r(256, r_wq);     // item + 256 = (r + r_step, q + q_step) or (r + r_step + 1, q + q_step - wq)
+    const int k_first = tid - (int)div_r(tid, r_ww) * ww, s_first = div_r(tid, r_ww);   // the same for the strip's 64-pixel words
+    const int k_step = 256 - (int)div_r(256, r_ww) * ww, s_step = div_r(256, r_ww);
+    // 8 mask bits -> 8 bytes of 0/255: a 256-entry table in LDS instead of two multiplies per nibble (phase 4)
+    __shared__ uint64_t s_lut[256];
+    if (FAST) s_lut[tid] = (uint64_t)expand4(tid) | ((uint64_t)expand4(tid >> 4) << 32);
     for (;;) {
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
@@ -143,14 +152,13 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint8_t*>(frames), 0, (int)((int64_t)(n_frames - 1) * frame_pitch + (int64_t)(h - 1) * stride + 3 * w), RSRC3);
         const uint32_t fbase = (uint32_t)((int64_t)f * frame_pitch);
+        int rq = r_first, q = q_first; // (row, group) of item it0 + 256 * u, stepped
         for (int it0 = tid; it0 < items; it0 += 256 * U) {
             u32x4v v[U][3];
             int rq_[U]; // row of the strip << 16 | 16-pixel group; -1: beyond the strip's items
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int it = it0 + 256 * u;
-                const int rq = div_r(it, r_wq);
-                const int q = it - rq * wq;
                 // neighbouring strips share halo rows: odd strips sweep top->bottom, even strips bottom->top, so a
                 // shared row is requested by both workgroups at about the same time and one of them hits in L2
                 const int rr = (L & 1) ? rq : srh - 1 - rq;
@@ -160,11 +168,14 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
 #ifdef RMCV_K1_NOLOAD
                 const uint32_t off = OOB;
 #else
-                const uint32_t off = ok ? fbase + (uint32_t)y * (uint32_t)stride + (uint32_t)q * 48u : OOB;
+                const uint32_t off = ok ? fbase + __umul24(y, stride) + __umul24(q, 48) : OOB; // y, stride, q < 2^24
 #endif
                 v[u][0] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 0, RMCV_K1_LDAUX);
                 v[u][1] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 16, RMCV_K1_LDAUX);
                 v[u][2] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 32, RMCV_K1_LDAUX);
+                q += q_step;
+                rq += r_step;
+                if (q >= wq) { q -= wq; rq++; }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
                     const int y = y0 - halo + rr;
                     m = (y >= 0 && y < h) ? 0xFFFFu : 0u;
                 }
-                if (rq_[u] >= 0) reinterpret_cast<uint16_t*>(T + rr * ww)[q] = (uint16_t)m;
+                if (rq_[u] >= 0) reinterpret_cast<uint16_t*>(T + __umul24(rr, ww))[q] = (uint16_t)m;
             }
         }
     } else {
@@ -214,17 +225,19 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     if (morph != RMCV_MORPH_NONE) {
         // ---------------- phase 2: dilate -> D (rows 1 .. srh-2)
         const int items = (srh - 2) * ww;
-        for (int it = tid; it < items; it += 256) {
-            const int r_ = div_r(it, r_ww);
-            const int rr = 1 + r_, k = it - r_ * ww;
+        int r_ = s_first, k = k_first; // (row, word) of item it, stepped (see the kernel's prologue)
+        for (int it = tid; it < items; it += 256, k += k_step, r_ += s_step) {
+            if (k >= ww) { k -= ww; r_++; }
+            const int rr = 1 + r_;
             const int y = y0 - halo + rr;
+            const int row = FAST ? (int)__umul24(rr, ww) : rr * ww;
             uint64_t d;
             if (y < 0 || y >= h) {
                 d = ~0ull; // outside the image: never wins the erode
             } else {
-                const uint64_t* t0 = T + (rr - 1) * ww;
-                const uint64_t* t1 = T + rr * ww;
-                const uint64_t* t2 = T + (rr + 1) * ww;
+                const uint64_t* t0 = T + row - ww;
+                const uint64_t* t1 = T + row;
+                const uint64_t* t2 = T + row + ww;
                 uint64_t c = t0[k] | t1[k] | t2[k];
                 uint64_t l = (k > 0) ? (t0[k - 1] | t1[k - 1] | t2[k - 1]) >> 63 : 0;
                 uint64_t r = (k < ww - 1) ? (t0[k + 1] | t1[k + 1] | t2[k + 1]) & 1 : 0;
@@ -234,25 +247,27 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
                     if (morph == RMCV_MORPH_CLOSE) d |= ~last_valid; // columns >= w never win the erode
                 }
             }
-            D[rr * ww + k] = d;
+            D[row + k] = d;
         }
         __syncthreads();
         R = D;
         if (morph == RMCV_MORPH_CLOSE) {
             // ---------------- phase 3: erode -> T (rows 2 .. srh-3 = the strip)
             const int items3 = sr * ww;
-            for (int it = tid; it < items3; it += 256) {
-                const int r_ = div_r(it, r_ww);
-                const int rr = 2 + r_, k = it - r_ * ww;
-                const uint64_t* d0 = D + (rr - 1) * ww;
-                const uint64_t* d1 = D + rr * ww;
-                const uint64_t* d2 = D + (rr + 1) * ww;
+            int r3 = s_first, k = k_first;
+            for (int it = tid; it < items3; it += 256, k += k_step, r3 += s_step) {
+                if (k >= ww) { k -= ww; r3++; }
+                const int rr = 2 + r3;
+                const int row = FAST ? (int)__umul24(rr, ww) : rr * ww;
+                const uint64_t* d0 = D + row - ww;
+                const uint64_t* d1 = D + row;
+                const uint64_t* d2 = D + row + ww;
                 uint64_t c = d0[k] & d1[k] & d2[k];
                 uint64_t l = (k > 0) ? (d0[k - 1] & d1[k - 1] & d2[k - 1]) >> 63 : 1;
                 uint64_t r = (k < ww - 1) ? (d0[k + 1] & d1[k + 1] & d2[k + 1]) & 1 : 1;
                 uint64_t e = c & ((c << 1) | l) & ((c >> 1) | (r << 63));
                 if (k == ww - 1) e &= last_valid;
-                T[rr * ww + k] = e;
+                T[row + k] = e;
             }
             __syncthreads();
             R = T;
@@ -272,30 +287,39 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
         const uint32_t plane_base = (uint32_t)((int64_t)f * plane_pitch);
         { // the strip's words -> the frame's bit plane (8 contiguous bytes per lane)
             const int nw = sr * ww;
+            int s_ = s_first, k = k_first;
             for (int it = tid; it - (tid & 63) < nw; it += 256) {
-                const int s_ = div_r(it, r_ww), k = it - s_ * ww, y = y0 + s_;
+                const int y = y0 + s_;
                 const bool ok = it < nw && y < h;
                 uint64_t word = 0;
-                if (ok) word = R[(s_ + halo) * ww + k];
+                if (ok) word = R[__umul24(s_ + halo, ww) + k];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane,
-                                                      ok ? (plane_base + (uint32_t)(y + 1) * (uint32_t)prow + 1u + (uint32_t)k) * 8u : OOB, 0, 0);
+                                                      ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB, 0, 0);
+                k += k_step;
+                s_ += s_step;
+                if (k >= ww) { k -= ww; s_++; }
             }
         }
         if (binary) { // RMCV_STAGE_NO_IMAGE: the 0/255 byte image is not wanted
             const int items = sr * wq;
             const uint32_t bin_base = (uint32_t)((int64_t)f * w * h);
+            int s_ = r_first, q = q_first;
             for (int it = tid; it - (tid & 63) < items; it += 256) {
-                const int s_ = div_r(it, r_wq), q = it - s_ * wq, y = y0 + s_;
+                const int y = y0 + s_;
                 const bool ok = it < items && y < h;
                 uint32_t m = 0;
-                if (ok) m = reinterpret_cast<const uint16_t*>(R + (s_ + halo) * ww)[q];
-                const u32x4v o = {expand4(m), expand4(m >> 4), expand4(m >> 8), expand4(m >> 12)};
+                if (ok) m = reinterpret_cast<const uint16_t*>(R + __umul24(s_ + halo, ww))[q];
+                const uint64_t lo = s_lut[m & 0xFF], hi = s_lut[m >> 8];
+                const u32x4v o = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
 #ifdef RMCV_K1_NOSTORE
                 const uint32_t off = OOB;
 #else
-                const uint32_t off = ok ? bin_base + (uint32_t)y * (uint32_t)w + (uint32_t)q * 16u : OOB;
+                const uint32_t off = ok ? bin_base + __umul24(y, w) + (uint32_t)q * 16u : OOB;
 #endif
                 __builtin_amdgcn_raw_buffer_store_b128(o, r_bin, off, 0, 2 /* nt: written once, read by nobody here */);
+                q += q_step;
+                s_ += r_step;
+                if (q >= wq) { q -= wq; s_++; }
             }
         }
     } else {
