@@ -138,6 +138,12 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * frame buffers (the reference's cameras do, hardware/src/daheng.cpp:83); the buffers must stay mapped while the context
  * lives.  Results are identical. */
 #define RMCV_OPT_FRAME_UPLOAD 3
+/* RMCV_OPT_RUN_AHEAD: 1 (default): rmcv_extract_color also enqueues the blob and armour stages with the parameters the PREVIOUS
+ * frame's rmcv_filter_lightblobs / rmcv_filter_armours calls used; when this frame's calls come with the same parameters and the
+ * lists rmcv_extract_color / rmcv_filter_lightblobs returned, they hand over results that are already on the host -- the whole
+ * chain of executable/main.cpp:172-176 is then one stream sequence with one synchronisation.  0: every call does its own work.
+ * Results are identical. */
+#define RMCV_OPT_RUN_AHEAD 4
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 
 /* ---- single frame, host buffers: one call per reference function ---------------------- */

@@ -33,23 +33,30 @@ struct rmcv_ctx {
     bool order_pending = false;
     // ---- per-frame drop-in path (rmcv_extract_color -> rmcv_filter_lightblobs -> rmcv_filter_armours, executable/main.cpp:172-176)
     int frame_upload = 0;          // RMCV_OPT_FRAME_UPLOAD
+    int run_ahead = 1;             // RMCV_OPT_RUN_AHEAD
     struct Reg { const void* p; size_t bytes; };
     std::vector<Reg> registered;   // caller buffers pinned by hipHostRegister (RMCV_OPT_FRAME_UPLOAD = 2)
-    uint8_t* h_frame = nullptr;    // pinned staging (lazy): the BGR frame on its way up ...
+    uint8_t* h_frame = nullptr;    // pinned staging (lazy): the BGR frame on its way up (RMCV_OPT_FRAME_UPLOAD = 1); small results on their way down:
     size_t h_frame_bytes = 0;
-    uint8_t* h_binary = nullptr;   // ... and every result on its way down
-    int32_t* h_hdr = nullptr;      // [8]
+    int32_t* h_hdr = nullptr;      // [16]: contours at 0, blobs at 4, armours at 8
     rmcv_point* h_pts = nullptr;   // [max_points]      the CSR the last rmcv_extract_color returned
     int32_t* h_offs = nullptr;     // [max_contours + 1]
     rmcv_lightblob* h_blobs = nullptr; // [max_blobs]   the positive list the last rmcv_filter_lightblobs returned
     int32_t* h_blob_src = nullptr; // [max_blobs]
     int32_t* h_neg = nullptr;      // [max_contours]
     rmcv_armour* h_armours = nullptr; // [max_armours]
-    int32_t* d_hdr = nullptr;      // device [8]
+    int32_t* d_hdr = nullptr;      // device [16]
     // Device-resident hand-over: what frame slot 0 of the device buffers holds right now.  When the next call of the chain is
     // handed exactly these bytes back (the usual case: the reference passes the results straight on), nothing is re-uploaded.
     int res_nc = -1, res_total = 0; // contours (+ the fit stage's work list) = h_pts / h_offs; -1: not resident
     int res_nb = -1;                // light blobs = h_blobs; -1: not resident
+    // Run-ahead: a caller that filters every frame with the same parameters (executable/main.cpp:172-176 does) gets the blob and
+    // armour stages enqueued by rmcv_extract_color already, with the parameters its previous frame used -- one stream sequence and
+    // one synchronisation for the whole chain; rmcv_filter_lightblobs / rmcv_filter_armours then only hand the results over.
+    struct LbParams { float tilt_max, ratio_lo, ratio_hi; double area_lo, area_hi; int enemy; } last_lb{};
+    struct ArParams { float angle_diff_max, shear_max, length_ratio_max; int enemy; } last_ar{};
+    bool last_lb_valid = false, last_ar_valid = false; // what the previous frame's calls asked for
+    bool ahead_lb = false, ahead_ar = false;           // this frame's extract_color has run them: headers + windows are in pinned memory
     int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
     int pixel_groups = 3;         // RMCV_OPT_PIXEL_GROUPS
     char err[256] = {0};
@@ -62,6 +69,7 @@ static int fail(rmcv_ctx* c, int code, const char* what, hipError_t e = hipSucce
         if (e != hipSuccess) snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(e));
         else snprintf(c->err, sizeof(c->err), "%s", what);
     }
+    if (e != hipSuccess) (void)hipGetLastError(); // reported through the return code: do not leave it in the thread's sticky slot for others
     return code;
 }
 
@@ -125,7 +133,7 @@ void rmcv_ctx_destroy(rmcv_ctx* c)
     for (void* p : c->allocs) hipFree(p);
     if (c->own_frames) hipFree(c->own_frames);
     for (auto& r : c->registered) hipHostUnregister(const_cast<void*>(r.p));
-    for (void* h : {(void*)c->h_frame, (void*)c->h_binary, (void*)c->h_hdr, (void*)c->h_pts, (void*)c->h_offs, (void*)c->h_blobs,
+    for (void* h : {(void*)c->h_frame, (void*)c->h_hdr, (void*)c->h_pts, (void*)c->h_offs, (void*)c->h_blobs,
                     (void*)c->h_blob_src, (void*)c->h_neg, (void*)c->h_armours})
         if (h) hipHostFree(h);
     for (auto& e : c->ev)
@@ -217,7 +225,11 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
 } // extern "C"
 
 // frame slot 0 of the device buffers no longer holds what the per-frame chain returned last (see rmcv_ctx::res_nc)
-static void resident_none(rmcv_ctx* c) { c->res_nc = c->res_nb = -1; }
+static void resident_none(rmcv_ctx* c)
+{
+    c->res_nc = c->res_nb = -1;
+    c->ahead_lb = c->ahead_ar = false;
+}
 
 static int ensure_own_frames(rmcv_ctx* c, size_t need)
 {
@@ -237,15 +249,14 @@ static int ensure_staging(rmcv_ctx* c)
 {
     if (c->h_hdr) return RMCV_OK;
     const Limits& L = c->lim;
-    hipError_t e = hipHostMalloc((void**)&c->h_hdr, 8 * sizeof(int32_t), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_binary, (size_t)L.max_width * L.max_height, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void**)&c->h_hdr, 16 * sizeof(int32_t), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_pts, (size_t)L.max_points * sizeof(rmcv_point), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_offs, (size_t)(L.max_contours + 1) * 4, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_blobs, (size_t)L.max_blobs * sizeof(rmcv_lightblob), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_blob_src, (size_t)L.max_blobs * 4, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_neg, (size_t)L.max_contours * 4, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_armours, (size_t)L.max_armours * sizeof(rmcv_armour), hipHostMallocDefault);
-    if (e == hipSuccess) e = dalloc(c, &c->d_hdr, 8);
+    if (e == hipSuccess) e = dalloc(c, &c->d_hdr, 16);
     if (e != hipSuccess) return fail(c, RMCV_ERR_NOMEM, "pinned staging", e);
     return RMCV_OK;
 }
@@ -414,6 +425,10 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
     if (!c) return RMCV_ERR_BAD_ARG;
     if (option == RMCV_OPT_SPARSE_WAVES && (value == 4 || value == 8)) {
         c->sparse_waves = value;
+        return RMCV_OK;
+    }
+    if (option == RMCV_OPT_RUN_AHEAD && (value == 0 || value == 1)) {
+        c->run_ahead = value;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_FRAME_UPLOAD && value >= 0 && value <= 2) {
@@ -719,6 +734,93 @@ static int upload_one(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride,
     return RMCV_OK;
 }
 
+// the blob stage on frame slot 0 + its results on their way to pinned memory (header at h_hdr[4..6]); no synchronisation
+static int enqueue_blobs(rmcv_ctx* c, const rmcv_ctx::LbParams& q, bool compute = true)
+{
+    rmcv_params p;
+    rmcv_default_params(&p);
+    p.tilt_max = q.tilt_max;
+    p.ratio_lo = q.ratio_lo;
+    p.ratio_hi = q.ratio_hi;
+    p.area_lo = q.area_lo;
+    p.area_hi = q.area_hi;
+    p.camp = q.enemy;
+    Geom g1 = c->geom;
+    g1.n_frames = 1;
+    const Bufs& b = c->bufs;
+    hipStream_t s = c->stream;
+    if (compute) {
+        HIPCHK(c, launch_status_clear(g1, b, RMCV_FRAME_OVF_BLOBS | RMCV_FRAME_OVF_ARMOURS | RMCV_FRAME_HULL, s), "k_status_clear");
+        HIPCHK(c, launch_blobs(g1, b, c->lim, p, s), "k_blobs");
+    }
+    HIPCHK(c, launch_gather3(b.n_blobs, b.n_neg, b.status, c->d_hdr + 4, s), "k_gather3");
+    HIPCHK(c, hipMemcpyAsync(c->h_hdr + 4, c->d_hdr + 4, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
+    const int bw = std::min(SF_BLOB_WIN, c->lim.max_blobs), nw = std::min(SF_NEG_WIN, c->lim.max_contours);
+    HIPCHK(c, hipMemcpyAsync(c->h_blobs, b.blobs, (size_t)bw * sizeof(rmcv_lightblob), hipMemcpyDeviceToHost, s), "D2H blobs");
+    HIPCHK(c, hipMemcpyAsync(c->h_blob_src, b.blob_src, (size_t)bw * 4, hipMemcpyDeviceToHost, s), "D2H blob_src");
+    HIPCHK(c, hipMemcpyAsync(c->h_neg, b.neg_idx, (size_t)nw * 4, hipMemcpyDeviceToHost, s), "D2H neg");
+    return RMCV_OK;
+}
+
+// after the stream has been synchronised: what did not fit the windows, then the hand-over to the caller
+static int finish_blobs(rmcv_ctx* c, rmcv_lightblob* blobs_out, int blobs_cap, int32_t* n_blobs, int32_t* blob_src, int32_t* neg_idx_out,
+                        int32_t* n_neg)
+{
+    const Bufs& b = c->bufs;
+    const int bw = std::min(SF_BLOB_WIN, c->lim.max_blobs), nw = std::min(SF_NEG_WIN, c->lim.max_contours);
+    const int32_t nb = c->h_hdr[4], nn = c->h_hdr[5], st = c->h_hdr[6];
+    if (n_blobs) *n_blobs = nb;
+    if (n_neg) *n_neg = nn;
+    if (st & RMCV_FRAME_OVF_BLOBS) return fail(c, RMCV_ERR_CAPACITY, "context limit exceeded (max_blobs)");
+    if (nb > bw) {
+        HIPCHK(c, hipMemcpy(c->h_blobs + bw, b.blobs + bw, (size_t)(nb - bw) * sizeof(rmcv_lightblob), hipMemcpyDeviceToHost), "D2H blobs");
+        HIPCHK(c, hipMemcpy(c->h_blob_src + bw, b.blob_src + bw, (size_t)(nb - bw) * 4, hipMemcpyDeviceToHost), "D2H blob_src");
+    }
+    if (nn > nw) HIPCHK(c, hipMemcpy(c->h_neg + nw, b.neg_idx + nw, (size_t)(nn - nw) * 4, hipMemcpyDeviceToHost), "D2H neg");
+    c->res_nb = nb; // the device holds this positive list, h_blobs its bytes
+    if (nb > blobs_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    if (blobs_out && nb) memcpy(blobs_out, c->h_blobs, (size_t)nb * sizeof(rmcv_lightblob));
+    if (blob_src && nb) memcpy(blob_src, c->h_blob_src, (size_t)nb * 4);
+    if (neg_idx_out && nn) memcpy(neg_idx_out, c->h_neg, (size_t)nn * 4);
+    return RMCV_OK;
+}
+
+static int enqueue_armours(rmcv_ctx* c, const rmcv_ctx::ArParams& q, bool compute = true)
+{
+    rmcv_params p;
+    rmcv_default_params(&p);
+    p.angle_diff_max = q.angle_diff_max;
+    p.shear_max = q.shear_max;
+    p.length_ratio_max = q.length_ratio_max;
+    p.camp = q.enemy;
+    Geom g1 = c->geom;
+    g1.n_frames = 1;
+    const Bufs& b = c->bufs;
+    hipStream_t s = c->stream;
+    if (compute) {
+        HIPCHK(c, launch_status_clear(g1, b, RMCV_FRAME_OVF_ARMOURS, s), "k_status_clear");
+        HIPCHK(c, launch_armours(g1, b, c->lim, p, s), "k_armours");
+    }
+    HIPCHK(c, launch_gather3(b.n_armours, b.status, b.status, c->d_hdr + 8, s), "k_gather3");
+    HIPCHK(c, hipMemcpyAsync(c->h_hdr + 8, c->d_hdr + 8, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
+    const int aw = std::min(SF_ARM_WIN, c->lim.max_armours);
+    HIPCHK(c, hipMemcpyAsync(c->h_armours, b.armours, (size_t)aw * sizeof(rmcv_armour), hipMemcpyDeviceToHost, s), "D2H armours");
+    return RMCV_OK;
+}
+
+static int finish_armours(rmcv_ctx* c, rmcv_armour* armours_out, int armours_cap, int32_t* n_armours)
+{
+    const Bufs& b = c->bufs;
+    const int aw = std::min(SF_ARM_WIN, c->lim.max_armours);
+    const int32_t na = c->h_hdr[8], st = c->h_hdr[9];
+    if (n_armours) *n_armours = na;
+    if (st & RMCV_FRAME_OVF_ARMOURS) return fail(c, RMCV_ERR_CAPACITY, "context limit exceeded (max_armours)");
+    if (na > aw) HIPCHK(c, hipMemcpy(c->h_armours + aw, b.armours + aw, (size_t)(na - aw) * sizeof(rmcv_armour), hipMemcpyDeviceToHost), "D2H armours");
+    if (na > armours_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    if (armours_out && na) memcpy(armours_out, c->h_armours, (size_t)na * sizeof(rmcv_armour));
+    return RMCV_OK;
+}
+
 int rmcv_extract_color(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride, int camp, int lower_bound, int morph,
                        uint8_t* binary_out, rmcv_point* pts_out, int pts_cap, int32_t* offs_out, int contours_cap,
                        int32_t* n_contours, int32_t* n_points)
@@ -740,12 +842,41 @@ int rmcv_extract_color(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride
     const Bufs& b = c->bufs;
     hipStream_t s = c->stream;
     HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, s), "k_binary");
-    HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
+    // running ahead with both parameter sets known: the frame's whole sparse part is ONE kernel (the fused per-frame kernel of
+    // the batch path: findContours, fits and pairing back to back), not three
+    const bool fused_ahead = c->run_ahead && c->last_lb_valid && c->last_ar_valid && c->last_lb.enemy == c->last_ar.enemy;
+    if (fused_ahead) {
+        rmcv_params p;
+        rmcv_default_params(&p);
+        p.tilt_max = c->last_lb.tilt_max;
+        p.ratio_lo = c->last_lb.ratio_lo;
+        p.ratio_hi = c->last_lb.ratio_hi;
+        p.area_lo = c->last_lb.area_lo;
+        p.area_hi = c->last_lb.area_hi;
+        p.camp = c->last_lb.enemy;
+        p.angle_diff_max = c->last_ar.angle_diff_max;
+        p.shear_max = c->last_ar.shear_max;
+        p.length_ratio_max = c->last_ar.length_ratio_max;
+        HIPCHK(c, launch_sparse(g, b, c->lim, p, true, 8, s), "k_contours (fused)");
+    } else {
+        HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
+    }
     HIPCHK(c, launch_pack_contours(g, b, c->lim, c->pack_pts, c->pack_offs, c->d_hdr, s), "k_pack_contours");
     HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
     HIPCHK(c, hipMemcpyAsync(c->h_offs, c->pack_offs, (size_t)(std::min(SF_OFFS_WIN, c->lim.max_contours) + 1) * 4, hipMemcpyDeviceToHost, s), "D2H offs");
     HIPCHK(c, hipMemcpyAsync(c->h_pts, c->pack_pts, (size_t)std::min(SF_PTS_WIN, c->lim.max_points) * sizeof(rmcv_point), hipMemcpyDeviceToHost, s), "D2H pts");
-    if (binary_out) HIPCHK(c, hipMemcpyAsync(c->h_binary, b.binary, (size_t)w * h, hipMemcpyDeviceToHost, s), "D2H binary");
+    // the byte image goes straight to the caller's buffer (the runtime's pageable path: 37 us for 1.3 MB); through the pinned
+    // staging buffer it cost a 65 us CPU copy on top of the DMA
+    if (binary_out) HIPCHK(c, hipMemcpyAsync(binary_out, b.binary, (size_t)w * h, hipMemcpyDeviceToHost, s), "D2H binary");
+    bool ahead_lb = false, ahead_ar = false;
+    if (c->last_lb_valid && c->run_ahead) { // the filters of this frame, with the previous frame's parameters (see rmcv_ctx::last_lb)
+        if ((rc = enqueue_blobs(c, c->last_lb, !fused_ahead))) return rc;
+        ahead_lb = true;
+        if (c->last_ar_valid) {
+            if ((rc = enqueue_armours(c, c->last_ar, !fused_ahead))) return rc;
+            ahead_ar = true;
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(s), "sync");
     const int32_t nc = c->h_hdr[0], total = c->h_hdr[1], st = c->h_hdr[2];
     if (n_contours) *n_contours = nc;
@@ -755,7 +886,8 @@ int rmcv_extract_color(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride
     if (total > SF_PTS_WIN) HIPCHK(c, hipMemcpy(c->h_pts + SF_PTS_WIN, c->pack_pts + SF_PTS_WIN, (size_t)(total - SF_PTS_WIN) * sizeof(rmcv_point), hipMemcpyDeviceToHost), "D2H pts");
     c->res_nc = nc; // the device holds these contours (discovery order + the fit work list) and h_pts / h_offs their CSR
     c->res_total = total;
-    if (binary_out) memcpy(binary_out, c->h_binary, (size_t)w * h);
+    c->ahead_lb = ahead_lb;
+    c->ahead_ar = ahead_ar;
     if (nc > contours_cap || total > pts_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
     if (offs_out) memcpy(offs_out, c->h_offs, (size_t)(nc + 1) * 4);
     if (pts_out && total) memcpy(pts_out, c->h_pts, (size_t)total * sizeof(rmcv_point));
@@ -815,43 +947,18 @@ int rmcv_filter_lightblobs(rmcv_ctx* c, const rmcv_point* pts, const int32_t* of
         if (rc) return rc;
     }
     c->res_nb = -1;
-    rmcv_params p;
-    rmcv_default_params(&p);
-    p.tilt_max = tilt_max;
-    p.ratio_lo = ratio_lo;
-    p.ratio_hi = ratio_hi;
-    p.area_lo = area_lo;
-    p.area_hi = area_hi;
-    p.camp = enemy;
-    Geom g1 = c->geom;
-    g1.n_frames = 1;
-    if (c->geom.n_frames < 1) c->geom.n_frames = 1;
-    const Bufs& b = c->bufs;
-    hipStream_t s = c->stream;
-    if (resident) HIPCHK(c, launch_status_clear(g1, b, RMCV_FRAME_OVF_BLOBS | RMCV_FRAME_OVF_ARMOURS | RMCV_FRAME_HULL, s), "k_status_clear");
-    HIPCHK(c, launch_blobs(g1, b, c->lim, p, s), "k_blobs");
-    HIPCHK(c, launch_gather3(b.n_blobs, b.n_neg, b.status, c->d_hdr, s), "k_gather3");
-    HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
-    const int bw = std::min(SF_BLOB_WIN, c->lim.max_blobs), nw = std::min(SF_NEG_WIN, c->lim.max_contours);
-    HIPCHK(c, hipMemcpyAsync(c->h_blobs, b.blobs, (size_t)bw * sizeof(rmcv_lightblob), hipMemcpyDeviceToHost, s), "D2H blobs");
-    if (blob_src) HIPCHK(c, hipMemcpyAsync(c->h_blob_src, b.blob_src, (size_t)bw * 4, hipMemcpyDeviceToHost, s), "D2H blob_src");
-    if (neg_idx_out) HIPCHK(c, hipMemcpyAsync(c->h_neg, b.neg_idx, (size_t)nw * 4, hipMemcpyDeviceToHost, s), "D2H neg");
-    HIPCHK(c, hipStreamSynchronize(s), "sync");
-    const int32_t nb = c->h_hdr[0], nn = c->h_hdr[1], st = c->h_hdr[2];
-    if (n_blobs) *n_blobs = nb;
-    if (n_neg) *n_neg = nn;
-    if (st & RMCV_FRAME_OVF_BLOBS) return fail(c, RMCV_ERR_CAPACITY, "context limit exceeded (max_blobs)");
-    if (nb > bw) {
-        HIPCHK(c, hipMemcpy(c->h_blobs + bw, b.blobs + bw, (size_t)(nb - bw) * sizeof(rmcv_lightblob), hipMemcpyDeviceToHost), "D2H blobs");
-        if (blob_src) HIPCHK(c, hipMemcpy(c->h_blob_src + bw, b.blob_src + bw, (size_t)(nb - bw) * 4, hipMemcpyDeviceToHost), "D2H blob_src");
+    const rmcv_ctx::LbParams q = {tilt_max, ratio_lo, ratio_hi, area_lo, area_hi, enemy};
+    const bool ran_ahead = resident && c->ahead_lb && memcmp(&q, &c->last_lb, sizeof(q)) == 0; // extract_color did it already
+    c->last_lb = q;
+    c->last_lb_valid = true;
+    if (!ran_ahead) {
+        c->ahead_ar = false; // the armours run ahead (if any) belong to other blobs
+        if (c->geom.n_frames < 1) c->geom.n_frames = 1;
+        if ((rc = enqueue_blobs(c, q))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
     }
-    if (neg_idx_out && nn > nw) HIPCHK(c, hipMemcpy(c->h_neg + nw, b.neg_idx + nw, (size_t)(nn - nw) * 4, hipMemcpyDeviceToHost), "D2H neg");
-    c->res_nb = nb; // the device holds this positive list, h_blobs its bytes
-    if (nb > blobs_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
-    if (blobs_out && nb) memcpy(blobs_out, c->h_blobs, (size_t)nb * sizeof(rmcv_lightblob));
-    if (blob_src && nb) memcpy(blob_src, c->h_blob_src, (size_t)nb * 4);
-    if (neg_idx_out && nn) memcpy(neg_idx_out, c->h_neg, (size_t)nn * 4);
-    return RMCV_OK;
+    c->ahead_lb = false;
+    return finish_blobs(c, blobs_out, blobs_cap, n_blobs, blob_src, neg_idx_out, n_neg);
 }
 
 int rmcv_filter_armours(rmcv_ctx* c, const rmcv_lightblob* blobs, int n_blobs, float angle_diff_max, float shear_max,
@@ -876,28 +983,16 @@ int rmcv_filter_armours(rmcv_ctx* c, const rmcv_lightblob* blobs, int n_blobs, f
         HIPCHK(c, hipMemcpy(b.n_blobs, &n_blobs, 4, hipMemcpyHostToDevice), "H2D");
         HIPCHK(c, hipMemcpy(b.status, &z, 4, hipMemcpyHostToDevice), "H2D");
     }
-    rmcv_params p;
-    rmcv_default_params(&p);
-    p.angle_diff_max = angle_diff_max;
-    p.shear_max = shear_max;
-    p.length_ratio_max = length_ratio_max;
-    p.camp = enemy;
-    Geom g1 = c->geom;
-    g1.n_frames = 1;
-    if (resident) HIPCHK(c, launch_status_clear(g1, b, RMCV_FRAME_OVF_ARMOURS, s), "k_status_clear");
-    HIPCHK(c, launch_armours(g1, b, c->lim, p, s), "k_armours");
-    HIPCHK(c, launch_gather3(b.n_armours, b.status, b.status, c->d_hdr, s), "k_gather3");
-    HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
-    const int aw = std::min(SF_ARM_WIN, c->lim.max_armours);
-    HIPCHK(c, hipMemcpyAsync(c->h_armours, b.armours, (size_t)aw * sizeof(rmcv_armour), hipMemcpyDeviceToHost, s), "D2H armours");
-    HIPCHK(c, hipStreamSynchronize(s), "sync");
-    const int32_t na = c->h_hdr[0], st = c->h_hdr[1];
-    if (n_armours) *n_armours = na;
-    if (st & RMCV_FRAME_OVF_ARMOURS) return fail(c, RMCV_ERR_CAPACITY, "context limit exceeded (max_armours)");
-    if (na > aw) HIPCHK(c, hipMemcpy(c->h_armours + aw, b.armours + aw, (size_t)(na - aw) * sizeof(rmcv_armour), hipMemcpyDeviceToHost), "D2H armours");
-    if (na > armours_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
-    if (armours_out && na) memcpy(armours_out, c->h_armours, (size_t)na * sizeof(rmcv_armour));
-    return RMCV_OK;
+    const rmcv_ctx::ArParams q = {angle_diff_max, shear_max, length_ratio_max, enemy};
+    const bool ran_ahead = resident && c->ahead_ar && memcmp(&q, &c->last_ar, sizeof(q)) == 0;
+    c->last_ar = q;
+    c->last_ar_valid = true;
+    c->ahead_ar = false;
+    if (!ran_ahead) {
+        if ((rc = enqueue_armours(c, q))) return rc;
+        HIPCHK(c, hipStreamSynchronize(s), "sync");
+    }
+    return finish_armours(c, armours_out, armours_cap, n_armours);
 }
 
 int rmcv_fit_ellipse(rmcv_ctx* c, const rmcv_point* pts, int n, rmcv_rrect* out)

@@ -103,12 +103,16 @@ def test_per_frame_chain_equals_oracle(oracle, upload):
         buf[:] = synth.frame(idx, 1280, 1024, CAMP_BLUE, 1 if idx > 1000 else 0)
         total += len(check_chain(oracle, chain(c, buf), buf)["armours"])
     assert total > 6
+    keep = []                                                   # mode 2 pins the caller's buffers in place: they must outlive the context
     for idx, (w, h) in [(5, (1920, 1200)), (6, (640, 480)), (7, (333, 200))]:   # geometry changes, unaligned widths
         img = synth.frame(idx, w, h)
+        keep.append(img)
         check_chain(oracle, chain(c, img), img)
     red = synth.frame(11, 1280, 1024, CAMP_RED, 0)
+    keep.append(red)
     check_chain(oracle, chain(c, red, CAMP_RED), red, CAMP_RED)
     c.close()
+    del keep
 
 
 def test_per_frame_handover_only_when_bytes_match(ctx, oracle):
@@ -315,3 +319,36 @@ def test_abi_gather_single_rank_moves_the_record(oracle):
     L.rmcv_comm_destroy.argtypes = [C.c_void_p]
     L.rmcv_comm_destroy(h)
     c.close()
+
+
+def test_run_ahead_changes_nothing_but_the_timing(oracle):
+    """RMCV_OPT_RUN_AHEAD: rmcv_extract_color enqueues the filters with the previous frame's parameters; the filter calls hand
+    the results over when this frame asks for the same.  Same results with it on and off, with parameters that stay, change and
+    change back, and when a caller edits the lists in between"""
+    from rmcv_amd import OPT_RUN_AHEAD
+    frames = [synth.frame(i, 1280, 1024, CAMP_BLUE, i % 2) for i in range(30, 38)]
+    gates = [dict(), dict(), dict(tilt_max=20.0, ratio_range=(3.0, 10.0)), dict(), dict(), dict(area_range=(50.0, 500.0)), dict(), dict()]
+    pairs = [dict(), dict(), dict(), dict(shear_max=40.0), dict(), dict(), dict(), dict()]
+    out = {}
+    for mode in (1, 0):
+        c = Context(device=0, max_frames=1, max_width=1280, max_height=1024)
+        c.set_option(OPT_RUN_AHEAD, mode)
+        res = []
+        for k, f in enumerate(frames):
+            pts, offs, binary = c.extract_color_csr(f)
+            if k == 6:                                         # a caller that drops the last contour: nothing run ahead may be used
+                pts, offs = pts[:offs[-2]].copy(), offs[:-1].copy()
+            blobs, src, neg = c.filter_lightblobs(pts, offs, **gates[k])
+            arm = c.filter_armours(blobs, **pairs[k])
+            res.append((pts.tobytes(), offs.tobytes(), binary.tobytes(), blobs.tobytes(), src.tobytes(), neg.tobytes(), arm.tobytes()))
+            # against the oracle with the same parameters
+            g = gates[k]
+            p = oracle.default_params(tilt_max=g.get("tilt_max", 70.0), ratio_lo=g.get("ratio_range", (1.5, 80.0))[0],
+                                      ratio_hi=g.get("ratio_range", (1.5, 80.0))[1], area_lo=g.get("area_range", (10.0, 99999.0))[0],
+                                      area_hi=g.get("area_range", (10.0, 99999.0))[1], shear_max=pairs[k].get("shear_max", 22.0))
+            rb, rs, rn = oracle.filter_lightblobs(pts, offs, p)
+            assert blobs.tobytes() == rb.tobytes() and np.array_equal(neg, rn), (mode, k)
+            assert arm.tobytes() == oracle.filter_armours(rb, p).tobytes(), (mode, k)
+        out[mode] = res
+        c.close()
+    assert out[0] == out[1]
