@@ -104,27 +104,32 @@ __device__ __forceinline__ void normal_refine(NormalFac& Fac, int n, int lane, d
         double xs[K];
 #pragma unroll
         for (int a = 0; a < K; a++) xs[a] = xv.get(a);
-        // one accumulator at a time (the rows are cheap to make again, registers are not: the sparse kernel's budget is 160)
-        LaneVec h(lane);
-#pragma unroll 1
-        for (int a = 0; a < K; a++) {
-            double acc = 0.0;
-#pragma unroll 1
-            for (int i = lane; i < n; i += 64) {
-                double row[K];
-                make_row(i, row);
-                double t = row[0] * xs[0];
+        double acc[K];
 #pragma unroll
-                for (int b = 1; b < K; b++) t += row[b] * xs[b];
-                const double r = bconst - t;
-                double ra = row[0];
+        for (int a = 0; a < K; a++) acc[a] = 0.0;
+#pragma unroll 1
+        for (int i = lane; i < n; i += 64) {
+            double row[K];
+            make_row(i, row);
+            double t = row[0] * xs[0];
 #pragma unroll
-                for (int b = 1; b < K; b++) ra = a == b ? row[b] : ra;
-                acc += ra * r;
-            }
-            const double ha = wave_sum_f64(acc);
-            h.reg = lane == a ? ha : h.reg;
+            for (int b = 1; b < K; b++) t += row[b] * xs[b];
+            const double r = bconst - t;
+#pragma unroll
+            for (int a = 0; a < K; a++) acc[a] += row[a] * r;
         }
+        // the K butterflies of wave_sum_f64 stage by stage, so that the K shuffles of a stage are in flight together (the same
+        // additions in the same order as K separate reductions, whose dependent round trips would follow one another)
+        for (int d = 32; d >= 1; d >>= 1) {
+            double o[K];
+#pragma unroll
+            for (int a = 0; a < K; a++) o[a] = __shfl_xor(acc[a], d);
+#pragma unroll
+            for (int a = 0; a < K; a++) acc[a] += o[a];
+        }
+        LaneVec h(lane);
+#pragma unroll
+        for (int a = 0; a < K; a++) h.reg = lane == a ? acc[a] : h.reg;
         double dx[5];
         normal_apply(Fac, h, dx, lane);
 #pragma unroll
