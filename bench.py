@@ -55,14 +55,17 @@ def parse_args(argv=None):
                          "legacy: c3 with rm::FindLightBlobs(fitEllipse=false) as the blob stage")
     ap.add_argument("--pose", action="store_true",
                     help="add the pose stage (rm::solve_PnP + world position per armour, SURVEY 8f-3) to every step")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="contexts (buffer sets) the steps are pipelined over (1 = strictly serial steps)")
-    ap.add_argument("--mode", choices=("pipeline", "alternate"), default="alternate",
-                    help="alternate (default): whole steps on streams of alternating priority; pipeline: all pixel kernels on "
-                         "one stream, the sparse stages on higher-priority streams, chained by events (measured 5-10 % slower)")
-    ap.add_argument("--gather", choices=("torch", "abi"), default="torch",
-                    help="the armour-list gather of a launched run: torch.distributed.gather (default) or rmcv_gather, the C-ABI "
-                         "entry point that calls RCCL itself (what a C++ host uses)")
+    ap.add_argument("--mode", choices=("pipeline", "alternate"), default="pipeline",
+                    help="pipeline (default): the pixel kernels of consecutive steps alternate over --pixel-streams streams, the sparse "
+                         "stages run on --sparse-streams higher-priority streams, a step's two halves chained by events; alternate: "
+                         "whole steps on one stream per context (round 1's schedule: the same steady state, a longer ramp)")
+    ap.add_argument("--pixel-streams", type=int, default=2)
+    ap.add_argument("--sparse-streams", type=int, default=2)
+    ap.add_argument("--gather", choices=("torch", "abi"), default="abi",
+                    help="the armour-list gather of a launched run: rmcv_gather, the C-ABI entry point that calls RCCL itself (what a "
+                         "C++ host uses; default), or torch.distributed.gather")
     return ap.parse_args(argv)
 
 
@@ -182,14 +185,41 @@ def main():
     head, _ = rdist.record_layout(n, cap)
     recs_buf = [rdist.new_record(n, cap, dev) for _ in range(ns)]
     gather_out = [rdist.new_gather_list(r) if use_dist else None for r in recs_buf]   # rank 0's receive buffers, one set per stream
-    abi_gather = rdist.AbiGather(local_rank) if (use_dist and args.gather == "abi") else None   # RCCL called by librmcv_hip itself
-    abi_recv = [abi_gather.new_recv(r) for r in recs_buf] if abi_gather else None
+    # The gather of a step is enqueued on the stream its record was produced on (a gather stream of its own added stream-to-queue
+    # sharing and event hops that cost 0.07 ms per step).  A communicator's operations must execute in ONE order on every rank;
+    # the steps' gathers are issued in step order but on alternating streams, so each gather first waits (an event, on the GPU)
+    # for the previous step's gather -- ONE communicator: a second RCCL communicator in the process cost 0.07 ms per step
+    # by itself (0.335-0.343 against 0.268-0.284 ms, same box).  torch.distributed.gather synchronises the calling stream with the
+    # process group's own stream, which in the pipelined schedule holds up the next step's sparse kernels (711-721 k frames/s).
+    abi_gathers = [rdist.AbiGather(local_rank)] if (use_dist and args.gather == "abi") else None
+    ev_gath = [torch.cuda.Event() for _ in range(ns)]
+    abi_recv = [abi_gathers[0].new_recv(r) for r in recs_buf] if abi_gathers else None
+    gather_note = args.gather if use_dist else None
+    if abi_gathers:
+        # self-check before anything is timed: the communicator moves a stamped record from every rank to its slot on the root
+        probe = torch.full((4096,), rank + 1, dtype=torch.uint8, device=dev)
+        rb = abi_gathers[0].new_recv(probe)
+        parts = abi_gathers[0].gather(probe, rb, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ok = 1
+        if rank == 0 and any(int(pt.min()) != r_ + 1 or int(pt.max()) != r_ + 1 for r_, pt in enumerate(parts)):
+            ok = 0
+        t_ok = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.broadcast(t_ok, src=0)
+        if int(t_ok.item()) != 1:          # never time a path that moved wrong bytes: fall back to torch.distributed.gather, and say so
+            abi_gathers[0].close()
+            abi_gathers, abi_recv, gather_note = None, None, "torch (rmcv_gather failed its self-check)"
 
-    def gather_step(k, hs):
+    def gather_step(k, hs, stream_index):
         if not use_dist:
             return [recs_buf[k]]
-        if abi_gather:
-            return abi_gather.gather(recs_buf[k], abi_recv[k], hs)
+        if abi_gathers:
+            cur = torch.cuda.current_stream()
+            if step_no[0] > 1:
+                cur.wait_event(ev_gath[(k - 1) % ns])     # the previous step's gather (step_no was advanced already)
+            out = abi_gathers[0].gather(recs_buf[k], abi_recv[k], hs)
+            ev_gath[k].record(cur)
+            return out
         return rdist.gather_records(recs_buf[k], out=gather_out[k])
     # one stream per batch in flight (priorities alternate; with GPU_MAX_HW_QUEUES = 6 every stream has its own hardware queue, which is
     # what lets kernels of two steps actually run concurrently
@@ -199,12 +229,11 @@ def main():
     step_no = [0]
     # software pipeline: stream A carries only k_binary (HBM-bound), stream B (higher priority) the sparse stages;
     # step i's sparse chain waits for its own pixel kernel, the pixel kernel of step i+ns waits for the buffers
-    sA = torch.cuda.Stream(device=dev, priority=0)
-    sBs = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(max(1, ns - 1))]
+    sAs = [torch.cuda.Stream(device=dev, priority=0) for _ in range(max(1, args.pixel_streams))]
+    sBs = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(max(1, args.sparse_streams))]
     ev_bin = [torch.cuda.Event() for _ in range(ns)]
     ev_done = [torch.cuda.Event() for _ in range(ns)]
     pipelined = args.mode == "pipeline" and ns > 1
-    sparse_stages = stages & ~STAGE_BINARY
 
     cur_stages = [stages]
 
@@ -216,18 +245,19 @@ def main():
             with torch.cuda.stream(streams[k]):
                 run_path(ctxs[k], cur_stages[0], streams[k].cuda_stream)
                 ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
-                return gather_step(k, streams[k].cuda_stream)
+                return gather_step(k, streams[k].cuda_stream, k)
+        sA = sAs[(step_no[0] - 1) % len(sAs)]
         with torch.cuda.stream(sA):
             if not first_use:
                 sA.wait_event(ev_done[k])
-            ctxs[k].run(params, STAGE_BINARY, sA.cuda_stream)
+            ctxs[k].run(params, cur_stages[0] & (STAGE_BINARY | STAGE_NO_IMAGE), sA.cuda_stream)
             ev_bin[k].record(sA)
         sB = sBs[k % len(sBs)]
         with torch.cuda.stream(sB):
             sB.wait_event(ev_bin[k])
-            run_path(ctxs[k], sparse_stages, sB.cuda_stream)
+            run_path(ctxs[k], cur_stages[0] & ~(STAGE_BINARY | STAGE_NO_IMAGE), sB.cuda_stream)
             ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), sB.cuda_stream)
-            out = gather_step(k, sB.cuda_stream)
+            out = gather_step(k, sB.cuda_stream, k % len(sBs))
             ev_done[k].record(sB)
             return out
 
@@ -261,12 +291,13 @@ def main():
         barrier()
     # the timed region: EXACTLY --steps steps between two (barrier + synchronize), MAX over ranks; repeated --repeats times,
     # value = the median repeat (median and min over the passes)
-    rep_dt = []
+    rep_dt, enq_dt = [], []
     for _ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             recs = step()
+        enq_dt.append(time.perf_counter() - t0)       # host time to enqueue the region's steps (the GPU may still be running them)
         barrier()
         rep_dt.append(agree_max(time.perf_counter() - t0))
     srt = sorted(rep_dt)
@@ -360,6 +391,7 @@ def main():
         "timed_region": {"repeats": len(rep_dt), "ms_per_step_each": [round(d / args.steps * 1e3, 4) for d in rep_dt],
                          "ms_per_step_median": round(ms_per_step, 4), "ms_per_step_min": round(srt[0] / args.steps * 1e3, 4),
                          "value_at_min": round(world * n * args.steps / srt[0], 1), "warmup_steps_by_time": warm_steps,
+                         "host_enqueue_ms_per_step": round(sorted(enq_dt)[len(enq_dt) // 2] / args.steps * 1e3, 4),
                          "note": "each repeat = exactly `steps` steps between barrier+synchronize pairs; value/ms_per_step = the median repeat"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%s: batch=%d/GPU %dx%d BGR, blue lb=80, close3x3 + findContours + lightblob fit + armour "
@@ -369,9 +401,9 @@ def main():
                                                 (" + solve_PnP (IPPE square) and world position per armour" if args.pose else ""),
                                                 " + RCCL gather of armour lists (C4)" if world > 1 else ""),
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
-                   "double_buffered_steps": ns, "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "pixel_groups_per_cu": 2 if ns >= 2 else 3, "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("2-stream software pipeline" if pipelined else "alternating streams"),
+                   "double_buffered_steps": ns, "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "pixel_groups_per_cu": 2 if ns >= 2 else 3, "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("software pipeline: pixel kernels alternate over %d streams, sparse stages on %d higher-priority streams, chained by events" % (len(sAs), len(sBs)) if pipelined else "alternating streams"),
                    "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad,
-                   "rccl_ranks": (dist.get_world_size() if use_dist else None), "gather": (args.gather if use_dist else None)},
+                   "rccl_ranks": (dist.get_world_size() if use_dist else None), "gather": gather_note},
         "lone_batch_ms": {"median": round(lone[len(lone) // 2], 4), "min": round(lone[0], 4), "passes": len(lone),
                           "note": "one batch at a time on one stream, events around detect + compaction (latency, not the metric)"},
         "path_hbm_frac": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
@@ -404,7 +436,7 @@ def main():
         out["c2_binary_only"] = ex
         # detection only: the byte image `binary` is not written (RMCV_STAGE_NO_IMAGE; only the reference's debug view reads it,
         # executable/main.cpp:200-201).  NOT the metric: 3 B/px of algorithmic traffic instead of 4.
-        if not pipelined and legacy is None:
+        if legacy is None:
             cur_stages[0] = stages | STAGE_NO_IMAGE
             for _ in range(args.warmup):
                 step()
@@ -500,7 +532,12 @@ def main():
                 cpu_frame(0)
                 ts.append((time.perf_counter() - t1) * 1e3)
             out["single_frame_ms"]["cpu_port_median_ms"] = round(float(np.median(ts)), 4)
+        try:
+            cpu_model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+        except Exception:
+            cpu_model = "unknown"
         out["cpu_baseline"] = {"value": round(passes * m / dc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "cpu_model": cpu_model, "hardware_concurrency": os.cpu_count(),
                                "sample": "%d passes over the first %d frames of the same batch (%.1f s), oracle/ full path, 1 thread "
                                          "(the reference runs detection on one process_thread)" % (passes, m, dc),
                                "armours": tot}
@@ -524,8 +561,8 @@ def main():
                                          "armours": tot_all}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if abi_gather:
-        abi_gather.close()
+    for g_ in (abi_gathers or []):
+        g_.close()
     if use_dist:
         dist.destroy_process_group()
 
