@@ -166,7 +166,7 @@ def main():
     for k, c in enumerate(ctxs):
         # several batches in flight: 4 wavefronts per frame in the sparse kernel (throughput); a lone batch: 8 (latency)
         c.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
-        c.set_option(OPT_PIXEL_GROUPS, 2 if ns >= 2 else 3)       # likewise: 2 pixel workgroups per CU when batches overlap, 3 alone
+        c.set_option(OPT_PIXEL_GROUPS, int(os.environ.get("RMCV_PIXEL_GROUPS", "2" if ns >= 2 else "3")))   # likewise: 2 pixel workgroups per CU when batches overlap, 3 alone
         c.bind_device_frames(frames_k[k].data_ptr(), n, H, W, keepalive=frames_k[k])
         if svm:
             c.svm_load(*svm)
