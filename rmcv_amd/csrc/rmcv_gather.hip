@@ -48,9 +48,14 @@ template <typename F> bool sym(F& f, const char* name)
 const Rccl* rccl()
 {
     std::call_once(g_once, [] {
-        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        // first a copy the process already carries (PyTorch bundles one without a version in its name), then the system's
+        for (const char* n : {"librccl.so.1", "librccl.so"}) {
+            g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
             if (g_rccl.h) break;
+        }
+        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (g_rccl.h) break;
+            g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!g_rccl.h) {
             snprintf(g_rccl.err, sizeof(g_rccl.err), "cannot load librccl.so.1: %s", dlerror());
