@@ -20,6 +20,8 @@
 // outside the image never win, i.e. they read 0 for the dilate and 1 for the erode.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "rmcv_internal.h"
 
 namespace rmcv {
@@ -362,37 +364,46 @@ template <int CA, int CB>
 static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, int groups, hipStream_t s)
 {
     const int strips = (g.h + SR - 1) / SR;
-    const int n_blocks = g.n_frames * strips;
     int lb = lower_bound, all_pass = 0;
     if (lb <= 0) { all_pass = 1; lb = 1; }
     if (lb > 256) lb = 256;
     const size_t planes = (size_t)2 * (SR + 4) * g.ww * sizeof(uint64_t);
-    const int64_t lim = 0xFFFFFF00ll; // 32-bit buffer offsets
-    const bool fast = (g.w % 64 == 0) && (g.stride % 16 == 0) && (g.frame_pitch % 16 == 0) && ((uintptr_t)b.frames % 16 == 0) &&
-                      (int64_t)g.n_frames * g.frame_pitch < lim && (int64_t)g.n_frames * g.plane_pitch * 8 < lim &&
-                      (int64_t)g.n_frames * g.w * g.h < lim;
-    // persistent grid: `groups` workgroups per CU (RMCV_OPT_PIXEL_GROUPS; RMCV_K1_BPC overrides for A/B runs).  Measured on
-    // MI355X: alone the kernel is fastest with 4 (0.257-0.262 ms; 0.277-0.285 with 2, 0.42 with 1) -- the default, for a lone
-    // batch.  2 (= 2 of the 8 wave slots and 2 x 80 VGPRs of every SIMD) leaves room for the pixel kernel of the next batch AND
-    // the sparse kernel of the previous one on the same CU: with 3 batches in flight 930 k frames/s against 790 k with 4.
+    const bool aligned = (g.w % 64 == 0) && (g.stride % 16 == 0) && (g.frame_pitch % 16 == 0) && ((uintptr_t)b.frames % 16 == 0);
+    // The FAST path addresses its buffers with 32-bit offsets, so one launch covers at most as many frames as keep every extent
+    // (input, byte image, bit plane) below 4 GiB - 256; a larger batch (288 GB of HBM hold 70 000 frames) is a few launches in a
+    // row on the same stream, each with its pointers advanced -- not a fall-back to the byte-wise loader.
+    const int64_t lim = 0xFFFFFF00ll;
+    const int64_t per_frame = std::max<int64_t>(std::max<int64_t>(g.frame_pitch, g.plane_pitch * 8), (int64_t)g.w * g.h);
+    const int chunk = aligned ? (int)std::min<int64_t>(g.n_frames, std::max<int64_t>(1, (lim - 1) / per_frame)) : g.n_frames;
+    const bool fast = aligned && (int64_t)chunk * per_frame < lim;
+    // persistent grid: `groups` workgroups per CU (RMCV_OPT_PIXEL_GROUPS; RMCV_K1_BPC overrides for A/B runs): alone the kernel is
+    // equally fast with 2 and 3 and slower with 4 and more; 2 leaves room on every CU for the kernels of the other batches in flight
     static const int bpc_env = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 0;
     const int bpc = bpc_env > 0 ? bpc_env : groups;
-    int grid = (g.n_cu > 0 ? g.n_cu : 256) * (bpc > 0 ? bpc : 4); // n_cu: of the context's own device
-    if (grid > ((n_blocks + 7) & ~7)) grid = (n_blocks + 7) & ~7;
-    grid = (grid + 7) & ~7;
     // tapered queue (see the kernel): 16 strips at the head (one 8-row piece per workgroup of an XCD at 2 per CU) and 32 at the tail
     static const int taper_on = getenv("RMCV_K1_TAPER") ? atoi(getenv("RMCV_K1_TAPER")) : 0; // dev knob for A/B runs: since the loads
     // became unconditional buffer operations the tapered hand-out no longer pays (0.2672 ms without against 0.2692 ms with, same box)
-    const int per_xcd = (n_blocks + 7) >> 3;
-    int taper_head = 0, taper_tail = 0;
-    if (taper_on && per_xcd >= 192) { taper_head = 16; taper_tail = 32; }
-#define RMCV_K1_LAUNCH(F)                                                                                                       \
-    launch(k_binary<CA, CB, F>, dim3(grid), dim3(256), planes, s, b.frames, g.frame_pitch, g.stride, g.n_frames, g.w, g.h, g.ww, lb, \
-           all_pass, morph, image ? b.binary : nullptr, b.bits, g.prow, g.plane_pitch, strips, n_blocks, b.rowmask, b.strip_ctr,      \
-           taper_head, taper_tail)
-    if (fast) return RMCV_K1_LAUNCH(true);
-    return RMCV_K1_LAUNCH(false);
+    for (int f0 = 0; f0 < g.n_frames; f0 += chunk) {
+        const int nf = std::min(chunk, g.n_frames - f0);
+        const int n_blocks = nf * strips;
+        int grid = (g.n_cu > 0 ? g.n_cu : 256) * (bpc > 0 ? bpc : 4); // n_cu: of the context's own device
+        if (grid > ((n_blocks + 7) & ~7)) grid = (n_blocks + 7) & ~7;
+        grid = (grid + 7) & ~7;
+        const int per_xcd = (n_blocks + 7) >> 3;
+        int taper_head = 0, taper_tail = 0;
+        if (taper_on && per_xcd >= 192) { taper_head = 16; taper_tail = 32; }
+        const uint8_t* frames = b.frames + (int64_t)f0 * g.frame_pitch;
+        uint8_t* binary = image ? b.binary + (int64_t)f0 * g.w * g.h : nullptr;
+        uint64_t* bits = b.bits + (int64_t)f0 * g.plane_pitch;
+        uint32_t* rowmask = b.rowmask + (int64_t)f0 * g.h;
+#define RMCV_K1_LAUNCH(F)                                                                                                          \
+    launch(k_binary<CA, CB, F>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
+           morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail)
+        const hipError_t e = fast ? RMCV_K1_LAUNCH(true) : RMCV_K1_LAUNCH(false);
 #undef RMCV_K1_LAUNCH
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s)

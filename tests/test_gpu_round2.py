@@ -352,3 +352,24 @@ def test_run_ahead_changes_nothing_but_the_timing(oracle):
         out[mode] = res
         c.close()
     assert out[0] == out[1]
+
+
+def test_batch_beyond_the_32_bit_extent_keeps_the_fast_path(oracle):
+    """1100 frames of 1280x1024 are 4.3 GB of input: more than one launch of the pixel kernel can address with its 32-bit buffer
+    offsets.  The library splits such a batch into launches over frame ranges (same stream, pointers advanced); every stage of a
+    sample of frames -- the first, the ones around the split, the last -- against the oracle"""
+    n = 1100
+    lim = 0xFFFFFF00
+    split = (lim - 1) // (3 * 1280 * 1024)                       # frames per launch (the input is the largest extent)
+    assert 1 < split < n
+    c = Context(device=0, max_frames=n, max_width=1280, max_height=1024, max_points=16384, max_contours=512)
+    frames = synth.batch(300000, n, 1280, 1024, CAMP_BLUE, 1, threads=16)
+    arm, offs = c.detect_batch(frames)
+    assert not (c.counts()["status"] & 15).any()
+    for f in (0, 1, split - 1, split, split + 1, 2 * split - 1 if 2 * split - 1 < n else n - 2, n - 1):
+        ref = oracle.detect_frame(frames[f])
+        assert np.array_equal(c.binary(f), ref["binary"]), f
+        pts, co = c.contours(f)
+        assert np.array_equal(co, ref["offs"]) and np.array_equal(pts, ref["pts"]), f
+        assert arm[offs[f]:offs[f + 1]].tobytes() == ref["armours"].tobytes(), f
+    c.close()
