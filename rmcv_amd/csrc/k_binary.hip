@@ -32,6 +32,9 @@ namespace rmcv {
 #ifndef RMCV_K1_UNROLL
 #define RMCV_K1_UNROLL 4
 #endif
+#ifndef RMCV_K1_STAUX
+#define RMCV_K1_STAUX 2 // cache-policy bits of the byte-image stores (2 = nt)
+#endif
 #ifndef RMCV_K1_LDAUX
 #define RMCV_K1_LDAUX 0 // cache-policy bits of the frame loads (dev knob; 2 = nt)
 #endif
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
 #else
                 const uint32_t off = ok ? bin_base + __umul24(y, w) + (uint32_t)q * 16u : OOB;
 #endif
-                __builtin_amdgcn_raw_buffer_store_b128(o, r_bin, off, 0, 2 /* nt: written once, read by nobody here */);
+                __builtin_amdgcn_raw_buffer_store_b128(o, r_bin, off, 0, RMCV_K1_STAUX /* nt: written once, read by nobody here */);
                 q += q_step;
                 s_ += r_step;
                 if (q >= wq) { q -= wq; s_++; }
