@@ -804,6 +804,30 @@ static void get_ofs(int i, float eps, float* ox, float* oy)
     *oy = (float)(((i & 2) - 1)) * eps;
 }
 
+/* G = A^T A (k x k, both triangles filled) and g = A^T (bconst, ..., bconst) of the n x k design matrix given by make_row, summed
+ * the way the device sums them: 64 partial sums over the points i = l, l + 64, ... in increasing i, then the butterfly.  (The
+ * direct fit's scatter matrix keeps OpenCV's sequential order; this matrix only seeds the refinement, whose fixed point does
+ * not depend on its rounding.) */
+static void normal_equations(row_fn make_row, const void* ctx, int n, int k, double bconst, double* G, double* g)
+{
+    double pg[25][64], pv[5][64];
+    memset(pg, 0, sizeof(pg));
+    memset(pv, 0, sizeof(pv));
+    for (int l = 0; l < 64; l++)
+        for (int i = l; i < n; i += 64) {
+            double row[5];
+            make_row(ctx, i, row);
+            for (int a = 0; a < k; a++) {
+                for (int b = a; b < k; b++) pg[a * k + b][l] += row[a] * row[b];
+                pv[a][l] += row[a] * bconst;
+            }
+        }
+    for (int a = 0; a < k; a++) {
+        for (int b = a; b < k; b++) G[a * k + b] = G[b * k + a] = butterfly64(pg[a * k + b]);
+        g[a] = butterfly64(pv[a]);
+    }
+}
+
 /* design-matrix rows of the general fit (the n x 5 and n x 3 matrices of [OCV] fitEllipseNoDirect), produced on demand */
 typedef struct { const orc_point* pts; float cx, cy; double scale; float eps; double r0, r1; } gen_rows;
 static void gen_pxy(const gen_rows* R, int i, double* px, double* py)
@@ -852,19 +876,8 @@ static void fit_ellipse_general(const orc_point* pts, int n, orc_rrect* box)
     for (int iter = 0; iter < 2; iter++) {
         double G[25], g[5];
         normal_fac F;
-        memset(G, 0, sizeof(G));
-        memset(g, 0, sizeof(g));
         R.eps = iter ? eps : 0.0f;
-        for (int i = 0; i < n; i++) {
-            double row[5];
-            gen_row5(&R, i, row);
-            for (int a = 0; a < 5; a++) {
-                for (int b = a; b < 5; b++) G[a * 5 + b] += row[a] * row[b];
-                g[a] += row[a] * 10000.0;
-            }
-        }
-        for (int a = 0; a < 5; a++)
-            for (int b = 0; b < a; b++) G[a * 5 + b] = G[b * 5 + a];
+        normal_equations(gen_row5, &R, n, 5, 10000.0, G, g);
         normal_factor(G, 5, &F);
         if (iter == 0 && F.wmax * FLT_EPSILON > F.wmin) {
             eps = (float)(s / (n * 2) * 1e-3);
@@ -887,21 +900,10 @@ static void fit_ellipse_general(const orc_point* pts, int n, orc_rrect* box)
     {
         double G[9], g[3];
         normal_fac F;
-        memset(G, 0, sizeof(G));
-        memset(g, 0, sizeof(g));
         R.eps = eps;
         R.r0 = rp[0];
         R.r1 = rp[1];
-        for (int i = 0; i < n; i++) {
-            double row[5];
-            gen_row3(&R, i, row);
-            for (int a = 0; a < 3; a++) {
-                for (int b = a; b < 3; b++) G[a * 3 + b] += row[a] * row[b];
-                g[a] += row[a] * 1.0;
-            }
-        }
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < a; b++) G[a * 3 + b] = G[b * 3 + a];
+        normal_equations(gen_row3, &R, n, 3, 1.0, G, g);
         normal_factor(G, 3, &F);
         normal_apply(&F, g, gfp);
         normal_refine(&F, gen_row3, &R, n, 1.0, gfp);

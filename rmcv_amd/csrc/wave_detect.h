@@ -81,6 +81,41 @@ __device__ __forceinline__ double seq_sum_products(int n, int lane, WaveLds& L, 
     return acc;
 }
 
+// The sums of the GENERAL fit's normal equations (oracle/rmcv_oracle.c fit_ellipse_general): the upper triangle of row x row
+// (K (K + 1) / 2 sums) then row[a] * konst (K sums), written to out[] in that order by every lane (wave-uniform).  Unlike the
+// direct fit's scatter matrix, whose summation order restates OpenCV's, the order here is the build's own, and it is the
+// wave-shaped one of normal_refine: every lane sums its own points (i = lane, lane + 64, ... in increasing i), then one
+// butterfly per sum (strides 32 .. 1).  As sequential chains in point order these two passes cost 10 and 6 us per contour.
+template <int K, typename F>
+__device__ __forceinline__ void par_sum_products(int n, int lane, double konst, double* out, F make_row)
+{
+    constexpr int NT = K * (K + 1) / 2, NS = NT + K;
+    double acc[NS];
+#pragma unroll
+    for (int e = 0; e < NS; e++) acc[e] = 0.0;
+#pragma unroll 1
+    for (int i = lane; i < n; i += 64) {
+        double row[K];
+        make_row(i, row);
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < K; a++)
+#pragma unroll
+            for (int b = a; b < K; b++, e++) acc[e] += row[a] * row[b];
+#pragma unroll
+        for (int a = 0; a < K; a++) acc[NT + a] += row[a] * konst;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        double o[NS];
+#pragma unroll
+        for (int e = 0; e < NS; e++) o[e] = __shfl_xor(acc[e], d);
+#pragma unroll
+        for (int e = 0; e < NS; e++) acc[e] += o[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NS; e++) out[e] = acc[e];
+}
+
 // upper-triangle index e -> (a, b), a <= b, row-major, for a k x k symmetric matrix
 __device__ __forceinline__ void tri_index(int e, int k, int* a, int* b)
 {
@@ -224,8 +259,13 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
                 const double px = fx * scale, py = fy * scale;
                 r[0] = -px * px; r[1] = -py * py; r[2] = -px * py; r[3] = px; r[4] = py;
             };
-            const double acc = seq_sum_products<5>(n, lane, L, 20, la, lb, 10000.0, row5);
-            if (lane < 20) L.dm[lane] = acc;
+            {
+                double sums[20];
+                par_sum_products<5>(n, lane, 10000.0, sums, row5);
+#pragma unroll
+                for (int e = 0; e < 20; e++)
+                    if (lane == e) L.dm[e] = sums[e];
+            }
             __builtin_amdgcn_wave_barrier();
             LaneVec G(lane), g(lane);
             { // lane a*5+b takes G(a,b) = G(b,a) from the upper-triangle sums; lane a takes g(a)
@@ -259,8 +299,13 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
             const double px = fx * scale, py = fy * scale;
             r[0] = (px - r0) * (px - r0); r[1] = (py - r1) * (py - r1); r[2] = (px - r0) * (py - r1);
         };
-        const double acc = seq_sum_products<3>(n, lane, L, 9, la, lb, 1.0, row3);
-        if (lane < 9) L.dm[lane] = acc;
+        {
+            double sums[9];
+            par_sum_products<3>(n, lane, 1.0, sums, row3);
+#pragma unroll
+            for (int e = 0; e < 9; e++)
+                if (lane == e) L.dm[e] = sums[e];
+        }
         __builtin_amdgcn_wave_barrier();
         LaneVec G(lane), g(lane);
         {
