@@ -8,8 +8,9 @@
 // (split x3, subtract, inRange, dilate, erode, findContours' copy); here every intermediate lives
 // in registers or LDS:
 //
-//   phase 1  each lane loads 16 px = 48 contiguous bytes (3 x dwordx4), thresholds them to a 16-bit
-//            mask, 4 lanes merge to one u64 word of the strip's bit plane T in LDS
+//   phase 1  a wave loads a 256-px block of four rows with four coalesced dwordx3 (lane i: pixels 4i..4i+3 of each
+//            row), thresholds its 16 px to a 16-bit mask, a lane quad transposes its 4x4 nibbles (2 DPP exchanges) and
+//            each lane writes 16 bits of one row of the strip's bit plane T in LDS
 //   phase 2  dilate on the bit plane  D = hdil(T[y-1] | T[y] | T[y+1])          (64 px / lane-op)
 //   phase 3  erode                    E = hero(D[y-1] & D[y] & D[y+1])
 //   phase 4  E -> 0/255 bytes, 16 px per lane, one coalesced dwordx4 store; E word -> bit plane
@@ -21,6 +22,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "rmcv_internal.h"
 
@@ -36,7 +38,7 @@ namespace rmcv {
 #define RMCV_K1_STAUX 2 // cache-policy bits of the byte-image stores (2 = nt)
 #endif
 #ifndef RMCV_K1_LDAUX
-#define RMCV_K1_LDAUX 0 // cache-policy bits of the frame loads (dev knob; 2 = nt)
+#define RMCV_K1_LDAUX 2 // cache-policy bits of the frame loads that no other workgroup shares (2 = nt)
 #endif
 static constexpr int SR = RMCV_SR; // strip rows per workgroup
 
@@ -46,33 +48,30 @@ __device__ __forceinline__ uint32_t expand4(uint32_t nib)
 }
 
 // 16 pixels (48 bytes in 12 dwords) -> 16-bit mask of (a - b >= lb), two pixels per packed-16 operation:
-//   v_perm_b32 gathers byte a of pixels p, p+1 into the two halves of a dword (same for b),
+//   v_perm_b32 gathers byte a of pixels p and p+8 (24 bytes = 6 dwords apart) into the two halves of a dword (same for b),
 //   t = (A + (0x8000 - lb)) - B per half: bit 15 of a half is set  <=>  a - b - lb >= 0   (|a - b - lb| < 2^15),
-// the flags of the 8 pairs are collected as two 8-bit fields and bit-interleaved once at the end.
+// the flags are collected by shifting the accumulator (bit 15 -> pixels 0..7 end in bits 8..15, bit 31 -> pixels 8..15 in bits
+// 24..31) and one last v_perm picks the two bytes: 6 operations per pair of pixels.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 template <int CA, int CB>
 __device__ __forceinline__ uint32_t thresh16(const uint32_t d[12], int lb)
 {
     const uint32_t kk = (uint32_t)(0x8000 - lb) & 0xFFFFu;
     const uint32_t K = kk | (kk << 16);
-    uint32_t acc = 0; // bit i: pixel 2i, bit 16+i: pixel 2i+1
+    uint32_t acc = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int ia = 6 * j + CA, ib = 6 * j + CB; // byte offsets of pixel 2j; pixel 2j+1 is 3 bytes further
+        const int ia = 3 * j + CA, ib = 3 * j + CB; // byte offsets of pixel j; pixel j+8 is 24 bytes = 6 dwords further
         // v_perm_b32(S0, S1, sel): selector 0..3 = bytes of S1, 4..7 = bytes of S0, 0x0c = zero
-        const uint32_t sa = (uint32_t)(ia & 3) | (0x0cu << 8) | ((uint32_t)((ia & 3) + 3) << 16) | (0x0cu << 24);
-        const uint32_t sb = (uint32_t)(ib & 3) | (0x0cu << 8) | ((uint32_t)((ib & 3) + 3) << 16) | (0x0cu << 24);
-        const uint32_t A = __builtin_amdgcn_perm(d[(ia >> 2) + 1 < 12 ? (ia >> 2) + 1 : 11], d[ia >> 2], sa);
-        const uint32_t B = __builtin_amdgcn_perm(d[(ib >> 2) + 1 < 12 ? (ib >> 2) + 1 : 11], d[ib >> 2], sb);
+        const uint32_t sa = (uint32_t)(ia & 3) | (0x0cu << 8) | ((uint32_t)((ia & 3) + 4) << 16) | (0x0cu << 24);
+        const uint32_t sb = (uint32_t)(ib & 3) | (0x0cu << 8) | ((uint32_t)((ib & 3) + 4) << 16) | (0x0cu << 24);
+        const uint32_t A = __builtin_amdgcn_perm(d[(ia >> 2) + 6], d[ia >> 2], sa);
+        const uint32_t B = __builtin_amdgcn_perm(d[(ib >> 2) + 6], d[ib >> 2], sb);
         u16x2 t = __builtin_bit_cast(u16x2, A) + __builtin_bit_cast(u16x2, K);
         t = t - __builtin_bit_cast(u16x2, B);
-        acc |= ((__builtin_bit_cast(uint32_t, t) >> 15) & 0x00010001u) << j;
+        acc = (acc >> 1) | (__builtin_bit_cast(uint32_t, t) & 0x80008000u);
     }
-    // interleave the two 8-bit fields: pixel 2i -> bit 2i, pixel 2i+1 -> bit 2i+1
-    acc = (acc | (acc << 4)) & 0x0F0F0F0Fu;
-    acc = (acc | (acc << 2)) & 0x33333333u;
-    acc = (acc | (acc << 1)) & 0x55555555u;
-    return (acc & 0xFFFFu) | ((acc >> 16) << 1);
+    return __builtin_amdgcn_perm(0u, acc, 0x0c0c0301u); // byte 1 (pixels 0..7), byte 3 (pixels 8..15)
 }
 
 // n / d for n < 2^16 with a precomputed reciprocal r = ceil(2^32 / d) (exact in that range); d == 1 gives r == 0
@@ -87,6 +86,7 @@ __device__ __forceinline__ int div_r(int n, uint32_t r) { return r ? (int)__umul
 // loads compiled out).
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3v __attribute__((ext_vector_type(3)));
 static constexpr uint32_t OOB = 0xFFFFFF00u; // voffset of a lane that moves nothing (extents are checked below 4 GiB - 256)
 static constexpr int RSRC3 = 0x00020000;     // raw buffer descriptor word 3, gfx9 family
 
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
     const int k_step = 256 - (int)div_r(256, r_ww) * ww, s_step = div_r(256, r_ww);
     // 8 mask bits -> 8 bytes of 0/255: a 256-entry table in LDS instead of two multiplies per nibble (phase 4)
     __shared__ uint64_t s_lut[256];
+    __shared__ uint16_t s_spare[256]; // where a lane without a place in the plane writes (no write sits behind a branch)
     if (FAST) s_lut[tid] = (uint64_t)expand4(tid) | ((uint64_t)expand4(tid >> 4) << 32);
     for (;;) {
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
@@ -150,50 +151,106 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
 
     // ---------------- phase 1: load + threshold -> T
     if (FAST) {
-        // U items per thread per iteration: all 3*U loads are issued before the first threshold (memory-level
+        // U items per wave per iteration: all 4*U loads are issued before the first threshold (memory-level
         // parallelism per wave); every 16-bit mask goes straight to its place in the LDS plane (ds_write_b16)
         constexpr int U = RMCV_K1_UNROLL;
         const int items = srh * wq;
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint8_t*>(frames), 0, (int)((int64_t)(n_frames - 1) * frame_pitch + (int64_t)(h - 1) * stride + 3 * w), RSRC3);
         const uint32_t fbase = (uint32_t)((int64_t)f * frame_pitch);
-        int rq = r_first, q = q_first; // (row, group) of item it0 + 256 * u, stepped
-        for (int it0 = tid; it0 < items; it0 += 256 * U) {
-            u32x4v v[U][3];
-            int rq_[U]; // row of the strip << 16 | 16-pixel group; -1: beyond the strip's items
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int it = it0 + 256 * u;
-                // neighbouring strips share halo rows: odd strips sweep top->bottom, even strips bottom->top, so a
-                // shared row is requested by both workgroups at about the same time and one of them hits in L2
-                const int rr = (L & 1) ? rq : srh - 1 - rq;
-                const int y = y0 - halo + rr;
-                const bool ok = it < items && y >= 0 && y < h;
-                rq_[u] = it < items ? (rr << 16) | q : -1;
-#ifdef RMCV_K1_NOLOAD
-                const uint32_t off = OOB;
-#else
-                const uint32_t off = ok ? fbase + __umul24(y, stride) + __umul24(q, 48) : OOB; // y, stride, q < 2^24
-#endif
-                v[u][0] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 0, RMCV_K1_LDAUX);
-                v[u][1] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 16, RMCV_K1_LDAUX);
-                v[u][2] = __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 32, RMCV_K1_LDAUX);
+        // Wave-coalesced loads: an item is a 256-pixel block of FOUR rows; lane i loads pixels 4i..4i+3 of each row with one
+        // dwordx3, so the wave reads 768 contiguous bytes = six whole cache lines per instruction and every line is touched by
+        // exactly one instruction -- which is what lets the loads carry the non-temporal hint (round 2 measured it: per-lane
+        // 48-byte loads touch a line with three instructions and lose 15-30 % with the hint; these gain 13 % with it,
+        // profiles/r02d_k_binary_coalesced_x3.txt).  The 12 dwords of a lane are 16 whole pixels (thresh16): bit 4k+t = row k,
+        // pixel 4i+t; the four lanes of a quad then transpose their 4x4 nibbles with two DPP exchanges, after which lane l of the
+        // quad holds the 16 mask bits of row l and writes them with one ds_write_b16.  The item's (row quad, block) is
+        // wave-uniform: its address arithmetic runs on the scalar unit.
+        const int lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int nb = (w + 255) >> 8, nq = (srh + 3) >> 2, n_it = nq * nb;
+        const uint32_t r_nb = (uint32_t)((0x100000000ull + nb - 1) / nb);
+        const uint32_t lane_off = (uint32_t)lane * 12u;
+        const uint32_t lds_lane = (uint32_t)__umul24(lane & 3, ww) * 8u + (uint32_t)(lane >> 2) * 2u;
+        const uint32_t M1 = (lane & 1) ? 0xF0F0u : 0x0F0Fu, S1 = (lane & 1) ? 12u : 4u;
+        const uint32_t P2 = (lane & 2) ? 0x0c0c0105u : 0x0c0c0400u;
+        constexpr uint32_t OOB_S = 0xFFFFFC00u; // scalar part of an offset that moves nothing (+ 63 * 12 stays out of extent)
+        const int rr_lo = max(0, halo - y0), rr_hi = min(srh, h - y0 + halo); // the strip's rows that lie inside the image
+        const uint32_t rr_span = (uint32_t)(rr_hi - rr_lo);
+        const uint32_t strip_base = fbase + (uint32_t)(y0 - halo) * (uint32_t)stride; // wraps for the rows above the image: never used
+        const int ragged = (w & 255) ? 1 : 0;
+        const bool plain = rr_lo == 0 && rr_hi == srh && (srh & 3) == 0 && !ragged; // the strip needs no validity selects at all
+        uint32_t dk1 = (uint32_t)stride, dk2 = 2u * (uint32_t)stride, dk3 = 3u * (uint32_t)stride;
+        asm volatile("" : "+s"(dk1), "+s"(dk2), "+s"(dk3)); // opaque: otherwise every row's offset is re-derived with its own multiply
+        if (all_pass) {
+            int rq = r_first, q = q_first;
+            for (int it = tid; it < items; it += 256) {
+                const int y = y0 - halo + rq;
+                reinterpret_cast<uint16_t*>(T + __umul24(rq, ww))[q] = (y >= 0 && y < h) ? 0xFFFFu : 0u;
                 q += q_step;
                 rq += r_step;
                 if (q >= wq) { q -= wq; rq++; }
             }
+        } else
+        for (int it0 = wv; it0 < n_it; it0 += 4 * U) {
+            // One batch = U items of the wave: all 4 * U loads are issued, then thresholded.  CHK = false is the common case (a strip
+            // with every row inside the image, whole row quads, whole 256-pixel blocks, a full batch): no validity selects.
+            auto batch = [&](auto chk) {
+                constexpr bool CHK = decltype(chk)::value;
+                u32x3v v[U][4];
+                int info[U]; // LDS byte offset of the item's (row quad, block) | ragged-block flag; -1: beyond the strip's items
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t d[12] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w, v[u][1].x, v[u][1].y,
-                                        v[u][1].z, v[u][1].w, v[u][2].x, v[u][2].y, v[u][2].z, v[u][2].w};
-                const int rr = rq_[u] >> 16, q = rq_[u] & 0xFFFF;
-                uint32_t m = thresh16<CA, CB>(d, lb); // zeros (a row outside the image) give 0: lb >= 1
-                if (all_pass) {
-                    const int y = y0 - halo + rr;
-                    m = (y >= 0 && y < h) ? 0xFFFFu : 0u;
+                for (int u = 0; u < U; u++) {
+                    const int it = it0 + 4 * u; // wave-uniform: everything up to the four vector adds runs on the scalar unit
+                    const int jq0 = div_r(it, r_nb), b = it - jq0 * nb;
+                    const int jq = (L & 1) ? jq0 : nq - 1 - jq0; // sweep direction, see below
+                    const int rr0 = 4 * jq;
+                    info[u] = (int)(__umul24(rr0, ww) * 8u + (uint32_t)b * 32u);
+                    if (CHK) info[u] = it < n_it ? info[u] | (b == nb - 1 ? ragged : 0) : -1; // bit 0: ragged block
+#ifdef RMCV_K1_NOLOAD
+                    const uint32_t base = OOB_S - dk3; // ablation build: nothing is read
+#else
+                    const uint32_t base = strip_base + (uint32_t)rr0 * (uint32_t)stride + (uint32_t)b * 768u;
+#endif
+                    const uint32_t rowk[4] = {base, base + dk1, base + dk2, base + dk3};
+                    uint32_t vo[4];
+                    // rows rr_lo <= rr < rr_hi of the strip are inside the image; the others (and a whole item beyond the
+                    // strip's) are "loaded" from beyond the extent: zeros, no traffic
+                    const uint32_t t0 = (uint32_t)(rr0 - rr_lo), span = it < n_it ? rr_span : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) vo[k] = (!CHK || t0 + (uint32_t)k < span ? rowk[k] : OOB_S) + lane_off;
+                    // the first and the last row quad hold the rows this strip shares with its neighbours: those stay
+                    // cacheable (the neighbour finds them in L2), everything else is read once and says so
+                    if (halo && (jq == 0 || jq == nq - 1)) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b96(r_in, vo[k], 0, 0);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b96(r_in, vo[k], 0, RMCV_K1_LDAUX);
+                    }
                 }
-                if (rq_[u] >= 0) reinterpret_cast<uint16_t*>(T + __umul24(rr, ww))[q] = (uint16_t)m;
-            }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t d[12] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][1].x, v[u][1].y, v[u][1].z,
+                                            v[u][2].x, v[u][2].y, v[u][2].z, v[u][3].x, v[u][3].y, v[u][3].z};
+                    uint32_t m = thresh16<CA, CB>(d, lb);
+                    // pixels beyond the row's end (w % 256 != 0, last block): the lane has read the next row's bytes
+                    if (CHK && (info[u] & 1) && lane * 4 >= w - ((nb - 1) << 8)) m = 0;
+                    // 4x4 nibble transpose within the quad: exchange with lane^1 (nibbles), then with lane^2 (bytes)
+                    const uint32_t p1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xF, 0xF, true);
+                    const uint32_t t1 = (m & M1) | (((p1 << 8) >> S1) & ~M1);
+                    const uint32_t p2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)t1, 0x4E, 0xF, 0xF, true);
+                    const uint32_t t2 = __builtin_amdgcn_perm(p2, t1, P2);
+                    uint16_t* dst = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(T) + ((uint32_t)info[u] & ~1u) + lds_lane);
+                    if (CHK) { // the quad's 16 pixels of the last block may lie beyond the row: those go to a spare word
+                        const bool in_row = !(info[u] & 1) || (lane >> 2) * 16 < w - ((nb - 1) << 8);
+                        if (!(info[u] >= 0 && in_row)) dst = s_spare + tid;
+                    }
+                    *dst = (uint16_t)t2;
+                }
+            };
+            if (plain && it0 + 4 * (U - 1) < n_it) batch(std::false_type{});
+            else batch(std::true_type{});
         }
     } else {
         const int items = srh * wq;
@@ -306,25 +363,24 @@ __global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ fram
             }
         }
         if (binary) { // RMCV_STAGE_NO_IMAGE: the 0/255 byte image is not wanted
-            const int items = sr * wq;
-            const uint32_t bin_base = (uint32_t)((int64_t)f * w * h);
-            int s_ = r_first, q = q_first;
-            for (int it = tid; it - (tid & 63) < items; it += 256) {
-                const int y = y0 + s_;
-                const bool ok = it < items && y < h;
-                uint32_t m = 0;
-                if (ok) m = reinterpret_cast<const uint16_t*>(R + __umul24(s_ + halo, ww))[q];
+            // w % 64 == 0: the strip's rows are contiguous both in the LDS plane (ww * 64 == w bits per row) and in the byte
+            // image, so the strip is ONE run of 16-pixel items: no (row, group) bookkeeping, and the loop bound is wave-uniform
+            const int n_valid = min(sr, h - y0) * wq;
+            const uint16_t* R16 = reinterpret_cast<const uint16_t*>(R + __umul24(halo, ww));
+            const uint32_t out0 = (uint32_t)((int64_t)f * w * h) + (uint32_t)y0 * (uint32_t)w;
+            const int lane = tid & 63;
+            for (int base = __builtin_amdgcn_readfirstlane(tid - lane); base < n_valid; base += 256) {
+                const int it = base + lane;
+                const bool ok = it < n_valid;
+                const uint32_t m = R16[ok ? it : 0];
                 const uint64_t lo = s_lut[m & 0xFF], hi = s_lut[m >> 8];
                 const u32x4v o = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
 #ifdef RMCV_K1_NOSTORE
                 const uint32_t off = OOB;
 #else
-                const uint32_t off = ok ? bin_base + __umul24(y, w) + (uint32_t)q * 16u : OOB;
+                const uint32_t off = ok ? out0 + (uint32_t)it * 16u : OOB;
 #endif
                 __builtin_amdgcn_raw_buffer_store_b128(o, r_bin, off, 0, RMCV_K1_STAUX /* nt: written once, read by nobody here */);
-                q += q_step;
-                s_ += r_step;
-                if (q >= wq) { q -= wq; s_++; }
             }
         }
     } else {
@@ -375,7 +431,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     // The FAST path addresses its buffers with 32-bit offsets, so one launch covers at most as many frames as keep every extent
     // (input, byte image, bit plane) below 4 GiB - 256; a larger batch (288 GB of HBM hold 70 000 frames) is a few launches in a
     // row on the same stream, each with its pointers advanced -- not a fall-back to the byte-wise loader.
-    const int64_t lim = 0xFFFFFF00ll;
+    const int64_t lim = 0xFFFFF000ll;
     const int64_t per_frame = std::max<int64_t>(std::max<int64_t>(g.frame_pitch, g.plane_pitch * 8), (int64_t)g.w * g.h);
     const int chunk = aligned ? (int)std::min<int64_t>(g.n_frames, std::max<int64_t>(1, (lim - 1) / per_frame)) : g.n_frames;
     const bool fast = aligned && (int64_t)chunk * per_frame < lim;
