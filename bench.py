@@ -363,16 +363,24 @@ def main():
     # stream, so the event/launch latency (~20 us, visible in stage_ms.binary) is amortised and the figure is the
     # kernel's duration, the same quantity rocprofv3 --kernel-trace reports
     R = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    with torch.cuda.stream(stream):
-        ctx.run(params, STAGE_BINARY, sh)
-        e0.record(stream)
-        for _ in range(R):
+    def k_binary_alone(groups):
+        ctx.set_option(OPT_PIXEL_GROUPS, groups)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
             ctx.run(params, STAGE_BINARY, sh)
-        e1.record(stream)
-    torch.cuda.synchronize()
-    k1_ms = e0.elapsed_time(e1) / R
+            e0.record(stream)
+            for _ in range(R):
+                ctx.run(params, STAGE_BINARY, sh)
+            e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / R
+    # alone the kernel runs at the library's default of 3 workgroups per CU (what `--streams 1` and a lone batch launch, and what the
+    # serial rocprofv3 summary under profiles/ shows); the pipelined steps launch it with 2 per CU, two launches overlapping
+    groups_in_steps = 2 if ns >= 2 else 3
+    k1_ms = k_binary_alone(3)
+    k1_steps_ms = k_binary_alone(groups_in_steps) if groups_in_steps != 3 else k1_ms
+    ctx.set_option(OPT_PIXEL_GROUPS, groups_in_steps)
     achieved = n * BYTES_PER_FRAME / (k1_ms * 1e-3) / 1e9
 
     traffic = None
@@ -416,7 +424,10 @@ def main():
         "roofline": {"kernel": "k_binary", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME, "avg_launch_ms": round(k1_ms, 4),
-                     "launches_timed": R},
+                     "launches_timed": R, "workgroups_per_cu": 3,
+                     "as_launched_by_the_steps": {"workgroups_per_cu": groups_in_steps, "avg_launch_ms": round(k1_steps_ms, 4),
+                                                  "frac": round(n * BYTES_PER_FRAME / (k1_steps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                  "note": "alone, back to back; in the steps two such launches overlap (4 workgroups per CU resident)"}},
     }
 
     if not args.no_extras and rank == 0:

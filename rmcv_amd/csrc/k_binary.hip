@@ -90,8 +90,11 @@ typedef uint32_t u32x3v __attribute__((ext_vector_type(3)));
 static constexpr uint32_t OOB = 0xFFFFFF00u; // voffset of a lane that moves nothing (extents are checked below 4 GiB - 256)
 static constexpr int RSRC3 = 0x00020000;     // raw buffer descriptor word 3, gfx9 family
 
+// Register budget: 6 waves per SIMD = at most 80 VGPRs.  Two launches of consecutive batches overlap (2 workgroups per CU each = 4
+// waves per SIMD) next to one wave of the 4-wavefront sparse kernel (168 VGPRs): 4 x 80 + 168 <= 512.  At 88 the sparse kernel
+// would no longer fit beside them and the batches in flight would take turns instead of sharing the CUs.
 template <int CA, int CB, bool FAST>
-__global__ __launch_bounds__(256) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride, int n_frames,
+__global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride, int n_frames,
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
