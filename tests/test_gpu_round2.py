@@ -373,3 +373,43 @@ def test_batch_beyond_the_32_bit_extent_keeps_the_fast_path(oracle):
         assert np.array_equal(co, ref["offs"]) and np.array_equal(pts, ref["pts"]), f
         assert arm[offs[f]:offs[f + 1]].tobytes() == ref["armours"].tobytes(), f
     c.close()
+
+
+@pytest.mark.parametrize("morph", [0, 1, 2])
+def test_pixel_kernel_coalesced_loader_geometries(oracle, morph):
+    """The wave-coalesced loader of k_binary (256-pixel blocks of four rows per wavefront, 12 bytes per lane): widths that are a
+    multiple of 64 but not of 256 (ragged last block), one block, many blocks; heights below, at and around the 32-row strip and
+    its row quads (1, 2, 3, 5, 31..34, 63..65); packed rows and rows / frames with padding; every camp, lb at the borders
+    (lb <= 0 passes everything, 256 nothing).  Byte image of every frame against the oracle."""
+    import torch
+    from rmcv_amd import (CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL, CAMP_RED, STAGE_BINARY, Context, default_params)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(4242 + morph)
+    widths = [64, 128, 192, 256, 320, 448, 512, 576, 768, 832, 1280, 1344]
+    heights = [1, 2, 3, 5, 31, 32, 33, 34, 63, 64, 65, 100]
+    cases = [(widths[i % len(widths)], heights[(i * 5 + morph) % len(heights)]) for i in range(24)]
+    for ci, (w, h) in enumerate(cases):
+        n = 1 + ci % 3
+        pad_row, pad_frame = [(0, 0), (16, 0), (48, 64), (0, 4096)][ci % 4]
+        stride = 3 * w + pad_row
+        pitch = stride * h + pad_frame
+        host = rng.integers(0, 256, n * pitch, dtype=np.uint8)            # padding bytes are random too: they must not matter
+        frames = np.empty((n, h, w, 3), np.uint8)
+        for f in range(n):
+            img = rng.integers(0, 48, (h, w, 3), dtype=np.uint8)
+            m = rng.random((h, w)) < 0.35                                  # dense foreground: exercises every morphology border
+            img[m] = (255, 120, 10) if ci % 2 == 0 else (10, 200, 255)
+            img[rng.random((h, w)) < 0.05] = (200, 255, 40)
+            frames[f] = img
+            for y in range(h):
+                host[f * pitch + y * stride:f * pitch + y * stride + 3 * w] = img[y].reshape(-1)
+        buf = torch.from_numpy(host).to(dev)
+        c = Context(device=0, max_frames=n, max_width=w, max_height=h)
+        c.bind_device_frames(buf.data_ptr(), n, h, w, stride=stride, frame_pitch=pitch, keepalive=buf)
+        for camp, lb in [(CAMP_BLUE, 80), (CAMP_RED, 80), (CAMP_GUIDELIGHT, 60), (CAMP_NEUTRAL, 1), (CAMP_BLUE, 0), (CAMP_RED, 256)]:
+            c.run(default_params(camp=camp, lower_bound=lb, morph=morph), STAGE_BINARY)
+            c.sync()
+            for f in range(n):
+                ref = oracle.extract_binary(frames[f], camp, lb, morph)
+                assert np.array_equal(c.binary(f), ref), (w, h, n, stride, pitch, camp, lb, f)
+        c.close()
