@@ -14,6 +14,7 @@
 
 #include "../../include/rmcv_abi.h"
 #include "pinned_math.h"
+#include "device_eig3.h"
 
 namespace rmcv {
 
@@ -420,6 +421,15 @@ __device__ inline void eig_hqr2(LaneMat3& H, LaneMat3& V, LaneVec& d, LaneVec& e
 // cv::eigenNonSymmetric: eigenvalues sorted descending (stable), eigenvectors as rows
 __device__ inline void eigen_nonsymmetric3(const double M[3][3], double eval[3], double evec[3][3], int lane)
 {
+#ifndef RMCV_EIG3_GENERAL
+    // the 3 x 3 specialisation with compile-time subscripts (device_eig3.h) on the lane-resident arrays: same operations in the
+    // same order, but an element access is a v_readlane with an immediate lane / a select against a constant mask, and there is
+    // no loop or subscript bookkeeping on the wave's dependent chain
+    Eig3T<LaneMat3, LaneVec> E(lane);
+    eig3_solve(M, E);
+    LaneVec& d = E.d;
+    LaneMat3& V = E.V;
+#else
     LaneMat3 H(lane), V(lane);
     LaneVec d(lane), e(lane);
 #pragma unroll
@@ -428,6 +438,7 @@ __device__ inline void eigen_nonsymmetric3(const double M[3][3], double eval[3],
         for (int j = 0; j < 3; j++) H[i][j] = M[i][j];
     eig_orthes(H, V, lane);
     eig_hqr2(H, V, d, e);
+#endif
     const double d0 = d.get(0), d1 = d.get(1), d2 = d.get(2);
     // insertion sort of (0,1,2) by d, descending, ties keep their order
     int i0 = 0, i1 = 1, i2 = 2;
