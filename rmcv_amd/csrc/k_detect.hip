@@ -174,14 +174,20 @@ __global__ __launch_bounds__(64) void k_pairs(const int32_t* __restrict__ slot_k
 }
 
 // frame-major compaction of the per-frame armour slots into one list + offsets (the payload of the
-// multi-GPU detection gather).  One workgroup; n_frames is a few hundred.
+// multi-GPU detection gather).  n_frames is a few hundred: EVERY workgroup scans all the counts (one read each + an LDS scan: a few
+// microseconds) and then copies the armours of its own COMPACT_FRAMES consecutive frames, one wavefront per frame, dword per lane.
+// (Round 1 had one workgroup whose threads each copied their frame's armours dword after dword: ~60 dependent global round trips,
+// 8 us alone but 50 us beside the streaming kernels of the other batches -- on the critical path of every step's sparse chain.)
+static constexpr int COMPACT_FRAMES = 16;
 __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __restrict__ armours,
                                                         const int32_t* __restrict__ n_armours, int n_frames, int max_armours,
                                                         rmcv_armour* __restrict__ out, int cap, int32_t* __restrict__ frame_offs)
 {
     __shared__ int s_part[256];
     __shared__ int s_base;
-    const int tid = threadIdx.x;
+    __shared__ int s_off[COMPACT_FRAMES], s_cnt[COMPACT_FRAMES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f_begin = blockIdx.x * COMPACT_FRAMES; // this workgroup's frames
     if (tid == 0) s_base = 0;
     __syncthreads();
     for (int f0 = 0; f0 < n_frames; f0 += 256) {
@@ -196,19 +202,24 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
             __syncthreads();
         }
         const int excl = s_base + s_part[tid] - c;
-        if (f < n_frames) {
+        if (f < n_frames && f >= f_begin && f < f_begin + COMPACT_FRAMES) {
             frame_offs[f] = excl;
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(armours + (int64_t)f * max_armours);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(out + excl);
-            for (int k = 0; k < c; k++)
-                if (excl + k < cap)
-                    for (int w = 0; w < (int)(sizeof(rmcv_armour) / 4); w++) dst[k * (sizeof(rmcv_armour) / 4) + w] = src[k * (sizeof(rmcv_armour) / 4) + w];
+            s_off[f - f_begin] = excl;
+            s_cnt[f - f_begin] = c;
         }
         __syncthreads();
         if (tid == 255) s_base += s_part[255];
         __syncthreads();
     }
-    if (tid == 0) frame_offs[n_frames] = s_base;
+    if (tid == 0 && blockIdx.x == 0) frame_offs[n_frames] = s_base;
+    constexpr int DW = (int)(sizeof(rmcv_armour) / 4);
+    for (int fi = wave; fi < COMPACT_FRAMES && f_begin + fi < n_frames; fi += 4) {
+        const int excl = s_off[fi], c = s_cnt[fi];
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(armours + (int64_t)(f_begin + fi) * max_armours);
+        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(out + excl);
+        const int nd = min(c, max(0, cap - excl)) * DW; // armours beyond the capacity of the list are dropped (the caller is told)
+        for (int i = lane; i < nd; i += 64) dst[i] = src[i];
+    }
 }
 
 __global__ void k_status_clear(int32_t* __restrict__ status, int n, int mask)
@@ -225,7 +236,7 @@ hipError_t launch_status_clear(const Geom& g, const Bufs& b, int mask, hipStream
 hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
                                   int32_t* d_frame_offs, hipStream_t s)
 {
-    return launch(k_compact_armours, dim3(1), dim3(256), 0, s, b.armours, b.n_armours, g.n_frames, lim.max_armours, d_out,
+    return launch(k_compact_armours, dim3(std::max(1, (g.n_frames + COMPACT_FRAMES - 1) / COMPACT_FRAMES)), dim3(256), 0, s, b.armours, b.n_armours, g.n_frames, lim.max_armours, d_out,
                        cap, d_frame_offs);
 }
 
