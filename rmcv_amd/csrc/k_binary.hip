@@ -458,6 +458,16 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
         uint8_t* binary = image ? b.binary + (int64_t)f0 * g.w * g.h : nullptr;
         uint64_t* bits = b.bits + (int64_t)f0 * g.plane_pitch;
         uint32_t* rowmask = b.rowmask + (int64_t)f0 * g.h;
+        // beyond 64 KiB of dynamic LDS (frames wider than ~6700 pixels) the kernel has to be told; per device and instantiation
+        static size_t lds_set[MAX_DEVICES][2] = {};
+        if (planes > 60 * 1024 && planes > lds_set[g.device][fast ? 1 : 0]) {
+            const hipError_t ea = fast ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_binary<CA, CB, true>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes)
+                                       : hipFuncSetAttribute(reinterpret_cast<const void*>(k_binary<CA, CB, false>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes);
+            if (ea != hipSuccess) return ea;
+            lds_set[g.device][fast ? 1 : 0] = planes;
+        }
 #define RMCV_K1_LAUNCH(F)                                                                                                          \
     launch(k_binary<CA, CB, F>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
            morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail)

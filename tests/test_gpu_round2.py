@@ -413,3 +413,26 @@ def test_pixel_kernel_coalesced_loader_geometries(oracle, morph):
                 ref = oracle.extract_binary(frames[f], camp, lb, morph)
                 assert np.array_equal(c.binary(f), ref), (w, h, n, stride, pitch, camp, lb, f)
         c.close()
+
+
+def test_pixel_kernel_very_wide_frames(oracle):
+    """frames wider than ~6700 pixels need more than 64 KiB of dynamic LDS for the strip's two bit planes: the launch raises the
+    kernel's limit instead of failing (7168 and 8192 wide, both loaders)"""
+    for (w, h, stride) in [(7168, 40, 3 * 7168), (8192, 37, 3 * 8192), (7200, 35, 3 * 7200 + 5)]:
+        rng = np.random.default_rng(w + h)
+        img = rng.integers(0, 48, (h, w, 3), dtype=np.uint8)
+        img[rng.random((h, w)) < 0.3] = (255, 100, 10)
+        c = Context(device=0, max_frames=1, max_width=w, max_height=h, max_contours=1 << 16, max_points=1 << 20)
+        if stride == 3 * w:
+            c.upload(img[None])
+        else:
+            import torch
+            host = np.zeros(stride * h, np.uint8)
+            for y in range(h):
+                host[y * stride:y * stride + 3 * w] = img[y].reshape(-1)
+            buf = torch.from_numpy(host).to(torch.device("cuda", 0))
+            c.bind_device_frames(buf.data_ptr(), 1, h, w, stride=stride, keepalive=buf)
+        c.run(default_params(), STAGE_BINARY)
+        c.sync()
+        assert np.array_equal(c.binary(0), oracle.extract_binary(img, CAMP_BLUE, 80, MORPH_CLOSE)), (w, h)
+        c.close()
