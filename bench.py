@@ -256,7 +256,14 @@ def main():
         with torch.cuda.stream(sB):
             sB.wait_event(ev_bin[k])
             run_path(ctxs[k], cur_stages[0] & ~(STAGE_BINARY | STAGE_NO_IMAGE), sB.cuda_stream)
+            if abi_gathers and not first_use:
+                sB.wait_event(ev_gath[k])                  # the record is rewritten: its previous gather (ns steps back) must be through
             ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), sB.cuda_stream)
+            if abi_gathers:
+                # the context's buffers are free once its list is compacted: the gather only reads the record, so the pixel kernel
+                # that reuses this context does not wait for the collective (it would lengthen the chain the step rate hangs on)
+                ev_done[k].record(sB)
+                return gather_step(k, sB.cuda_stream, k % len(sBs))
             out = gather_step(k, sB.cuda_stream, k % len(sBs))
             ev_done[k].record(sB)
             return out
