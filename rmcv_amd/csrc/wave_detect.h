@@ -246,6 +246,7 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
             return dabs((double)px) + dabs((double)py);
         });
         const double scale = 100.0 / (s > FLT_EPSILON ? s : (double)FLT_EPSILON);
+        FSTAMP(8);
         double gfp[5], rp[5] = {0, 0, 0, 0, 0};
         float eps = 0.0f;
         int la = 0, lb = 0;
@@ -276,14 +277,17 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
                 g.reg = lane < 5 ? L.dm[15 + lane] : 0.0;
             }
             __builtin_amdgcn_wave_barrier();
+            FSTAMP(9);
             NormalFac Fac(lane);
             double wmax, wmin;
             normal_factor(G, 5, Fac, &wmax, &wmin);
+            FSTAMP(10);
             if (iter == 0 && wmax * FLT_EPSILON > wmin) {
                 eps = (float)(s / (n * 2) * 1e-3);
                 continue;
             }
             normal_apply(Fac, g, gfp, lane);
+            FSTAMP(11);
             normal_refine<5>(Fac, n, lane, 10000.0, gfp, row5);
             break;
         }
@@ -321,7 +325,9 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
         double wmax3, wmin3;
         normal_factor(G, 3, Fac, &wmax3, &wmin3);
         normal_apply(Fac, g, gfp, lane);
+        FSTAMP(12);
         normal_refine<3>(Fac, n, lane, 1.0, gfp, row3);
+        FSTAMP(13);
         general_finish(gfp, rp, scale, cx, cy, box);
         FSTAMP(6);
     }
@@ -359,12 +365,14 @@ __device__ inline void fit_contour_slot(int f, int k, int n, const rmcv_point* _
         const double area = dabs(a00 * 0.5);
         if (area >= G.area_lo && area <= G.area_hi) {
 #ifdef RMCV_PROFILE
-            long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            long long pr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const int path = fit_ellipse_wave(cp, len, sx, sy, L, lane, &ell, pr);
-            if (lane == 0 && f == 0 && len > 150)
-                printf("[fit f%d c%d n=%d path=%d] s %.1f moments+reduce %.1f finish %.1f | gen s+G+solve %.1f refit %.1f solve3+finish %.1f us\n", f, c,
-                       len, path, (pr[1] - pr[0]) / 100.0, (pr[2] - pr[1]) / 100.0, (pr[3] - pr[2]) / 100.0,
-                       (pr[4] - pr[3]) / 100.0, (pr[5] - pr[4]) / 100.0, (pr[6] - pr[5]) / 100.0);
+            if (lane == 0 && ((f == 0 && len > 150) || (path == 1 && f < 64)))
+                printf("[fit f%d c%d n=%d path=%d] s %.1f moments+reduce %.1f finish %.1f | gen: s %.1f sums20 %.1f jacobi5 %.1f apply %.1f refine5 %.1f | "
+                       "centre+sums9 %.1f jacobi3+apply %.1f refine3 %.1f finish %.1f us\n", f, c, len, path, (pr[1] - pr[0]) / 100.0,
+                       (pr[2] - pr[1]) / 100.0, (pr[3] - pr[2]) / 100.0, (pr[8] - pr[3]) / 100.0, (pr[9] - pr[8]) / 100.0, (pr[10] - pr[9]) / 100.0,
+                       (pr[11] - pr[10]) / 100.0, (pr[4] - pr[11]) / 100.0, (pr[5] - pr[4]) / 100.0, (pr[12] - pr[5]) / 100.0,
+                       (pr[13] - pr[12]) / 100.0, (pr[6] - pr[13]) / 100.0);
 #else
             fit_ellipse_wave(cp, len, sx, sy, L, lane, &ell); // :68  (:69 minAreaRect is dead code in the reference)
 #endif
