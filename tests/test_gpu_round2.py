@@ -436,3 +436,34 @@ def test_pixel_kernel_very_wide_frames(oracle):
         c.sync()
         assert np.array_equal(c.binary(0), oracle.extract_binary(img, CAMP_BLUE, 80, MORPH_CLOSE)), (w, h)
         c.close()
+
+
+def test_armour_list_compaction_many_frames_and_overflow(oracle):
+    """rmcv_batch_compact_armours (the record of the multi-GPU gather): 300 frames -- more than one chunk of the count scan, 19
+    workgroups -- with wide-open gates (0 to dozens of armours per frame); the frame-major list and its offsets equal the per-frame
+    lists laid end to end, and a list capacity below the total drops exactly the armours beyond it"""
+    import torch
+    n, w, h = 300, 320, 192
+    frames = np.stack([synth.frame(7000 + i, w, h, CAMP_BLUE, i % 2) for i in range(n)])
+    frames[5] = 0                                                   # a frame with nothing in it
+    p = default_params()
+    p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi = 1e9, 0.0, 1e30, 0.0, 1e30
+    p.angle_diff_max, p.shear_max, p.length_ratio_max = 1e9, 1e9, 0.0
+    c = Context(device=0, max_frames=n, max_width=w, max_height=h, max_blobs=64, max_armours=512)
+    c.upload(frames)
+    c.run(p, STAGE_ALL)
+    c.sync()
+    arm, offs = c.armours()                                         # host-side reference: the per-frame slots, read back one by one
+    total = int(offs[-1])
+    assert total > 600 and offs[6] == offs[5]
+    dt = arm.dtype
+    for cap in (total + 10, total, total // 2 + 3, 1):
+        out = torch.full((cap * dt.itemsize,), 0xEE, dtype=torch.uint8, device="cuda")
+        fo = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        c.compact_armours_into(out.data_ptr(), cap, fo.data_ptr())
+        torch.cuda.synchronize()
+        assert fo.cpu().numpy().tolist() == offs.tolist(), cap      # the offsets always describe the complete list
+        got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=dt)
+        keep = min(cap, total)
+        assert got[:keep].tobytes() == arm[:keep].tobytes(), cap
+    c.close()
