@@ -225,7 +225,10 @@ static constexpr int SLOT_CAP = 1024;  // non-empty words of a frame the LDS lab
 static constexpr int CT_THREADS_MAX = 512;
 static constexpr int MULTI_CAP = 32;    // pixels of a frame visited 3 or 4 times (junctions of 1-pixel lines) the cycle formulation lists
 static constexpr int NN_CAP = VISIT_CAP;    // border visits (nodes) of a frame the cycle formulation holds in LDS
-static constexpr int CT_MAXH = 2048;   // rows covered by the LDS row tables (taller/wider frames take the literal path)
+#ifndef RMCV_CT_MAXH
+#define RMCV_CT_MAXH 2048
+#endif
+static constexpr int CT_MAXH = RMCV_CT_MAXH;   // rows covered by the LDS row tables (taller/wider frames take the literal path)
 
 struct ContoursLds {
     unsigned long long lab[SLOT_CAP], neg[SLOT_CAP];
