@@ -467,3 +467,24 @@ def test_armour_list_compaction_many_frames_and_overflow(oracle):
         keep = min(cap, total)
         assert got[:keep].tobytes() == arm[:keep].tobytes(), cap
     c.close()
+
+
+@pytest.mark.parametrize("camp_name,lb,morph", [("GUIDELIGHT", 60, MORPH_CLOSE), ("NEUTRAL", 80, MORPH_DILATE), ("BLUE", 1, MORPH_CLOSE),
+                                                ("BLUE", 255, 0)])
+def test_full_size_binary_other_camps_and_bounds(oracle, camp_name, lb, morph):
+    """the other two instantiations of the pixel kernel (G - R for the guide light; NEUTRAL = R - B, imgproc.cpp:56-65) and the
+    ends of the lower bound's range (1: nearly everything above the noise floor passes -- dense planes; 255: only saturated
+    differences) on 64 full-size frames each"""
+    import rmcv_amd
+    camp = getattr(rmcv_amd, "CAMP_" + camp_name)
+    n = 64
+    frames = synth.batch(130000 + lb, n, 1280, 1024, CAMP_BLUE, 1, threads=16)
+    c = Context(device=0, max_frames=n, max_width=1280, max_height=1024)
+    c.upload(frames)
+    c.run(default_params(camp=camp, lower_bound=lb, morph=morph), STAGE_BINARY)
+    c.sync()
+    with ThreadPoolExecutor(16) as ex:
+        refs = list(ex.map(lambda f: oracle.extract_binary(frames[f], camp, lb, morph), range(n)))
+    for f in range(n):
+        assert np.array_equal(c.binary(f), refs[f]), (f, camp_name, lb, morph)
+    c.close()
