@@ -340,12 +340,13 @@ struct FitGates {
     float tilt_max, ratio_lo, ratio_hi;
     double area_lo, area_hi;
 };
-__device__ inline void fit_contour_slot(int f, int k, int n, const rmcv_point* __restrict__ pts, const int32_t* __restrict__ cs,
-                                        const int32_t* __restrict__ cl, int max_contours, int max_points, const FitGates& G,
-                                        int32_t* __restrict__ slot_kind, rmcv_rrect* __restrict__ slot_ell, WaveLds& L, int lane)
+// (start, len): the contour's place in the frame's point list -- the caller's copy, so that a workgroup that has just produced
+// them need not read them back from global memory (a dependent round trip per contour: microseconds beside streaming kernels)
+__device__ inline void fit_contour_slot_at(int f, int k, int n, const rmcv_point* __restrict__ pts, int start, int len, int max_contours,
+                                           int max_points, const FitGates& G, int32_t* __restrict__ slot_kind,
+                                           rmcv_rrect* __restrict__ slot_ell, WaveLds& L, int lane)
 {
     const int c = n - 1 - k; // findContours order
-    const int start = cs[k], len = cl[k];
     int kind = 0;
     rmcv_rrect ell = {0, 0, 0, 0, 0};
     if (len >= 6 && start + len <= max_points) { // objdetect.cpp:64
@@ -389,6 +390,13 @@ __device__ inline void fit_contour_slot(int f, int k, int n, const rmcv_point* _
         slot_kind[(int64_t)f * max_contours + c] = kind;
         slot_ell[(int64_t)f * max_contours + c] = ell;
     }
+}
+
+__device__ inline void fit_contour_slot(int f, int k, int n, const rmcv_point* __restrict__ pts, const int32_t* __restrict__ cs,
+                                        const int32_t* __restrict__ cl, int max_contours, int max_points, const FitGates& G,
+                                        int32_t* __restrict__ slot_kind, rmcv_rrect* __restrict__ slot_ell, WaveLds& L, int lane)
+{
+    fit_contour_slot_at(f, k, n, pts, cs[k], cl[k], max_contours, max_points, G, slot_kind, slot_ell, L, lane);
 }
 
 struct FitTail { // what k_pairs needs to finish filter_lightblobs and run filter_armours
