@@ -101,6 +101,9 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                                                  int* __restrict__ strip_ctr, int taper_head, int taper_tail)
 {
     extern __shared__ uint64_t smem[];
+#ifdef RMCV_K1_PRIO
+    __builtin_amdgcn_s_setprio(RMCV_K1_PRIO); // dev knob (A/B of issue priorities against the sparse kernel's)
+#endif
     const int halo = morph; // NONE 0, DILATE 1, CLOSE 2
     uint64_t* T = smem;
     uint64_t* D = smem + (size_t)(SR + 4) * ww;
