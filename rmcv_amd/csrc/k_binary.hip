@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
         const uint32_t rr_span = (uint32_t)(rr_hi - rr_lo);
         const uint32_t strip_base = fbase + (uint32_t)(y0 - halo) * (uint32_t)stride; // wraps for the rows above the image: never used
         const int ragged = (w & 255) ? 1 : 0;
-        const bool plain = rr_lo == 0 && rr_hi == srh && (srh & 3) == 0 && !ragged; // the strip needs no validity selects at all
+        const bool plain = rr_lo == 0 && rr_hi == srh && (srh & 3) == 0; // the strip's rows need no validity selects at all
         uint32_t dk1 = (uint32_t)stride, dk2 = 2u * (uint32_t)stride, dk3 = 3u * (uint32_t)stride;
         asm volatile("" : "+s"(dk1), "+s"(dk2), "+s"(dk3)); // opaque: otherwise every row's offset is re-derived with its own multiply
         if (all_pass) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
         } else
         for (int it0 = wv; it0 < n_it; it0 += 4 * U) {
             // One batch = U items of the wave: all 4 * U loads are issued, then thresholded.  CHK = false is the common case (a strip
-            // with every row inside the image, whole row quads, whole 256-pixel blocks, a full batch): no validity selects.
+            // with every row inside the image, whole row quads, a full batch): no validity selects.
             auto batch = [&](auto chk) {
                 constexpr bool CHK = decltype(chk)::value;
                 u32x3v v[U][4];
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                     const int jq0 = div_r(it, r_nb), b = it - jq0 * nb;
                     const int jq = (L & 1) ? jq0 : nq - 1 - jq0; // sweep direction, see below
                     const int rr0 = 4 * jq;
-                    info[u] = (int)(__umul24(rr0, ww) * 8u + (uint32_t)b * 32u);
-                    if (CHK) info[u] = it < n_it ? info[u] | (b == nb - 1 ? ragged : 0) : -1; // bit 0: ragged block
+                    info[u] = (int)(__umul24(rr0, ww) * 8u + (uint32_t)b * 32u) | (b == nb - 1 ? ragged : 0); // bit 0: ragged block
+                    if (CHK && it >= n_it) info[u] = -1;
 #ifdef RMCV_K1_NOLOAD
                     const uint32_t base = OOB_S - dk3; // ablation build: nothing is read
 #else
@@ -240,18 +240,18 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                     const uint32_t d[12] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][1].x, v[u][1].y, v[u][1].z,
                                             v[u][2].x, v[u][2].y, v[u][2].z, v[u][3].x, v[u][3].y, v[u][3].z};
                     uint32_t m = thresh16<CA, CB>(d, lb);
-                    // pixels beyond the row's end (w % 256 != 0, last block): the lane has read the next row's bytes
-                    if (CHK && (info[u] & 1) && lane * 4 >= w - ((nb - 1) << 8)) m = 0;
+                    const bool last_ragged = (info[u] & 1) != 0; // wave-uniform: the row's last block when w % 256 != 0
+                    // pixels beyond the row's end: the lane has read the next row's bytes
+                    if (last_ragged && lane * 4 >= w - ((nb - 1) << 8)) m = 0;
                     // 4x4 nibble transpose within the quad: exchange with lane^1 (nibbles), then with lane^2 (bytes)
                     const uint32_t p1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xF, 0xF, true);
                     const uint32_t t1 = (m & M1) | (((p1 << 8) >> S1) & ~M1);
                     const uint32_t p2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)t1, 0x4E, 0xF, 0xF, true);
                     const uint32_t t2 = __builtin_amdgcn_perm(p2, t1, P2);
                     uint16_t* dst = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(T) + ((uint32_t)info[u] & ~1u) + lds_lane);
-                    if (CHK) { // the quad's 16 pixels of the last block may lie beyond the row: those go to a spare word
-                        const bool in_row = !(info[u] & 1) || (lane >> 2) * 16 < w - ((nb - 1) << 8);
-                        if (!(info[u] >= 0 && in_row)) dst = s_spare + tid;
-                    }
+                    if (CHK && info[u] < 0) dst = s_spare + tid; // an item beyond the strip's
+                    // the quad's 16 pixels of the last block may lie beyond the row: those go to a spare word
+                    if (last_ragged && (lane >> 2) * 16 >= w - ((nb - 1) << 8)) dst = s_spare + tid;
                     *dst = (uint16_t)t2;
                 }
             };
