@@ -127,9 +127,9 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * pairing) in batch runs -- 8 (default): lowest latency of a lone batch; 4: highest throughput when several batches are in flight
  * on different streams (leaves register-file room on every CU for the pixel kernels of the next batches).  Results are identical. */
 #define RMCV_OPT_SPARSE_WAVES 1
-/* RMCV_OPT_PIXEL_GROUPS: persistent workgroups per CU of the pixel kernel, 1..8 -- 3 (default): fastest for a lone batch (2 and 3
- * are within 1 %, 4 and more are slower); 2: leaves wave slots and registers on every CU to the kernels of the other batches
- * in flight.  Results are identical. */
+/* RMCV_OPT_PIXEL_GROUPS: persistent workgroups per CU of the pixel kernel, 1..8 -- 3 (default): fastest for a lone batch (2 is
+ * 5 % slower, 4 within 3 %); 2: leaves wave slots and registers on every CU to the kernels of the other batches in flight
+ * (two pixel launches of consecutive batches then overlap, i.e. 4 workgroups per CU are resident).  Results are identical. */
 #define RMCV_OPT_PIXEL_GROUPS 2
 /* RMCV_OPT_FRAME_UPLOAD: how rmcv_extract_color brings the caller's host frame to the device -- 0 (default): the HIP runtime's
  * pageable copy (measured fastest of the two safe ways: 0.37 ms per frame chain against 0.41); 1: through the context's
