@@ -37,6 +37,9 @@ namespace rmcv {
 #ifndef RMCV_K1_STAUX
 #define RMCV_K1_STAUX 2 // cache-policy bits of the byte-image stores (2 = nt)
 #endif
+#ifndef RMCV_K1_PLAUX
+#define RMCV_K1_PLAUX 0 // cache-policy bits of the bit-plane stores (the sparse kernel of the same batch reads them back)
+#endif
 #ifndef RMCV_K1_LDAUX
 #define RMCV_K1_LDAUX 2 // cache-policy bits of the frame loads that no other workgroup shares (2 = nt)
 #endif
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                 uint64_t word = 0;
                 if (ok) word = R[__umul24(s_ + halo, ww) + k];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane,
-                                                      ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB, 0, 0);
+                                                      ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB, 0, RMCV_K1_PLAUX);
                 k += k_step;
                 s_ += s_step;
                 if (k >= ww) { k -= ww; s_++; }
