@@ -5,9 +5,14 @@
 //   rm::filter_lightblobs  include/objdetect.h:47-49  (body: src/objdetect.cpp:55-87)
 //   rm::filter_armours     include/objdetect.h:70-71  (body: src/objdetect.cpp:114-166)
 //
-// Usage: compile this header into ONE translation unit of librmcv in place of
-// those three bodies, after including the reference's own "core.h" (it supplies rm::camp, rm::range,
+// Usage: compile this header into EXACTLY ONE translation unit of librmcv in place of
+// those bodies, after including the reference's own "core.h" (it supplies rm::camp, rm::range,
 // rm::contour, rm::lightblob, rm::armour and the cv:: types), and link librmcv_hip.so.
+// The seven rm:: functions below are DEFINITIONS WITH EXTERNAL LINKAGE (they are what executable/main.cpp's
+// undefined references resolve to, executable/CMakeLists.txt:1-2): including this header in two translation
+// units of one program is an ODR violation by design, exactly as compiling src/objdetect.cpp twice would be.
+// A header-only use (caller and shim in one TU) may define RMCV_SHIM_LINKAGE=inline before including it.
+// Default arguments stay on the reference's declarations (include/objdetect.h:22-37, include/mobility.h:106-108).
 // Also the legacy matcher rm::MatchLightBlob / rm::FindLightBlobs / rm::LightBlobOverlap (include/objdetect.h:22-37, 62)
 // and rm::solve_PnP (include/mobility.h:106-108).
 // The legacy names of the north star are aliased at the bottom (docs/core_8h_source.html:101,114).
@@ -16,7 +21,9 @@
 #pragma once
 #if __has_include(<opencv2/opencv.hpp>)
 
+#include <cstdlib>
 #include <stdexcept>
+#include <string>
 #include <tuple>
 #include <vector>
 
@@ -24,6 +31,10 @@
 
 #ifndef RMCV_CORE_H
 #error "include the reference's core.h before rmcv_shim.hpp"
+#endif
+
+#ifndef RMCV_SHIM_LINKAGE
+#define RMCV_SHIM_LINKAGE /* external: the backend TU emits rm::extract_color & co. whether or not it calls them */
 #endif
 
 namespace rm {
@@ -78,7 +89,7 @@ inline rmcv_lightblob from_lightblob(const lightblob& b)
 
 } // namespace hip_detail
 
-inline std::tuple<std::vector<contour>, cv::Mat> extract_color(cv::InputArray image, camp target, int lower_bound)
+RMCV_SHIM_LINKAGE std::tuple<std::vector<contour>, cv::Mat> extract_color(cv::InputArray image, camp target, int lower_bound)
 {
     cv::Mat img = image.getMat();
     CV_Assert(img.type() == CV_8UC3);
@@ -101,7 +112,7 @@ inline std::tuple<std::vector<contour>, cv::Mat> extract_color(cv::InputArray im
     return {contours, binary};
 }
 
-inline auto filter_lightblobs(const std::vector<contour>& contours, const float tilt_max, const range<float> ratio_range,
+RMCV_SHIM_LINKAGE auto filter_lightblobs(const std::vector<contour>& contours, const float tilt_max, const range<float> ratio_range,
                               const range<double> area_range, camp enemy)
     -> std::tuple<std::vector<lightblob>, std::vector<contour>>
 {
@@ -128,7 +139,7 @@ inline auto filter_lightblobs(const std::vector<contour>& contours, const float 
     return {positive, negative};
 }
 
-inline std::vector<armour> filter_armours(std::vector<lightblob>& lightblobs, const float angle_difference_max,
+RMCV_SHIM_LINKAGE std::vector<armour> filter_armours(std::vector<lightblob>& lightblobs, const float angle_difference_max,
                                           const float shear_max, const float lenght_ratio_max, const camp enemy)
 {
     std::vector<rmcv_lightblob> in;
@@ -160,7 +171,7 @@ inline std::vector<armour> filter_armours(std::vector<lightblob>& lightblobs, co
 
 // ---- legacy per-contour matcher (include/objdetect.h:22-37, 62; bodies src/objdetect.cpp:9-53, 89-112).  The default
 // argument `fitEllipse = true` lives on the reference's declarations.
-inline bool MatchLightBlob(const rm::contour& contour, float minRatio, float maxRatio, float tiltAngle, float minArea,
+RMCV_SHIM_LINKAGE bool MatchLightBlob(const rm::contour& contour, float minRatio, float maxRatio, float tiltAngle, float minArea,
                            float maxArea, cv::RotatedRect& lightBlobBox, bool fitEllipse)
 {
     std::vector<rmcv_point> pts;
@@ -175,7 +186,7 @@ inline bool MatchLightBlob(const rm::contour& contour, float minRatio, float max
     return true;
 }
 
-inline void FindLightBlobs(std::vector<contour>& contours, std::vector<lightblob>& lightBlobs, float minRatio, float maxRatio,
+RMCV_SHIM_LINKAGE void FindLightBlobs(std::vector<contour>& contours, std::vector<lightblob>& lightBlobs, float minRatio, float maxRatio,
                            float tiltAngle, float minArea, float maxArea, const cv::Mat& source, bool fitEllipse)
 {
     lightBlobs.clear();
@@ -196,7 +207,7 @@ inline void FindLightBlobs(std::vector<contour>& contours, std::vector<lightblob
     for (int i = 0; i < nb; i++) lightBlobs.push_back(hip_detail::to_lightblob(blobs[i]));
 }
 
-inline bool LightBlobOverlap(const std::vector<rm::lightblob>& lightBlobs, int leftIndex, int rightIndex)
+RMCV_SHIM_LINKAGE bool LightBlobOverlap(const std::vector<rm::lightblob>& lightBlobs, int leftIndex, int rightIndex)
 {
     std::vector<rmcv_lightblob> in;
     in.reserve(lightBlobs.size());
@@ -209,7 +220,7 @@ inline bool LightBlobOverlap(const std::vector<rm::lightblob>& lightBlobs, int l
 
 // ---- armour pose (include/mobility.h:106-108; body src/mobility.cpp:166-190).  The default argument ROI = {0,0,0,0} lives on
 // the reference's declaration.  cameraMatrix: 3x3 CV_64F, distortionFactor: 1x5 (or 5x1) CV_64F, as executable/main.cpp:7-13.
-inline std::tuple<cv::Mat, cv::Mat> solve_PnP(const cv::Point2f points_image[4], cv::InputArray cameraMatrix,
+RMCV_SHIM_LINKAGE std::tuple<cv::Mat, cv::Mat> solve_PnP(const cv::Point2f points_image[4], cv::InputArray cameraMatrix,
                                               cv::InputArray distortionFactor, const cv::Size2f& exactSize, const cv::Rect& ROI)
 {
     const cv::Mat K = cameraMatrix.getMat(), D = distortionFactor.getMat();

@@ -1,40 +1,11 @@
-// TEST-ONLY driver of include/rmcv_shim.hpp: the three calls of the reference's process loop
-// (/root/reference/executable/main.cpp:172-176) through the rm:: signatures, on one synthetic frame.
-// The rm:: data types below restate the DATA CONTRACT of the reference's include/core.h:20-44,87-130 (names,
-// public members, constructor signatures) so that the shim's conversions are exercised; they carry no logic.
-#include <cmath>
+// TEST-ONLY caller translation unit of the link test: sees the reference-style DECLARATIONS only (rm_contract.hpp stands in for
+// "rmcv.h"), never the shim -- the position executable/main.cpp is in (executable/CMakeLists.txt:1-2).  It makes the three
+// calls of the reference's process loop (executable/main.cpp:172-176) on one synthetic frame, then the legacy three and
+// solve_PnP; every rm:: reference below must be resolved by backend.o at link time.
 #include <cstdio>
-#include <map>
-#include <tuple>
-#include <vector>
 
-#include <opencv2/opencv.hpp>
-#define RMCV_CORE_H
-namespace rm {
-enum camp { CAMP_RED = 0, CAMP_BLUE = 1, CAMP_GUIDELIGHT = 2, CAMP_NEUTRAL = -1 };
-template <typename T> struct range {
-    T lower_bound, upper_bound;
-    range(T lower, T upper) : lower_bound(lower), upper_bound(upper) {}
-};
-typedef std::vector<cv::Point> contour;
-class lightblob {
-public:
-    float angle = 0;
-    camp target = CAMP_NEUTRAL;
-    cv::Point2f center;
-    cv::Point2f vertices[4];
-    cv::Size2f size;
-    explicit lightblob(cv::RotatedRect box, rm::camp c = rm::CAMP_NEUTRAL) : target(c), center(box.center) {}
-};
-class armour {
-public:
-    cv::Point2f icon[4];
-    cv::Point2f vertices[4];
-    cv::Rect2f bounding_box;
-    explicit armour(std::vector<lightblob>) {}
-};
-} // namespace rm
-#include "rmcv_shim.hpp"
+#include "rm_contract.hpp"
+#include "rmcv_abi.h" // rmcv_synth_frame / rmcv_default_pnp_config only (test input + the literals of main.cpp:7-13)
 
 int main(int argc, char** argv)
 {
@@ -62,7 +33,7 @@ int main(int argc, char** argv)
     std::printf("\n");
     size_t matched = 0;
     cv::RotatedRect box;
-    for (auto& c : contours) matched += rm::MatchLightBlob(c, 1.5f, 80.0f, 70.0f, 10.0f, 99999.0f, box, true) ? 1 : 0;
+    for (auto& c : contours) matched += rm::MatchLightBlob(c, 1.5f, 80.0f, 70.0f, 10.0f, 99999.0f, box) /* default fitEllipse = true */ ? 1 : 0;
     int overlaps = 0;
     for (int i = 0; i + 2 < (int)legacy.size(); i++) overlaps += rm::LightBlobOverlap(legacy, i, i + 2) ? 1 : 0;
     std::printf("matched %zu overlaps %d\n", matched, overlaps);
@@ -73,11 +44,11 @@ int main(int argc, char** argv)
     for (int i = 0; i < 9; i++) cammat.ptr<double>()[i] = pc.camera_matrix[i];
     for (int i = 0; i < 5; i++) discof.ptr<double>()[i] = pc.dist[i];
     for (auto& a : armours) {
-        auto [rvec, tvec] = rm::solve_PnP(a.vertices, cammat, discof, {27, 27}, cv::Rect(0, 0, 0, 0));
+        auto [rvec, tvec] = rm::solve_PnP(a.vertices, cammat, discof, {27, 27}) /* default ROI */;
         std::printf("pose %a %a %a %a %a %a\n", rvec.ptr<double>()[0], rvec.ptr<double>()[1], rvec.ptr<double>()[2],
                     tvec.ptr<double>()[0], tvec.ptr<double>()[1], tvec.ptr<double>()[2]);
     }
-    rm::LightBlob* alias_check = positive.empty() ? nullptr : &positive[0];
-    (void)alias_check;
+    for (auto& a : armours)
+        if (!a.has_filter_state()) return 3; // every returned armour owns its Kalman state, as a reference armour does
     return 0;
 }

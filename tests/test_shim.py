@@ -1,6 +1,7 @@
-"""include/rmcv_shim.hpp -- the reference's rm:: signatures over the C-ABI -- compiled as C++17 and run end to end.
-OpenCV is absent from this image, so the shim is compiled against tests/cv_mock (a test-only stand-in for the few
-cv:: types it touches; no reference source is built)."""
+"""include/rmcv_shim.hpp -- the reference's rm:: signatures over the C-ABI -- compiled as C++17, LINKED the way
+INTEGRATION.md prescribes (backend TU + unchanged caller TU, tests/shim/) and run end to end.
+OpenCV is absent from this image, so the units are compiled against tests/cv_mock (a test-only stand-in for the few
+cv:: types they touch; no reference source is built)."""
 import os
 import subprocess
 
@@ -12,16 +13,49 @@ HERE = os.path.join(ROOT, "tests")
 LIBDIR = os.path.join(ROOT, "rmcv_amd", "lib")
 
 
+SHIM = os.path.join(HERE, "shim")
+RM_SYMBOLS = ["rm::extract_color(", "rm::filter_lightblobs(", "rm::filter_armours(", "rm::MatchLightBlob(", "rm::FindLightBlobs(",
+              "rm::LightBlobOverlap(", "rm::solve_PnP("]
+
+
+def compile_units(tmp):
+    """the layout INTEGRATION.md section 2 prescribes: backend TU (declarations + shim), the reference's own core TU
+    (constructors; a stub here), and a caller TU that sees declarations only -- three separate objects"""
+    objs = {}
+    for unit in ("backend", "core_stub", "caller"):
+        objs[unit] = os.path.join(tmp, unit + ".o")
+        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(HERE, "cv_mock"), "-I", os.path.join(ROOT, "include"),
+                        "-I", SHIM, "-c", os.path.join(SHIM, unit + ".cpp"), "-o", objs[unit]], check=True)
+    return objs
+
+
 def build(tmp):
+    objs = compile_units(tmp)
     exe = os.path.join(tmp, "shim_main")
-    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(HERE, "cv_mock"), "-I", os.path.join(ROOT, "include"),
-           os.path.join(HERE, "shim_main.cpp"), "-o", exe, "-L", LIBDIR, "-lrmcv_hip", "-Wl,-rpath," + LIBDIR,
-           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"]
+    cmd = ["g++", objs["caller"], objs["backend"], objs["core_stub"], "-o", exe, "-L", LIBDIR, "-lrmcv_hip",
+           "-Wl,-rpath," + LIBDIR, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"]
     subprocess.run(cmd, check=True)
     return exe
 
 
-def test_shim_compiles(tmp_path):
+def nm(obj, flag):
+    return subprocess.run(["nm", "-C", flag, obj], check=True, capture_output=True, text=True).stdout
+
+
+def test_backend_unit_defines_the_rm_symbols(tmp_path):
+    """round 2's shim was all `inline`: a backend TU that does not call the functions emitted nothing and
+    executable/main.cpp would not have linked.  The backend object must DEFINE (T) all seven; the caller object must
+    leave the same seven UNDEFINED (U) -- it never saw the shim."""
+    objs = compile_units(str(tmp_path))
+    defined = nm(objs["backend"], "--defined-only")
+    undefined = nm(objs["caller"], "--undefined-only")
+    for sym in RM_SYMBOLS:
+        assert any(sym in l and " T " in l for l in defined.splitlines()), "backend.o does not define " + sym
+        assert any(sym in l for l in undefined.splitlines()), "caller.o does not reference " + sym
+    assert "rmcv_extract_color" not in undefined  # the caller reaches the C-ABI only through rm::
+
+
+def test_shim_links_as_two_translation_units(tmp_path):
     assert os.path.exists(build(str(tmp_path)))
 
 
