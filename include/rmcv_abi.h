@@ -328,7 +328,8 @@ int  rmcv_track_predict(rmcv_track* t, int64_t new_timestamp, double tick_freque
 /* one pass of the tracking thread (executable/main.cpp:60-85) over this frame's observations: targets whose bounding box
  * overlaps an observation by IoU > 0.5 take it (and it leaves the list), the others age (dropped after 26 misses -- with
  * the reference's skip of the target behind an erased one) or coast; what is left of the observations becomes new targets.
- * *n_obs is 0 afterwards.  At most 64 observations. */
+ * *n_obs is 0 afterwards.  Any number of observations; RMCV_ERR_CAPACITY when *n_tracking + *n_obs > cap (checked before
+ * anything is changed) or when a target would see its 33rd distinct identity (lists handed back consistent). */
 int  rmcv_track_step(rmcv_track* tracking, int32_t* n_tracking, int cap, rmcv_track* observations, int32_t* n_obs, double tick_frequency);
 
 /* ---- synthetic stream: host generator, integer-only, bit-reproducible --- */

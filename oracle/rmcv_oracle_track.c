@@ -10,6 +10,7 @@
  * [OCV] Rect_<float>::operator& is the overflow-safe form of OpenCV >= 4.5 as recalled; parity unpinned (rmcv_oracle.h).
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "rmcv_oracle.h"
@@ -334,11 +335,11 @@ int orc_track_step(orc_track* tracking, int32_t* n_tracking, int cap, orc_track*
         int32_t index = -1;
         float iou = 0;
         { // armour::max_IoU over the remaining observations (src/core.cpp:144-162)
-            orc_armour boxes[64];
-            const int m = no < 64 ? no : 64;
-            if (no > 64) return -2;
-            for (int k = 0; k < m; k++) boxes[k] = obs[k].armour;
-            orc_max_iou(&tracking[i].armour, boxes, m, &index, &iou);
+            orc_armour* boxes = (orc_armour*)malloc((size_t)no * sizeof(orc_armour) + 1); // std::vector<armour>: no bound
+            if (!boxes) return -3;
+            for (int k = 0; k < no; k++) boxes[k] = obs[k].armour;
+            orc_max_iou(&tracking[i].armour, boxes, no, &index, &iou);
+            free(boxes);
         }
         if (iou > 0.5f) {
             int rc = orc_track_update(&tracking[i], &obs[index], tick_frequency);

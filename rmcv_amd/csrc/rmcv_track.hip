@@ -266,8 +266,10 @@ int rmcv_track_step(rmcv_track* tracking, int32_t* n_tracking, int cap, rmcv_tra
     if (!tracking || !n_tracking || !n_obs || *n_tracking < 0 || *n_obs < 0 || (*n_obs > 0 && !obs) || !(tick_frequency > 0)) return RMCV_ERR_BAD_ARG;
     int nt = *n_tracking, no = *n_obs;
     if (no == 0) return RMCV_OK; // :61
-    if (nt == 0) {               // :63-67
-        if (no > cap) return RMCV_ERR_CAPACITY;
+    // the reference's vectors grow without bound; here `cap` is the caller's.  The list can only shrink before the survivors are
+    // appended, so nt + no bounds the result: checked BEFORE anything is touched, an error leaves both lists as they were.
+    if (nt + no > cap) return RMCV_ERR_CAPACITY;
+    if (nt == 0) { // :63-67
         memcpy(tracking, obs, (size_t)no * sizeof(rmcv_track));
         *n_tracking = no;
         return RMCV_OK;
@@ -275,16 +277,22 @@ int rmcv_track_step(rmcv_track* tracking, int32_t* n_tracking, int cap, rmcv_tra
     for (int i = 0; i < nt; i++) { // :69-81
         int32_t index = -1;
         float iou = 0;
-        { // armour::max_IoU over the remaining observations (src/core.cpp:144-162)
-            rmcv_armour boxes[64];
-            const int m = no < 64 ? no : 64;
-            if (no > 64) return RMCV_ERR_CAPACITY;
-            for (int k = 0; k < m; k++) boxes[k] = obs[k].armour;
-            rmcv_max_iou(&tracking[i].armour, boxes, m, &index, &iou);
+        for (int k = 0; k < no; k++) { // armour::max_IoU over the remaining observations (src/core.cpp:144-162), any number of them
+            int32_t hit = -1;
+            float v = 0;
+            rmcv_max_iou(&tracking[i].armour, &obs[k].armour, 1, &hit, &v);
+            if (hit == 0 && v > iou) { // `iou > max` with max starting at 0: the first of equal maxima wins, as in the reference's loop
+                iou = v;
+                index = k;
+            }
         }
         if (iou > 0.5f) {
-            int rc = rmcv_track_update(&tracking[i], &obs[index], tick_frequency);
-            if (rc) return rc;
+            const int rc = rmcv_track_update(&tracking[i], &obs[index], tick_frequency);
+            if (rc) { // only the identity table can overflow (RMCV_TRACK_IDS), and it does before the target is touched: hand back
+                *n_tracking = nt; // consistent lists -- what has been processed so far stays processed, nothing is duplicated
+                *n_obs = no;
+                return rc;
+            }
             for (int k = index; k + 1 < no; k++) obs[k] = obs[k + 1]; // armours->erase(begin() + index)
             no--;
         } else if (tracking[i].lost_count++ > 25) {
@@ -294,7 +302,6 @@ int rmcv_track_step(rmcv_track* tracking, int32_t* n_tracking, int cap, rmcv_tra
             rmcv_track_predict(&tracking[i], tracking[i].timestamp, tick_frequency);
         }
     }
-    if (nt + no > cap) return RMCV_ERR_CAPACITY;
     memcpy(tracking + nt, obs, (size_t)no * sizeof(rmcv_track)); // tracking.insert(end(), armours...)
     *n_tracking = nt + no;
     *n_obs = 0;

@@ -4,9 +4,18 @@ C-ABI (no device work), checked against the oracle, against an independent numpy
 import math
 
 import numpy as np
+import pytest
 
 import oracle_lib as O
+from rmcv_amd.abi import RmcvError
 from rmcv_amd.api import Context
+
+
+@pytest.fixture(autouse=True, params=[pytest.param("host"), pytest.param("gpu-box", marks=pytest.mark.gpu)])
+def where(request):
+    """every test of this module runs twice: in the CPU suite (`-m "not gpu"`; the tracker is host code of librmcv_hip.so and
+    needs no device) AND in the driver's `-m gpu` run, i.e. against the library as deployed on the GPU box"""
+    return request.param
 
 
 def arm(x, y, w, h):
@@ -188,3 +197,35 @@ def test_association_loop_product_equals_oracle_on_random_traffic():
         ta, tb = Context.track_step(ta, obs_a), O.track_step(tb, obs_b)
         assert len(ta) == len(tb) and (len(ta) == 0 or ta.tobytes() == tb.tobytes()), frame
     assert len(ta) > 0 and max(int(t["initialized"]) for t in ta) == 1
+
+
+def test_association_loop_has_no_observation_limit():
+    """the reference's vectors are unbounded (executable/main.cpp:69-84); round 2 stopped at 64 observations"""
+    rng = np.random.default_rng(5)
+    mk = lambda new, k, stamp: new(arm(40.0 * (k % 40), 60.0 * (k // 40), 30.0, 30.0), k % 7, stamp, (float(k), 0.0, 1.0))
+    ta = Context.track_step([], [mk(Context.track_new, k, 1000) for k in range(150)], cap=512)
+    tb = O.track_step([], [mk(O.track_new, k, 1000) for k in range(150)], cap=512)
+    assert len(ta) == 150 and ta.tobytes() == tb.tobytes()
+    order = rng.permutation(200)                         # 150 re-observed in another order + 50 new ones, all in one frame
+    ta = Context.track_step(ta, [mk(Context.track_new, int(k), 2000) for k in order], cap=512)
+    tb = O.track_step(tb, [mk(O.track_new, int(k), 2000) for k in order], cap=512)
+    assert len(ta) == 200 and ta.tobytes() == tb.tobytes()
+    assert all(int(t["initialized"]) == 1 and int(t["timestamp"]) == 2000 for t in ta[:150])
+
+
+def test_association_loop_capacity_error_changes_nothing():
+    mk = lambda k, stamp: Context.track_new(arm(50.0 * k, 10.0, 30.0, 30.0), 1, stamp, (0.0, 0.0, 1.0))
+    tr = Context.track_step([], [mk(k, 10) for k in range(6)], cap=8)
+    before = tr.tobytes()
+    import ctypes as C
+    from rmcv_amd import abi
+    buf = np.zeros(8, abi.TRACK)
+    buf[:6] = tr
+    obs = np.array([mk(k, 20) for k in (0, 1, 20, 21, 22)], abi.TRACK)   # 6 + 5 > 8: refused before the first association
+    obs_before = obs.tobytes()
+    nt, no = C.c_int32(6), C.c_int32(5)
+    rc = abi.lib().rmcv_track_step(buf.ctypes.data_as(C.c_void_p), C.byref(nt), 8, obs.ctypes.data_as(C.c_void_p), C.byref(no), C.c_double(1e9))
+    assert rc == abi.ERR_CAPACITY and nt.value == 6 and no.value == 5
+    assert buf[:6].tobytes() == before and obs.tobytes() == obs_before
+    with pytest.raises(RmcvError):
+        Context.track_step(tr, [mk(k, 20) for k in (0, 1, 20, 21, 22)], cap=8)
