@@ -63,9 +63,11 @@ def parse_args(argv=None):
                          "whole steps on one stream per context (round 1's schedule: the same steady state, a longer ramp)")
     ap.add_argument("--pixel-streams", type=int, default=2)
     ap.add_argument("--sparse-streams", type=int, default=2)
-    ap.add_argument("--gather", choices=("torch", "abi"), default="abi",
-                    help="the armour-list gather of a launched run: rmcv_gather, the C-ABI entry point that calls RCCL itself (what a "
-                         "C++ host uses; default), or torch.distributed.gather")
+    ap.add_argument("--gather", choices=("auto", "torch", "abi"), default="auto",
+                    help="the armour-list gather of a launched run: torch.distributed.gather (asynchronous; the default for more than "
+                         "one rank: rmcv_gather's multi-rank path has not run on hardware yet -- no multi-GPU box was available to this "
+                         "build) or rmcv_gather, the C-ABI entry point that calls RCCL itself (what a C++ host uses; the default for a "
+                         "launched single rank, where it moves nothing)")
     return ap.parse_args(argv)
 
 
@@ -116,7 +118,7 @@ def main():
     args = parse_args()
     world, rank, local_rank, launched = resolve_world(args, os.environ)
     if args.gpus > 1 and not launched:
-        import torch                                             # device_count() does not initialise the GPU
+        import torch                                             # (may call hipGetDeviceCount; harmless: the ranks are fresh children)
         have = torch.cuda.device_count()
         if have < args.gpus:
             raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have))
@@ -191,7 +193,10 @@ def main():
     # for the previous step's gather -- ONE communicator: a second RCCL communicator in the process cost 0.07 ms per step
     # by itself (0.335-0.343 against 0.268-0.284 ms, same box).  torch.distributed.gather synchronises the calling stream with the
     # process group's own stream, which in the pipelined schedule holds up the next step's sparse kernels (711-721 k frames/s).
+    if args.gather == "auto":
+        args.gather = "abi" if world == 1 else "torch"
     abi_gathers = [rdist.AbiGather(local_rank)] if (use_dist and args.gather == "abi") else None
+    works = [None] * ns                                          # torch path: the asynchronous gather of the step that last used record k
     ev_gath = [torch.cuda.Event() for _ in range(ns)]
     abi_recv = [abi_gathers[0].new_recv(r) for r in recs_buf] if abi_gathers else None
     gather_note = args.gather if use_dist else None
@@ -220,7 +225,9 @@ def main():
             out = abi_gathers[0].gather(recs_buf[k], abi_recv[k], hs)
             ev_gath[k].record(cur)
             return out
-        return rdist.gather_records(recs_buf[k], out=gather_out[k])
+        # asynchronous: the process group's stream waits for the record, the calling stream does not wait for the collective
+        out, works[k] = rdist.gather_records(recs_buf[k], out=gather_out[k], async_op=True)
+        return out
     # one stream per batch in flight (priorities alternate; with GPU_MAX_HW_QUEUES = 6 every stream has its own hardware queue, which is
     # what lets kernels of two steps actually run concurrently
     prios = [int(x) for x in os.environ.get("RMCV_BENCH_PRIOS", "").split(",") if x] or [0, -1]
@@ -244,6 +251,8 @@ def main():
         if not pipelined:
             with torch.cuda.stream(streams[k]):
                 run_path(ctxs[k], cur_stages[0], streams[k].cuda_stream)
+                if works[k] is not None:
+                    works[k].wait()                        # the record is rewritten: its previous gather must be through (stream-side wait)
                 ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
                 return gather_step(k, streams[k].cuda_stream, k)
         sA = sAs[(step_no[0] - 1) % len(sAs)]
@@ -258,20 +267,25 @@ def main():
             run_path(ctxs[k], cur_stages[0] & ~(STAGE_BINARY | STAGE_NO_IMAGE), sB.cuda_stream)
             if abi_gathers and not first_use:
                 sB.wait_event(ev_gath[k])                  # the record is rewritten: its previous gather (ns steps back) must be through
+            if works[k] is not None:
+                works[k].wait()                            # likewise on the torch path (a stream-side wait on the collective, ns steps old)
             ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), sB.cuda_stream)
-            if abi_gathers:
-                # the context's buffers are free once its list is compacted: the gather only reads the record, so the pixel kernel
-                # that reuses this context does not wait for the collective (it would lengthen the chain the step rate hangs on)
-                ev_done[k].record(sB)
-                return gather_step(k, sB.cuda_stream, k % len(sBs))
-            out = gather_step(k, sB.cuda_stream, k % len(sBs))
+            # the context's buffers are free once its list is compacted: the gather only reads the record, so the pixel kernel
+            # that reuses this context does not wait for the collective (it would lengthen the chain the step rate hangs on)
             ev_done[k].record(sB)
-            return out
+            return gather_step(k, sB.cuda_stream, k % len(sBs))
 
     def barrier():
+        # every stream that carried a gather is drained BEFORE the process group's own collectives (barrier, all_reduce) are
+        # enqueued: rmcv_gather's communicator and torch's never have kernels resident together -- with streams sharing
+        # hardware queues, a recv queued ahead of an all-reduce on one rank and the reverse on another could otherwise wait on each other
+        for wk in works:
+            if wk is not None:
+                wk.wait()
+        torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     if os.environ.get("RMCV_BENCH_STAGES"):                      # dev knob: later stages need the planes of a full pass
         for k in range(ns):
@@ -416,10 +430,10 @@ def main():
 
     out = {
         "metric": "frames/sec (%dx%d BGR) armour detect" % (W, H), "value": round(value, 1), "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup + warm_steps, "ms_per_step": round(ms_per_step, 4),
         "timed_region": {"repeats": len(rep_dt), "ms_per_step_each": [round(d / args.steps * 1e3, 4) for d in rep_dt],
                          "ms_per_step_median": round(ms_per_step, 4), "ms_per_step_min": round(srt[0] / args.steps * 1e3, 4),
-                         "value_at_min": round(world * n * args.steps / srt[0], 1), "warmup_steps_by_time": warm_steps,
+                         "value_at_min": round(world * n * args.steps / srt[0], 1), "warmup_steps_requested": args.warmup, "warmup_steps_by_time": warm_steps,
                          "host_enqueue_ms_per_step": round(sorted(enq_dt)[len(enq_dt) // 2] / args.steps * 1e3, 4),
                          "note": "each repeat = exactly `steps` steps between barrier+synchronize pairs; value/ms_per_step = the median repeat"},
         "steady_state": steady,

@@ -135,8 +135,10 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * pageable copy (measured fastest of the two safe ways: 0.37 ms per frame chain against 0.41); 1: through the context's
  * pinned staging buffer; 2: the caller's buffer is pinned in place on first sight (hipHostRegister, kept for the context's
  * lifetime, at most 16 buffers) and read by DMA with no CPU copy (0.35 ms) -- for camera SDKs that hand out a fixed ring of
- * frame buffers (the reference's cameras do, hardware/src/daheng.cpp:83); the buffers must stay mapped while the context
- * lives.  Results are identical. */
+ * frame buffers (the reference's cameras do, hardware/src/daheng.cpp:83).  A pinning is keyed by ADDRESS (and size): the
+ * buffers must stay mapped while the context lives, or be handed to rmcv_ctx_forget_frame_buffer BEFORE they are freed -- memory
+ * that is freed and mapped again at the same address would otherwise be read through the stale pinning (the same contract
+ * hipHostRegister itself has).  Results are identical. */
 #define RMCV_OPT_FRAME_UPLOAD 3
 /* RMCV_OPT_RUN_AHEAD: 1 (default): rmcv_extract_color also enqueues the blob and armour stages with the parameters the PREVIOUS
  * frame's rmcv_filter_lightblobs / rmcv_filter_armours calls used; when this frame's calls come with the same parameters and the
@@ -145,6 +147,11 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * Results are identical. */
 #define RMCV_OPT_RUN_AHEAD 4
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
+/* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
+ * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */
+int  rmcv_ctx_check_guards(rmcv_ctx* ctx, int32_t* n_damaged);
+/* drop the pinning RMCV_OPT_FRAME_UPLOAD = 2 made for `frame` (NULL: all of them); drains the context's stream first */
+int  rmcv_ctx_forget_frame_buffer(rmcv_ctx* ctx, const void* frame);
 
 /* ---- single frame, host buffers: one call per reference function ---------------------- */
 

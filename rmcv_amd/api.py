@@ -110,6 +110,12 @@ class Context:
         """tuning knobs (abi.OPT_SPARSE_WAVES: 8 = latency of a lone batch, 4 = throughput with several batches in flight)"""
         self._chk(lib().rmcv_ctx_set_option(self._h, int(option), int(value)))
 
+    def check_guards(self):
+        """(number of damaged guard zones around the context's device buffers, description of the first) -- 0 in a correct build"""
+        n = C.c_int32(-1)
+        self._chk(lib().rmcv_ctx_check_guards(self._h, C.byref(n)))
+        return n.value, lib().rmcv_last_error(self._h).decode()
+
     # ---------------------------------------------------------------- armour pose (src/mobility.cpp:166-190, main.cpp:183-192)
     def pnp_load(self, cfg=None):
         """camera matrix, distortion, gripper->camera transform, square size (defaults: the reference's main.cpp literals)"""

@@ -61,6 +61,8 @@ struct rmcv_ctx {
     int pixel_groups = 3;         // RMCV_OPT_PIXEL_GROUPS
     char err[256] = {0};
     std::vector<void*> allocs;
+    struct Guarded { uint8_t* base; size_t bytes; const char* name; size_t rear = 0; };
+    std::vector<Guarded> guarded; // every dalloc'd buffer with its guard zones (rmcv_ctx_check_guards)
 };
 
 static int fail(rmcv_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
@@ -79,17 +81,30 @@ static int fail(rmcv_ctx* c, int code, const char* what, hipError_t e = hipSucce
         if (e__ != hipSuccess) return fail((c), RMCV_ERR_HIP, what, e__); \
     } while (0)
 
+// Every device buffer of a context lies between two GUARD-byte zones filled with a fixed pattern when the context is created;
+// rmcv_ctx_check_guards reads them back.  A kernel that stores one row, word or record past either end of its buffer -- the
+// partial last strip of a 1200-row frame, the ragged last block of a 1920-pixel row -- shows up there instead of in a neighbour.
+static constexpr size_t GUARD = 4096;
+static constexpr int GUARD_BYTE = 0xA5;
 template <typename T>
-static hipError_t dalloc(rmcv_ctx* c, T** p, size_t count)
+static hipError_t dalloc_named(rmcv_ctx* c, T** p, size_t count, const char* name)
 {
     void* q = nullptr;
-    hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&q, bytes + 2 * GUARD);
     if (e == hipSuccess) {
         c->allocs.push_back(q);
-        *p = (T*)q;
+        c->guarded.push_back({(uint8_t*)q, bytes, name});
+        *p = (T*)((uint8_t*)q + GUARD);
+        e = hipMemset(q, GUARD_BYTE, GUARD);
+        // the rounding slack behind the payload belongs to the rear zone
+        if (e == hipSuccess) e = hipMemset((uint8_t*)q + GUARD + count * sizeof(T), GUARD_BYTE, bytes - count * sizeof(T) + GUARD);
+        c->guarded.back().bytes = count * sizeof(T);
+        c->guarded.back().rear = bytes - count * sizeof(T) + GUARD;
     }
     return e;
 }
+#define dalloc(c, p, count) dalloc_named((c), (p), (count), #p)
 
 extern "C" {
 
@@ -440,6 +455,48 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         return RMCV_OK;
     }
     return fail(c, RMCV_ERR_BAD_ARG, "unknown option or value");
+}
+
+int rmcv_ctx_check_guards(rmcv_ctx* c, int32_t* n_damaged)
+{
+    if (!c || !n_damaged) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int rc = rmcv_batch_sync(c);
+    if (rc) return rc;
+    std::vector<uint8_t> h;
+    int bad = 0;
+    c->err[0] = 0;
+    for (const auto& g : c->guarded) {
+        for (int side = 0; side < 2; side++) {
+            const size_t n = side ? g.rear : GUARD;
+            const uint8_t* src = side ? g.base + GUARD + g.bytes : g.base;
+            h.resize(n);
+            HIPCHK(c, hipMemcpy(h.data(), src, n, hipMemcpyDeviceToHost), "D2H guard zone");
+            size_t first = n;
+            for (size_t i = 0; i < n; i++)
+                if (h[i] != GUARD_BYTE) { first = i; break; }
+            if (first < n) {
+                if (!bad) snprintf(c->err, sizeof(c->err), "guard zone %s %s damaged at byte %zu (buffer of %zu bytes)", side ? "behind" : "in front of", g.name, first, g.bytes);
+                bad++;
+            }
+        }
+    }
+    *n_damaged = bad;
+    return RMCV_OK;
+}
+
+int rmcv_ctx_forget_frame_buffer(rmcv_ctx* c, const void* frame)
+{ // RMCV_OPT_FRAME_UPLOAD = 2 keys its pinnings by address: a buffer must be forgotten before it is freed (see the header)
+    if (!c) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+    for (size_t i = 0; i < c->registered.size();) {
+        if (!frame || c->registered[i].p == frame) {
+            hipHostUnregister(const_cast<void*>(c->registered[i].p));
+            c->registered.erase(c->registered.begin() + i);
+        } else i++;
+    }
+    return RMCV_OK;
 }
 
 int rmcv_batch_sync(rmcv_ctx* c)
@@ -821,9 +878,25 @@ static int finish_armours(rmcv_ctx* c, rmcv_armour* armours_out, int armours_cap
     return RMCV_OK;
 }
 
+static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride, int camp, int lower_bound, int morph,
+                              uint8_t* binary_out, rmcv_point* pts_out, int pts_cap, int32_t* offs_out, int contours_cap,
+                              int32_t* n_contours, int32_t* n_points);
+
 int rmcv_extract_color(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride, int camp, int lower_bound, int morph,
                        uint8_t* binary_out, rmcv_point* pts_out, int pts_cap, int32_t* offs_out, int contours_cap,
                        int32_t* n_contours, int32_t* n_points)
+{
+    const int rc = extract_color_body(c, bgr, w, h, stride, camp, lower_bound, morph, binary_out, pts_out, pts_cap, offs_out,
+                                      contours_cap, n_contours, n_points);
+    // The body enqueues an upload FROM the caller's frame and a download INTO the caller's `binary_out`.  An error return after
+    // the first of them must not leave either in flight: the caller owns those buffers again the moment this function returns.
+    if (rc != RMCV_OK && c) (void)hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride, int camp, int lower_bound, int morph,
+                              uint8_t* binary_out, rmcv_point* pts_out, int pts_cap, int32_t* offs_out, int contours_cap,
+                              int32_t* n_contours, int32_t* n_points)
 {
     if (!c || !bgr) return RMCV_ERR_BAD_ARG;
     if (morph < RMCV_MORPH_NONE || morph > RMCV_MORPH_CLOSE) return fail(c, RMCV_ERR_BAD_ARG, "bad morph");

@@ -57,14 +57,17 @@ def new_gather_list(rec, group=None, dst=0):
     return [torch.empty_like(rec) for _ in range(dist.get_world_size(group))] if dist.get_rank(group) == dst else None
 
 
-def gather_records(rec, group=None, dst=0, out=None):
-    """the one collective of the path; returns the list of records on dst, None elsewhere.  `out`: a list from new_gather_list"""
+def gather_records(rec, group=None, dst=0, out=None, async_op=False):
+    """the one collective of the path; returns the list of records on dst, None elsewhere.  `out`: a list from new_gather_list.
+    async_op=True returns (records, work): the collective is ordered after the work already enqueued on the current stream but the
+    current stream does NOT wait for it -- a pipelined caller goes on with the next step's kernels and calls work.wait() (a
+    stream-side wait, no host block) before it rewrites `rec` or reads the records."""
     if not dist.is_initialized():
-        return [rec]
+        return ([rec], None) if async_op else [rec]
     rank = dist.get_rank(group)
     recs = (out if out is not None else [torch.empty_like(rec) for _ in range(dist.get_world_size(group))]) if rank == dst else None
-    dist.gather(rec, recs, dst=dst, group=group)
-    return recs
+    work = dist.gather(rec, recs, dst=dst, group=group, async_op=async_op)
+    return (recs, work) if async_op else recs
 
 
 def unpack_records(recs, n_local, cap):

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--gpus", type=int, required=True)
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--cap", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=1)
     a = ap.parse_args()
     import bench
     world, rank, _, launched = bench.resolve_world(a, os.environ)      # the check bench.py itself applies
@@ -31,18 +32,41 @@ def main():
     from rmcv_amd import dist as rdist
     from rmcv_amd import synth
     O.set_math_mode(0)
-    offs, arms = [0], []
-    for i in range(rank * a.frames, (rank + 1) * a.frames):             # bench.py: rank r owns frames [r*n, (r+1)*n)
-        x = O.detect_frame(synth.frame(i, 640, 512))["armours"]
-        arms.append(x)
-        offs.append(offs[-1] + len(x))
-    arm = (np.concatenate(arms) if arms else np.zeros(0, O.ARMOUR)).view(np.uint8).reshape(-1)
-    rec = rdist.fill_record(rdist.new_record(a.frames, a.cap, "cpu"), a.frames, a.cap, np.asarray(offs, np.int32), arm)
-    recs = rdist.gather_records(rec, out=rdist.new_gather_list(rec))
+    ap_steps = a.steps
+    # the bench's pipelined form: `ap_steps` steps over TWO alternating records, every gather asynchronous (async_op), a record
+    # rewritten only after work.wait() on the gather that last read it; step s of rank r detects frames [(s*world + r)*n, ...)
+    recs_buf = [rdist.new_record(a.frames, a.cap, "cpu") for _ in range(2)]
+    outs = [rdist.new_gather_list(r) for r in recs_buf]
+    works, results = [None, None], []
+    for s in range(ap_steps):
+        k = s % 2
+        if works[k] is not None:
+            works[k].wait()
+            if rank == 0:
+                results.append(rdist.unpack_records(outs[k], a.frames, a.cap))      # consumed before the buffers are reused
+        offs, arms = [0], []
+        base = (s * world + rank) * a.frames
+        for i in range(base, base + a.frames):                          # bench.py: rank r owns frames [r*n, (r+1)*n) of its step
+            x = O.detect_frame(synth.frame(i, 640, 512))["armours"]
+            arms.append(x)
+            offs.append(offs[-1] + len(x))
+        arm = (np.concatenate(arms) if arms else np.zeros(0, O.ARMOUR)).view(np.uint8).reshape(-1)
+        recs_buf[k].zero_()
+        rdist.fill_record(recs_buf[k], a.frames, a.cap, np.asarray(offs, np.int32), arm)
+        _, works[k] = rdist.gather_records(recs_buf[k], out=outs[k], async_op=True)
+    for s in range(max(0, ap_steps - 2), ap_steps):                     # drain, in step order
+        k = s % 2
+        works[k].wait()
+        if rank == 0:
+            results.append(rdist.unpack_records(outs[k], a.frames, a.cap))
     if rank == 0:
-        g, goffs = rdist.unpack_records(recs, a.frames, a.cap)
+        g, goffs = results[0]
+        h = hashlib.sha256()
+        for gg, _ in results:
+            h.update(gg.tobytes())
         print(json.dumps({"n_gpus": dist.get_world_size(), "armours_gathered": int(g.shape[0]), "frame_offs": goffs.tolist(),
-                          "sha256": hashlib.sha256(g.tobytes()).hexdigest()}), flush=True)
+                          "sha256": hashlib.sha256(g.tobytes()).hexdigest(), "steps": len(results),
+                          "armours_all_steps": int(sum(gg.shape[0] for gg, _ in results)), "sha256_all_steps": h.hexdigest()}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

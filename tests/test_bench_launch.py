@@ -65,3 +65,24 @@ def test_launch_ranks_world2_equals_single_process():
 def test_launch_ranks_reports_a_failing_rank():
     rc, line = bench.launch_ranks(2, ["--gpus", "3"], script=os.path.join(HERE, "_bench_stub_worker.py"), timeout=600)
     assert rc != 0 and line is None
+
+
+def test_pipelined_async_gathers_world2_keep_every_step_apart():
+    """the default gather of a multi-rank bench run: torch.distributed.gather with async_op over alternating records, a record
+    rewritten only after work.wait() -- five steps, every step's gathered list equals the single-process list of ITS frames"""
+    import oracle_lib as O
+    from rmcv_amd import synth
+    O.set_math_mode(0)
+    frames, steps = 2, 5
+    rc, line = bench.launch_ranks(2, ["--gpus", "2", "--frames", str(frames), "--steps", str(steps)],
+                                  script=os.path.join(HERE, "_bench_stub_worker.py"), timeout=600)
+    assert rc == 0 and line
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == steps
+    h, total = hashlib.sha256(), 0
+    for i in range(steps * 2 * frames):                                # step s covers frames [s*2*frames, (s+1)*2*frames) in rank order
+        a = O.detect_frame(synth.frame(i, 640, 512))["armours"]
+        h.update(a.view(np.uint8).tobytes())
+        total += len(a)
+    assert out["armours_all_steps"] == total > 0
+    assert out["sha256_all_steps"] == h.hexdigest()
