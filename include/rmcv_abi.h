@@ -111,7 +111,11 @@ typedef struct {            /* capacities of one context; 0 = default */
 #define RMCV_FRAME_OVF_POINTS 2
 #define RMCV_FRAME_OVF_BLOBS 4
 #define RMCV_FRAME_OVF_ARMOURS 8
-#define RMCV_FRAME_SLOW_PATH 16 /* informational: nested components, literal scan was used */
+#define RMCV_FRAME_SLOW_PATH 16 /* informational: the sequential (literal) scanner was used -- the last resort: a frame beyond the mid tier
+                                 * too (> 131072 border visits, wider than 2048 px or taller than the row tables) */
+#define RMCV_FRAME_MID_PATH 64  /* informational: findContours of this frame ran on the mid tier (tables in global memory: the frame is
+                                 * beyond the LDS tables -- > 4096 border visits, > 1024 non-empty words, > 512 contours -- but was not
+                                 * handed to the sequential scanner) */
 #define RMCV_FRAME_HULL 32      /* legacy matcher: a contour exceeded the hull tables (dimensions > 4096) or is not a closed border */
 
 typedef struct rmcv_ctx rmcv_ctx;
@@ -146,6 +150,11 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * chain of executable/main.cpp:172-176 is then one stream sequence with one synchronisation.  0: every call does its own work.
  * Results are identical. */
 #define RMCV_OPT_RUN_AHEAD 4
+/* RMCV_OPT_CONTOUR_TIER: which form of findContours a frame takes -- 0 (default): chosen per frame (tables in LDS; beyond their
+ * capacity the same formulation with tables in global memory, RMCV_FRAME_MID_PATH; beyond that the sequential scanner,
+ * RMCV_FRAME_SLOW_PATH); 1: the sequential scanner for every frame; 2: the mid tier for every frame.  A test / diagnosis knob:
+ * results are identical. */
+#define RMCV_OPT_CONTOUR_TIER 5
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */

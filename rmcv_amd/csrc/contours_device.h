@@ -14,6 +14,10 @@ __device__ __forceinline__ uint64_t ld_l2(const uint64_t* p)
 { // bypass the (non-coherent) vector L1: labels are written with L2 atomics by another lane
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ unsigned long long ld_l2(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // 64-bit window of row y starting at pixel xb (xb multiple of 32, may be -32 .. ) of a padded plane
 __device__ __forceinline__ uint64_t win_load(const uint32_t* plane32, int prow, int y, int xb)
@@ -346,10 +350,11 @@ __device__ __forceinline__ int multi_extra(const ContoursLds& S, int slot, int b
 // findContours of one frame by the whole workgroup (T threads); on return S.kkey/koff/klen/nkept/cursor describe the kept contours
 // (in any order; the caller ranks them by key), the points are written and the labels of the accepted borders are in the LDS
 // label store.
-// FL (= FL_COMPLEX) is OR-ed into S.flags when a capacity is exceeded or a pixel is visited three times.
+// FLCAP is OR-ed into S.flags when a capacity of the LDS tables is exceeded (the frame then takes the mid tier), FL when the
+// formulation met something it cannot express (the literal scanner settles it).
 template <int T>
 __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int prow, int h, int ww, int nrows, int tid,
-                             rmcv_point* __restrict__ pts, int max_points, int max_contours, int FL, uint32_t* __restrict__ pxy)
+                             rmcv_point* __restrict__ pts, int max_points, int max_contours, int FL, int FLCAP, uint32_t* __restrict__ pxy)
 {
     constexpr int NPT = NN_CAP / T; // nodes per thread in the doubling rounds
     const LabelStore LS = {S.rowmask, S.rowbase, S.lab, S.neg};
@@ -400,7 +405,7 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
             if (cnt >= 3) { // a junction of 1-pixel lines: listed on the side
                 const int m = atomicAdd(&S.nmulti, 1);
                 if (m < MULTI_CAP) S.multi[m] = (uint32_t)slot | ((uint32_t)b << 16) | (cnt << 24);
-                else atomicOr(&S.flags, FL);
+                else atomicOr(&S.flags, FLCAP);
                 extra += (int)cnt - 2;
             }
         }
@@ -435,11 +440,11 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
         }
         if (tid == T - 1) {
             S.nnodes = S.scan[tid];
-            if (S.scan[tid] > NN_CAP) S.flags |= FL;
+            if (S.scan[tid] > NN_CAP) S.flags |= FLCAP;
         }
     }
     __syncthreads();
-    if (S.flags & FL) return;
+    if (S.flags) return;
     const int nn = S.nnodes;
     CSTAMP();
     // ---- N2: the nodes
@@ -509,7 +514,7 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
         nxt[i] = (uint16_t)succ;
     }
     __syncthreads();
-    if (S.flags & FL) return;
+    if (S.flags) return;
     CSTAMP();
     // ---- N4: smallest node id of every cycle, by pointer doubling
     int rounds = 0;
@@ -592,7 +597,7 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
             const int len = dist[succ0[u]] + 1;
             const int slot = atomicAdd(&S.nkept, 1);
             if (slot >= KEPT_CAP || slot >= max_contours) {
-                atomicOr(&S.flags, FL);
+                atomicOr(&S.flags, FLCAP);
             } else {
                 const uint32_t p = pxy[i];
                 S.kkey[slot] = ((p >> 12) & 0xFFFu) << 16 | (p & 0xFFFu);
@@ -604,7 +609,7 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
         if (mn[i] == i) jp[i] = ks;
     }
     __syncthreads();
-    if (S.flags & FL) return;
+    if (S.flags) return;
     // ---- N7: RETR_EXTERNAL.  OpenCV's scanner skips an outer-border start when the last labelled pixel it met on the row is
     // positive, and only the borders it traced carry labels: a component inside a hole of a traced one is skipped.  A start's
     // left context consists of raster-earlier borders only, so the scanner's decisions are the fixed point of "label the accepted
@@ -661,11 +666,11 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
     for (int e = tid; e < ncand; e += T)
         if (S.kacc[e]) {
             const int off = atomicAdd(&S.cursor, S.klen[e]);
-            if (off + S.klen[e] > max_points) atomicOr(&S.flags, FL);
+            if (off + S.klen[e] > max_points) atomicOr(&S.flags, FLCAP);
             S.koff[e] = off;
         }
     __syncthreads();
-    if (S.flags & FL) return;
+    if (S.flags) return;
     for (int i = tid; i < nn; i += T) {
         const int ks = jp[mn[i]];
         if (ks == 0xFFFF || !S.kacc[ks]) continue;
@@ -705,6 +710,399 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
                (tc_[1] - tc_[0]) / 100.0, (tc_[2] - tc_[1]) / 100.0, (tc_[3] - tc_[2]) / 100.0, (tc_[4] - tc_[3]) / 100.0,
                (tc_[5] - tc_[4]) / 100.0, (tc_[6] - tc_[5]) / 100.0, (tc_[7] - tc_[6]) / 100.0);
 #endif
+}
+
+
+// ---- mid tier: the same cycle formulation with its tables in GLOBAL memory ---------------------------------------------------
+// cv::findContours has no bound (src/imgproc.cpp:71-72).  A frame beyond what the LDS tables hold (VISIT_CAP visits, SLOT_CAP
+// non-empty words, KEPT_CAP contours, MULTI_CAP junction pixels) used to go straight to the literal scanner -- one wavefront
+// walking borders step by step, ~0.3 us per step, and the rest of its launch waiting for it.  This tier keeps the parallel
+// formulation and moves the per-word and per-visit tables into a scratch block of the workgroup's own in HBM (L2-resident for
+// frames a little over the LDS tier): up to NN_MID visits, every word of the frame, CAND_MID outer borders, any number of
+// junction pixels (the 3- and 4-visit pixels get mask planes of their own instead of a side list).  The row tables (non-empty
+// rows, their word masks, slot bases) stay in LDS.  Differences from cycles_frame that the size forces:
+//   * node ids are 32-bit; (smallest id of the cycle | doubling pointer) and (distance to the start | doubling pointer) are
+//     packed into ONE 64-bit word each, read and written whole: a sweep of the pointer doubling then needs no read-all /
+//     write-all phases (a word is a consistent segment description whenever it is read), only a barrier per sweep;
+//   * discovery ranks and point offsets come from prefix sums over the candidates in node order (= raster order of the
+//     starts) instead of an all-pairs ranking.
+// The literal scanner remains the last resort (more visits than NN_MID, wider/taller than the row tables, verification failed).
+struct MidTables {
+    unsigned long long *lab, *neg, *bmask, *e2, *e3, *e4; // [slot_cap] per non-empty word
+    uint32_t *nbase, *spos;                               // [slot_cap]
+    unsigned long long *link, *dist;                      // [NN_MID]   mn << 32 | jp    and    dist << 32 | jp
+    uint32_t *pxy, *succ;                                 // [NN_MID]
+    uint32_t *cand, *klen, *koff, *kacc;                  // [CAND_MID]
+    int slot_cap;
+};
+__device__ __forceinline__ MidTables mid_tables(uint8_t* base, int slot_cap)
+{
+    MidTables M;
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(base);
+    M.lab = q; q += slot_cap;
+    M.neg = q; q += slot_cap;
+    M.bmask = q; q += slot_cap;
+    M.e2 = q; q += slot_cap;
+    M.e3 = q; q += slot_cap;
+    M.e4 = q; q += slot_cap;
+    M.link = q; q += NN_MID;
+    M.dist = q; q += NN_MID;
+    uint32_t* r = reinterpret_cast<uint32_t*>(q);
+    M.nbase = r; r += slot_cap;
+    M.spos = r; r += slot_cap;
+    M.pxy = r; r += NN_MID;
+    M.succ = r; r += NN_MID;
+    M.cand = r; r += CAND_MID;
+    M.klen = r; r += CAND_MID;
+    M.koff = r; r += CAND_MID;
+    M.kacc = r; r += CAND_MID;
+    M.slot_cap = slot_cap;
+    return M;
+}
+__device__ __forceinline__ unsigned long long ld64(const unsigned long long* p)
+{ // one 8-byte access, never split or cached in a register across a sweep
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void st64(unsigned long long* p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// exclusive prefix of one value per thread over the workgroup (scan[] holds T ints); *total = the sum
+template <int T>
+__device__ __forceinline__ int wg_scan_excl(int* scan, int tid, int v, int* total)
+{
+    scan[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < T; d <<= 1) {
+        const int t = tid >= d ? scan[tid - d] : 0;
+        __syncthreads();
+        scan[tid] += t;
+        __syncthreads();
+    }
+    const int incl = scan[tid];
+    *total = scan[T - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+// findContours of one frame on the mid tier.  On success (no FL in S.flags): points, cs[rank], cl[rank] (discovery order) are
+// written, *nc_out / *np_out hold the counts.  FL is OR-ed into S.flags when the frame is beyond this tier too.
+template <int T>
+__device__ void cycles_frame_mid(ContoursLds& S, const MidTables& M, const uint64_t* __restrict__ F, int prow, int h, int ww, int nrows,
+                                 int tid, rmcv_point* __restrict__ pts, int32_t* __restrict__ cs, int32_t* __restrict__ cl,
+                                 int max_points, int max_contours, int FL, int* nc_out, int* np_out)
+{
+    const LabelStore LS = {S.rowmask, S.rowbase, nullptr, nullptr};
+    for (int i = tid; i < 256; i += T) S.ringtab[i] = RINGTAB.v[i];
+    if (tid == 0) { S.nnodes = 0; S.revoked = 0; }
+    const int nslots = S.nslots;
+    if (nslots > M.slot_cap || nslots > 65535) { // (rowbase is 16 bits wide)
+        if (tid == 0) S.flags |= FL;
+        __syncthreads();
+        return;
+    }
+    __syncthreads();
+    // slot -> (row, word)
+    for (int r = tid; r < nrows; r += T) {
+        const int y = S.rows[r];
+        uint32_t occ = S.rowmask[y];
+        int slot = S.rowbase[y];
+        while (occ) {
+            const int k = __ffs((int)occ) - 1;
+            occ &= occ - 1;
+            M.spos[slot++] = (uint32_t)(y | (k << 11));
+        }
+    }
+    __syncthreads();
+    // ---- M1: per non-empty word: border pixels, pixels visited >= 2, >= 3, 4 times; node count
+    for (int slot = tid; slot < nslots; slot += T) {
+        const uint32_t sp = M.spos[slot];
+        const int y = sp & 2047, k = sp >> 11;
+        const int64_t base = (int64_t)(y + 1) * prow + 1;
+        const uint64_t mc = F[base + k];
+        const uint64_t ul = F[base - prow + k - 1], uc = F[base - prow + k], ur = F[base - prow + k + 1];
+        const uint64_t ml = F[base + k - 1], mr = F[base + k + 1];
+        const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
+        const uint64_t left = (mc << 1) | (ml >> 63), right = (mc >> 1) | (mr << 63);
+        const uint64_t B = mc & ~(uc & dc & left & right);
+        uint64_t E2 = 0, E3 = 0, E4 = 0, rem = B;
+        while (rem) {
+            const int b = __ffsll((long long)rem) - 1;
+            rem &= rem - 1;
+            const uint32_t cnt = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)] & 7u;
+            if (cnt >= 2) E2 |= 1ull << b;
+            if (cnt >= 3) E3 |= 1ull << b;
+            if (cnt >= 4) E4 |= 1ull << b;
+        }
+        M.bmask[slot] = B;
+        M.e2[slot] = E2;
+        M.e3[slot] = E3;
+        M.e4[slot] = E4;
+        M.nbase[slot] = (uint32_t)(__popcll(B) + __popcll(E2) + __popcll(E3) + __popcll(E4));
+    }
+    __syncthreads();
+    int nn;
+    { // exclusive prefix of the node counts over the slots (raster order)
+        const int per = (nslots + T - 1) / T;
+        int sum = 0;
+        for (int u = 0; u < per; u++) {
+            const int i = tid * per + u;
+            if (i < nslots) sum += (int)M.nbase[i];
+        }
+        int run = wg_scan_excl<T>(S.scan, tid, sum, &nn);
+        for (int u = 0; u < per; u++) {
+            const int i = tid * per + u;
+            if (i < nslots) {
+                const int c = (int)M.nbase[i];
+                M.nbase[i] = (uint32_t)run;
+                run += c;
+            }
+        }
+    }
+    if (nn > NN_MID) {
+        if (tid == 0) S.flags |= FL;
+        __syncthreads();
+        return;
+    }
+    if (tid == 0) S.nnodes = nn;
+    __syncthreads();
+    // ---- M2: the nodes
+    for (int slot = tid; slot < nslots; slot += T) {
+        const uint64_t B = M.bmask[slot];
+        if (!B) continue;
+        const uint32_t sp = M.spos[slot];
+        const int y = sp & 2047, k = sp >> 11;
+        const int64_t base = (int64_t)(y + 1) * prow + 1;
+        const uint64_t mc = F[base + k];
+        const uint64_t ul = F[base - prow + k - 1], uc = F[base - prow + k], ur = F[base - prow + k + 1];
+        const uint64_t ml = F[base + k - 1], mr = F[base + k + 1];
+        const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
+        uint32_t id = M.nbase[slot];
+        uint64_t rem = B;
+        while (rem) {
+            const int b = __ffsll((long long)rem) - 1;
+            rem &= rem - 1;
+            const uint32_t e = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)];
+            const int cnt = (int)(e & 7u);
+            const uint32_t xy = (uint32_t)(k * 64 + b) | ((uint32_t)y << 12);
+            for (int a = 0; a < cnt && a < 4; a++) {
+                const uint32_t back = (e >> (3 + 3 * a)) & 7u, nextd = (e >> (15 + 3 * a)) & 7u, ng = (e >> (28 + a)) & 1u;
+                const uint32_t west = a == 0 ? (e >> 27) & 1u : 0u;
+                M.pxy[id++] = xy | (back << 24) | (ng << 27) | (west << 28) | (nextd << 29);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- M3: successor of every node
+    for (int i = tid; i < nn; i += T) {
+        const uint32_t p = M.pxy[i];
+        const int x = (int)(p & 0xFFFu), y = (int)((p >> 12) & 0xFFFu), nd = (int)(p >> 29);
+        uint32_t succ = (uint32_t)i;
+        const int xs = x + dir_dx(nd), ys = y + dir_dy(nd);
+        const int ks = xs >> 6, bs = xs & 63;
+        bool ok = xs >= 0 && ys >= 0 && ys < h && ks < ww && ((S.rowmask[ys] >> ks) & 1u);
+        int slot2 = 0;
+        unsigned long long B2 = 0;
+        if (ok) {
+            slot2 = LS.slot(ys, ks);
+            B2 = M.bmask[slot2];
+            ok = (B2 >> bs) & 1ull;
+        }
+        if (ok) {
+            const uint64_t below = (1ull << bs) - 1;
+            const unsigned long long E2 = M.e2[slot2], E3 = M.e3[slot2], E4 = M.e4[slot2];
+            const uint32_t id0 = M.nbase[slot2] + (uint32_t)(__popcll(B2 & below) + __popcll(E2 & below) + __popcll(E3 & below) + __popcll(E4 & below));
+            const int cnt2 = 1 + (int)((E2 >> bs) & 1ull) + (int)((E3 >> bs) & 1ull) + (int)((E4 >> bs) & 1ull);
+            const uint32_t back2 = (uint32_t)((nd + 4) & 7);
+            succ = id0; // the visit of the successor pixel whose back direction points here
+            for (int a = 1; a < cnt2; a++)
+                if (((M.pxy[id0 + a] >> 24) & 7u) == back2) succ = id0 + (uint32_t)a;
+        } else { // only an isolated pixel has no successor (it stays where it is); anything else contradicts the bijection
+            const int k0 = x >> 6;
+            const int64_t base = (int64_t)(y + 1) * prow + 1;
+            const uint32_t ring = ring_of(x & 63, F[base - prow + k0 - 1], F[base - prow + k0], F[base - prow + k0 + 1], F[base + k0 - 1],
+                                          F[base + k0], F[base + k0 + 1], F[base + prow + k0 - 1], F[base + prow + k0], F[base + prow + k0 + 1]);
+            if (ring != 0) atomicOr(&S.flags, FL);
+        }
+        M.succ[i] = succ;
+        M.link[i] = ((unsigned long long)(uint32_t)i << 32) | succ;
+    }
+    __syncthreads();
+    if (S.flags & FL) return;
+    // ---- M4: smallest node id of every cycle.  A word (mn, jp) always describes a true segment [i, jp) of the cycle with its
+    // minimum, so a sweep may read words other threads have already advanced: after `rounds` sweeps every segment is at least
+    // nn long, i.e. covers its whole cycle.
+    int rounds = 0;
+    while ((1 << rounds) < nn) rounds++;
+    for (int rd = 0; rd < rounds; rd++) {
+        for (int i = tid; i < nn; i += T) {
+            const unsigned long long w = ld64(M.link + i);
+            const unsigned long long wt = ld64(M.link + (uint32_t)w);
+            const unsigned long long mn = (w >> 32) < (wt >> 32) ? (w >> 32) : (wt >> 32);
+            st64(M.link + i, (mn << 32) | (uint32_t)wt);
+        }
+        __syncthreads();
+    }
+    // ---- M5: steps from every node FORWARD to its cycle's start (the start absorbs)
+    for (int i = tid; i < nn; i += T) {
+        const bool start = (uint32_t)(ld64(M.link + i) >> 32) == (uint32_t)i;
+        M.dist[i] = start ? (unsigned long long)(uint32_t)i : ((1ull << 32) | M.succ[i]);
+    }
+    __syncthreads();
+    for (int rd = 0; rd < rounds; rd++) {
+        for (int i = tid; i < nn; i += T) {
+            const unsigned long long w = ld64(M.dist + i);
+            const unsigned long long wt = ld64(M.dist + (uint32_t)w);
+            st64(M.dist + i, (((w >> 32) + (wt >> 32)) << 32) | (uint32_t)wt);
+        }
+        __syncthreads();
+    }
+    // ---- M6: candidates = cycles whose start visit contains the west neighbour, numbered in node order (raster order of the starts)
+    int ncand;
+    {
+        const int per = (nn + T - 1) / T;
+        const int lo = tid * per, hi = (lo + per < nn) ? lo + per : nn;
+        int cnt = 0;
+        for (int i = lo; i < hi; i++)
+            cnt += ((uint32_t)(M.link[i] >> 32) == (uint32_t)i) && ((M.pxy[i] >> 28) & 1u);
+        int e = wg_scan_excl<T>(S.scan, tid, cnt, &ncand);
+        if (ncand <= CAND_MID) {
+            for (int i = lo; i < hi; i++) {
+                if ((uint32_t)(M.link[i] >> 32) != (uint32_t)i) continue;
+                if ((M.pxy[i] >> 28) & 1u) {
+                    M.cand[e] = (uint32_t)i;
+                    M.klen[e] = (uint32_t)(M.dist[M.succ[i]] >> 32) + 1u;
+                    M.kacc[e] = 1u;
+                    M.succ[i] = (uint32_t)e; // from here on: start node -> candidate index
+                    e++;
+                } else M.succ[i] = 0xFFFFFFFFu; // a hole border
+            }
+        }
+    }
+    if (ncand > CAND_MID) {
+        if (tid == 0) S.flags |= FL;
+        __syncthreads();
+        return;
+    }
+    __syncthreads();
+    // ---- M7: RETR_EXTERNAL as the fixed point of "label the accepted borders, revoke the starts whose nearest labelled pixel to
+    // the left is positive" (see cycles_frame)
+    for (int round = 0;; round++) {
+        if (tid == 0) S.revoked = 0;
+        for (int i = tid; i < nslots; i += T) { M.lab[i] = 0; M.neg[i] = 0; }
+        __syncthreads();
+        for (int i = tid; i < nn; i += T) {
+            const uint32_t e = M.succ[(uint32_t)(M.link[i] >> 32)];
+            if (e == 0xFFFFFFFFu || !M.kacc[e]) continue;
+            const uint32_t p = M.pxy[i];
+            const int x = (int)(p & 0xFFFu), y = (int)((p >> 12) & 0xFFFu);
+            const int slot = LS.slot(y, x >> 6);
+            atomicOr(&M.lab[slot], 1ull << (x & 63));
+            if ((p >> 27) & 1u) atomicOr(&M.neg[slot], 1ull << (x & 63));
+        }
+        __syncthreads();
+        for (int e = tid; e < ncand; e += T) {
+            if (!M.kacc[e]) continue;
+            const uint32_t p = M.pxy[M.cand[e]];
+            const int x0 = (int)(p & 0xFFFu), y0 = (int)((p >> 12) & 0xFFFu);
+            const uint32_t occ = S.rowmask[y0];
+            int k = x0 >> 6;
+            // (the labels were OR-ed in by L2 atomics: read them past the vector L1, like the literal scanner does)
+            unsigned long long l = ld_l2(M.lab + LS.slot(y0, k)) & ((1ull << (x0 & 63)) - 1);
+            uint32_t left = occ & ((1u << k) - 1u);
+            while (!l && left) {
+                k = 31 - __clz((int)left);
+                left &= ~(1u << k);
+                l = ld_l2(M.lab + LS.slot(y0, k));
+            }
+            if (l) {
+                const int top = 63 - __clzll((long long)l);
+                if (!((ld_l2(M.neg + LS.slot(y0, k)) >> top) & 1ull)) { // positive: inside a hole of that border
+                    M.kacc[e] = 0u;
+                    S.revoked = 1;
+                }
+            }
+        }
+        __syncthreads();
+        const int again = S.revoked;
+        __syncthreads();
+        if (!again) break;
+        if (round >= 32) {
+            if (tid == 0) S.flags |= FL;
+            __syncthreads();
+            return;
+        }
+    }
+    // ---- M8: discovery rank and point offset of every accepted border (prefix sums in candidate order), then the points
+    int nacc, npts;
+    {
+        const int per = (ncand + T - 1) / T;
+        const int lo = tid * per, hi = (lo + per < ncand) ? lo + per : ncand;
+        int cnt = 0, plen = 0;
+        for (int e = lo; e < hi; e++)
+            if (M.kacc[e]) { cnt++; plen += (int)M.klen[e]; }
+        int rank = wg_scan_excl<T>(S.scan, tid, cnt, &nacc);
+        int off = wg_scan_excl<T>(S.scan, tid, plen, &npts);
+        if (nacc <= max_contours && npts <= max_points) {
+            for (int e = lo; e < hi; e++)
+                if (M.kacc[e]) {
+                    M.koff[e] = (uint32_t)off;
+                    cs[rank] = off;
+                    cl[rank] = (int32_t)M.klen[e];
+                    off += (int)M.klen[e];
+                    rank++;
+                }
+        }
+    }
+    if (nacc > max_contours || npts > max_points) { // the literal scanner reports the overflow the way it always did
+        if (tid == 0) S.flags |= FL;
+        __syncthreads();
+        return;
+    }
+    __syncthreads();
+    for (int i = tid; i < nn; i += T) {
+        const uint32_t e = M.succ[(uint32_t)(M.link[i] >> 32)];
+        if (e == 0xFFFFFFFFu || !M.kacc[e]) continue;
+        const uint32_t p = M.pxy[i];
+        rmcv_point q;
+        q.x = (int)(p & 0xFFFu);
+        q.y = (int)((p >> 12) & 0xFFFu);
+        const int len = (int)M.klen[e], d = (int)(M.dist[i] >> 32), pos = d ? len - d : 0;
+        if (pos >= 0 && pos < len) pts[M.koff[e] + pos] = q;
+    }
+    // ---- V2 on the final labels: every unlabelled run start would have been rejected by the scanner (nearest labelled pixel to
+    // its left positive).  (V1 -- every accepted start acceptable -- is what the last round of M7 established.)
+    for (int r = tid; r < nrows; r += T) {
+        const int y = S.rows[r];
+        const int64_t base = (int64_t)(y + 1) * prow + 1;
+        uint32_t rem = S.rowmask[y];
+        int slot = S.rowbase[y];
+        uint64_t carry = 0;
+        bool last_pos = false;
+        int kprev = -2;
+        while (rem) {
+            const int k = __ffs((int)rem) - 1;
+            rem &= rem - 1;
+            const uint64_t fwd = F[base + k];
+            if (k != kprev + 1) carry = 0;
+            kprev = k;
+            const unsigned long long l = ld_l2(M.lab + slot), ng = ld_l2(M.neg + slot);
+            slot++;
+            uint64_t cnd = fwd & ~((fwd << 1) | carry) & ~l;
+            while (cnd) {
+                const int b = __ffsll((long long)cnd) - 1;
+                cnd &= cnd - 1;
+                const uint64_t below = l & ((1ull << b) - 1);
+                const bool pos = below ? !((ng >> (63 - __clzll((long long)below))) & 1ull) : last_pos;
+                if (!pos) atomicOr(&S.flags, FL);
+            }
+            if (l) last_pos = !((ng >> (63 - __clzll((long long)l))) & 1ull);
+            carry = fwd >> 63;
+        }
+    }
+    __syncthreads();
+    *nc_out = nacc;
+    *np_out = npts;
 }
 
 } // namespace rmcv

@@ -48,10 +48,12 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
         if (e != hipSuccess) return e;
         attr_set[g.device] = true;
     }
-    if (waves == 4) return launch_contours_w4(g, b, lim, X, force_literal, s);
+    const int force = force_literal ? force_literal : g.contour_tier;
+    if (waves == 4) return launch_contours_w4(g, b, lim, X, force, s);
     return launch(k_contours_w8, dim3(g.n_frames), dim3(512), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
                        g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
-                       lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy);
+                       lim.max_contours, lim.max_points, force, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy, b.mid, b.mid_stride,
+                       b.mid_slot_cap);
 }
 
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)

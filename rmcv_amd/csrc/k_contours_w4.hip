@@ -21,7 +21,8 @@ hipError_t launch_contours_w4(const Geom& g, const Bufs& b, const Limits& lim, c
     }
     return launch(k_contours_w4, dim3(g.n_frames), dim3(256), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
                        g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
-                       lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy);
+                       lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy, b.mid, b.mid_stride,
+                       b.mid_slot_cap);
 }
 
 } // namespace rmcv

@@ -206,6 +206,12 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.n_contours, F);
     if (e == hipSuccess) e = dalloc(c, &b.n_points, F);
     if (e == hipSuccess) e = dalloc(c, &b.visit_xy, F * VISIT_CAP);
+    if (e == hipSuccess) { // the mid tier's tables: one block per frame slot, its per-word tables sized for every word of the largest frame
+        const int64_t words = (int64_t)((d.max_width + 63) / 64) * d.max_height;
+        b.mid_slot_cap = (int)std::min<int64_t>(words, 65535);
+        b.mid_stride = (int64_t)((mid_bytes(b.mid_slot_cap) + 255) & ~(size_t)255);
+        e = dalloc(c, &b.mid, F * (size_t)b.mid_stride);
+    }
     if (e == hipSuccess) e = dalloc(c, &b.blobs, F * d.max_blobs);
     if (e == hipSuccess) e = dalloc(c, &b.blob_src, F * d.max_blobs);
     if (e == hipSuccess) e = dalloc(c, &b.ellipses, F * d.max_blobs);
@@ -448,6 +454,10 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
     }
     if (option == RMCV_OPT_FRAME_UPLOAD && value >= 0 && value <= 2) {
         c->frame_upload = value;
+        return RMCV_OK;
+    }
+    if (option == RMCV_OPT_CONTOUR_TIER && value >= 0 && value <= 2) {
+        c->geom.contour_tier = value;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_PIXEL_GROUPS && value >= 1 && value <= 8) {

@@ -18,6 +18,7 @@ namespace rmcv {
 struct Geom {
     int device;          // HIP device of the owning context: per-device launch state (function attributes) is indexed by it
     int n_cu;            // compute units of that device (sizes the persistent grid of k_binary)
+    int contour_tier;    // RMCV_OPT_CONTOUR_TIER: 0 = per frame (LDS tables, else mid tier, else literal scanner), 1 = literal, 2 = mid tier
     int n_frames;
     int w, h;
     int stride;          // bytes between rows of the BGR input
@@ -27,7 +28,14 @@ struct Geom {
     int64_t plane_pitch; // words per frame = (h + 2) * prow
 };
 
-static constexpr int VISIT_CAP = 4096; // border visits of one frame the contour stage holds (contours_device.h); more -> literal scanner
+static constexpr int VISIT_CAP = 4096; // border visits of one frame the contour stage holds in LDS (contours_device.h); more -> mid tier
+static constexpr int NN_MID = 1 << 17;   // border visits of one frame the mid tier holds (tables in global memory); more -> literal scanner
+static constexpr int CAND_MID = 1 << 15; // outer borders (before RETR_EXTERNAL drops the nested ones) the mid tier holds
+// bytes of one frame slot's mid-tier scratch block (layout: contours_device.h, mid_tables)
+inline size_t mid_bytes(int slot_cap)
+{
+    return (size_t)slot_cap * (6 * 8 + 2 * 4) + (size_t)NN_MID * (2 * 8 + 2 * 4) + (size_t)CAND_MID * 4 * 4;
+}
 
 struct Limits {
     int max_frames, max_width, max_height, max_contours, max_points, max_blobs, max_armours;
@@ -50,6 +58,9 @@ struct Bufs {
     int32_t* n_contours;   // [frame]
     int32_t* n_points;     // [frame]
     uint32_t* visit_xy;    // [frame][VISIT_CAP] scratch of the contour stage: packed (x, y, directions) of every border visit
+    uint8_t* mid;          // [frame][mid_stride] scratch of the contour stage's mid tier (contours_device.h: MidTables)
+    int64_t mid_stride;
+    int mid_slot_cap;      // words per frame the mid tier's per-word tables hold (= every word of the largest frame)
     // light blobs (positive list, in findContours order) and the negative list (contour indices)
     rmcv_lightblob* blobs; // [frame][max_blobs]
     int32_t* blob_src;     // [frame][max_blobs]   contour index (findContours order)

@@ -16,6 +16,15 @@
  *   specks      S in 0..20 enemy-colour specks of 1..3 px (area < 10: exercise the gate)
  *   variant 1 ("stress"): a white core of width/3 inside each enemy bar (holes / splits)
  *               and 0.1 % white salt pixels.
+ *   variants 10..14 ("dense", level L = variant - 10): the plain stream plus what a real camera adds to it -- bright
+ *               enemy-coloured areas (lit windows, reflections on the floor) and far more small specks (glare on edges, LEDs):
+ *               level     :    0     1     2     3     4
+ *               specks    :   +0  +100  +400 +1000 +2000   (1..3 px, on top of the plain stream's 0..20; exact counts)
+ *               windows   :    0     1     3     7    13   rectangles of 40..120 x 30..100 px with a ragged (noisy) rim
+ *               foreground:  0.25   0.6   1.4   2.9   5.3  % of the pixels at 1280x1024 (level 0 = the plain stream)
+ *               Windows and specks may touch bars and each other (nothing is kept apart): a frame of level 3 has ~950
+ *               contours, ~6000 border points and ~3000 non-empty words -- beyond what findContours' LDS tables
+ *               hold, which is what these variants are for (cv::findContours itself has no bound, src/imgproc.cpp:71-72).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -180,6 +189,36 @@ int rmcv_synth_frame(uint8_t* bgr, int w, int h, int stride, uint64_t frame_inde
         for (int k = 0; k < npx; k++) {
             uint8_t* p = bgr + (size_t)(y + sy[k]) * stride + 3 * (size_t)(x + sx[k]);
             p[0] = 255; p[1] = g0; p[2] = r0;
+        }
+    }
+
+    if (variant >= 10 && variant <= 14) { /* dense levels */
+        static const int n_specks[5] = {0, 100, 400, 1000, 2000}, n_windows[5] = {0, 1, 3, 7, 13};
+        const int L = variant - 10;
+        rng_t dn = {seed * 0xA24BAED4963EE407ull + 3};
+        for (int k = 0; k < n_windows[L]; k++) {
+            int ww_ = rng_range(&dn, 40, 120), wh_ = rng_range(&dn, 30, 100);
+            if (ww_ > w - 4) ww_ = w - 4;
+            if (wh_ > h - 4) wh_ = h - 4;
+            int x0 = rng_range(&dn, 1, w - 2 - ww_), y0 = rng_range(&dn, 1, h - 2 - wh_);
+            uint8_t g0 = (uint8_t)rng_range(&dn, 160, 220), r0 = (uint8_t)rng_range(&dn, 0, 60);
+            for (int y = y0; y < y0 + wh_; y++)
+                for (int x = x0; x < x0 + ww_; x++) {
+                    /* ragged rim: the outermost two pixel rings are lit with probability 1/2 */
+                    int rim = (y - y0 < 2) || (y0 + wh_ - 1 - y < 2) || (x - x0 < 2) || (x0 + ww_ - 1 - x < 2);
+                    if (rim && (rng_next(&dn) & 1)) continue;
+                    uint8_t* p = bgr + (size_t)y * stride + 3 * (size_t)x;
+                    p[0] = 255; p[1] = g0; p[2] = r0;
+                }
+        }
+        for (int s2 = 0; s2 < n_specks[L]; s2++) {
+            int x = rng_range(&dn, 1, w - 3), y = rng_range(&dn, 1, h - 3), npx = rng_range(&dn, 1, 3);
+            uint8_t g0 = (uint8_t)rng_range(&dn, 160, 220), r0 = (uint8_t)rng_range(&dn, 0, 60);
+            static const int sx[3] = {0, 1, 0}, sy[3] = {0, 0, 1};
+            for (int k = 0; k < npx; k++) {
+                uint8_t* p = bgr + (size_t)(y + sy[k]) * stride + 3 * (size_t)(x + sx[k]);
+                p[0] = 255; p[1] = g0; p[2] = r0;
+            }
         }
     }
 

@@ -33,4 +33,4 @@ st = ctx.counts()["status"]
 for f in range(4):
     ref = O.detect_frame(frames[f])
     assert arm[offs[f]:offs[f + 1]].tobytes() == ref["armours"].tobytes(), f
-print("variant ok; slow-path frames:", int(np.count_nonzero(st & 16)))
+print("variant ok; slow-path frames:", int(np.count_nonzero(st & 16)), "mid-tier frames:", int(np.count_nonzero(st & 64)))

@@ -13,7 +13,7 @@ import pytest
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,n", [(1920, 1200, 6), (1280, 1024, 3), (1984, 1210, 2), (1000, 700, 2), (64, 40, 5)])
+@pytest.mark.parametrize("w,h,n", [(1920, 1200, 6), (1280, 1024, 3), (1984, 1210, 2), (1000, 700, 2), (64, 64, 5)])
 def test_no_store_outside_the_buffers(oracle, w, h, n):
     from rmcv_amd import CAMP_RED, MORPH_DILATE, STAGE_ALL, STAGE_BINARY, STAGE_IDENTITY, Context, default_params, synth
     ctx = Context(device=0, max_frames=n, max_width=w, max_height=h)     # sized EXACTLY: the last frame ends at the rear guards

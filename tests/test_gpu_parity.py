@@ -59,7 +59,7 @@ def test_full_path_synthetic(ctx, oracle, variant):
     ctx.sync()
     arm, aoffs = ctx.armours()
     cnt = ctx.counts()
-    assert not cnt["status"].any() or set(np.unique(cnt["status"])) <= {0, 16}
+    assert not cnt["status"].any()            # the synthetic streams stay on the LDS tables: neither the mid tier nor the sequential scanner
     for f in range(n):
         ref = oracle.detect_frame(frames[f], oracle.default_params())
         assert np.array_equal(ctx.binary(f), ref["binary"]), f
@@ -337,8 +337,8 @@ def test_sparse_kernel_with_four_wavefronts(oracle):
             blobs, _ = c.blobs(f)
             assert blobs.tobytes() == ref["blobs"].tobytes(), f
             assert arm[aoffs[f]:aoffs[f + 1]].tobytes() == ref["armours"].tobytes(), f
-    # nested shapes (a blob inside a hole is dropped by RETR_EXTERNAL) stay on the cycle path; 23 1-px lines of 100 pixels (more
-    # than 4096 border visits) take the literal fallback inside the 4-wavefront workgroup
+    # nested shapes (a blob inside a hole is dropped by RETR_EXTERNAL) stay on the LDS tables; 23 1-px lines of 100 pixels (more
+    # than 4096 border visits) take the mid tier inside the 4-wavefront workgroup
     img = np.zeros((2, 256, 256, 3), np.uint8)
     img[0, 40:200, 40:200] = (255, 0, 0)
     img[0, 80:160, 80:160] = 0
@@ -356,7 +356,7 @@ def test_sparse_kernel_with_four_wavefronts(oracle):
         pts, offs = c.contours(f)
         assert np.array_equal(offs, ro) and np.array_equal(pts, rp), f
     st = c.counts()["status"]
-    assert st[0] == 0 and (st[1] & 16) and len(c.contours(0)[1]) - 1 == 1
+    assert st[0] == 0 and st[1] == 64 and len(c.contours(0)[1]) - 1 == 1
     c.close()
 
 
@@ -435,8 +435,9 @@ def test_c5_geometry_every_frame(oracle):
 
 
 def test_cycle_formulation_paths(oracle):
-    """which path findContours takes: thin lines / diagonals / spurs (pixels visited twice or -- up to 32 per frame -- three times) stay on the cycle path (status 0); more such junctions or a frame with more than 4096 border visits goes to the
-    literal scanner (status bit 16); the results are equal either way"""
+    """which path findContours takes: thin lines / diagonals / spurs (pixels visited twice or -- up to 32 per frame -- three times) stay on
+    the LDS tables (status 0); more such junctions, more than 4096 border visits or more than 512 contours take the mid tier
+    (status bit 64: tables in global memory, never the sequential scanner); the results are equal either way"""
     from rmcv_amd import Context
     c = Context(device=0, max_frames=1, max_width=512, max_height=512, max_contours=16384, max_points=1 << 17)
 
@@ -472,19 +473,19 @@ def test_cycle_formulation_paths(oracle):
             b[cy - i, cx - i] = b[cy - i, cx + i] = b[cy + i, cx] = 255
         b[cy, cx] = 255
     st, n, _ = run(b)
-    assert st & 16 and n == 40
+    assert st == 64 and n == 40
     d = np.zeros((300, 300), np.uint8)
     for r in range(22):
         d[4 + 3 * r, 10:110] = 255                         # 22 lines of 100 pixels = 22 x 198 = 4356 visits: more than 4096
     st, n, _ = run(d)
-    assert st & 16 and n == 22
+    assert st == 64 and n == 22
     d[4 + 3 * 20:4 + 3 * 22, :] = 0                        # 20 lines = 3960 visits fit
     st, n, npts = run(d)
     assert st == 0 and n == 20 and npts == 20 * 198
     e = np.zeros((300, 300), np.uint8)
     e[::3, ::3] = 255                                      # 10 000 isolated pixels again, but > SLOT capacity as well
     st, n, _ = run(e)
-    assert n == 10000
+    assert st == 64 and n == 10000
     c.close()
 
 
