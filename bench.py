@@ -47,7 +47,11 @@ def parse_args(argv=None):
     ap.add_argument("--warmup-seconds", type=float, default=0.4,
                     help="besides --warmup steps: untimed steps for at least this long, so the clocks have ramped before the timed region")
     ap.add_argument("--frames", type=int, default=FRAMES, help="frames per GPU per step")
-    ap.add_argument("--variant", type=int, default=0, help="0 plain stream, 1 stress stream")
+    ap.add_argument("--variant", type=variant_id, default=0,
+                    help="synthetic stream: plain (0, the metric's), stress (1), dense1..dense4 (11..14; dense = dense4: +2000 specks and 13 "
+                         "bright windows per frame, 5 %% foreground -- frames beyond findContours' LDS tables; a workload beside the metric)")
+    ap.add_argument("--density-sweep", action="store_true",
+                    help="after the run: steady-state step time on every density level (plain, dense1..dense4), printed as `density_sweep`")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames per pass of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 (binary only) side measurements")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
@@ -69,6 +73,13 @@ def parse_args(argv=None):
                          "build) or rmcv_gather, the C-ABI entry point that calls RCCL itself (what a C++ host uses; the default for a "
                          "launched single rank, where it moves nothing)")
     return ap.parse_args(argv)
+
+
+VARIANTS = {"plain": 0, "stress": 1, "dense1": 11, "dense2": 12, "dense3": 13, "dense4": 14, "dense": 14}
+
+
+def variant_id(v):
+    return VARIANTS[v] if v in VARIANTS else int(v)
 
 
 def free_port():
@@ -160,7 +171,9 @@ def main():
     # Steps are double-buffered over `--streams` contexts (own work buffers, own HIP stream, same resident
     # frames): while the sparse stages of step i (contours, fits, pairing: latency-bound, a few waves per CU) run,
     # the HBM-bound pixel kernel of step i+1 streams -- what a continuous camera feed would do.
-    ctxs = [Context(device=local_rank, max_frames=n, max_width=W, max_height=H) for _ in range(ns)]
+    # (the dense streams have up to ~2100 contours per frame: beyond the default limit of 2048)
+    ctxs = [Context(device=local_rank, max_frames=n, max_width=W, max_height=H, max_contours=(4096 if args.variant >= 10 or args.density_sweep else 2048))
+            for _ in range(ns)]
     stages = STAGE_ALL | (STAGE_IDENTITY if args.workload == "c5" else 0) | (STAGE_POSE if args.pose else 0)
     if os.environ.get("RMCV_BENCH_STAGES"):                      # dev knob (tools/ab_streams.sh): a partial path is NOT the metric
         stages = int(os.environ["RMCV_BENCH_STAGES"])
@@ -343,6 +356,8 @@ def main():
     # ---- what was computed (outside the timed region): status + gathered list sanity
     cnt = ctx.counts()
     bad = int(np.count_nonzero(cnt["status"] & 15))
+    slow = int(np.count_nonzero(cnt["status"] & 16))              # frames findContours handed to the sequential scanner
+    mid = int(np.count_nonzero(cnt["status"] & 64))               # frames beyond the LDS tables: mid tier (tables in global memory)
     n_arm_local = int(cnt["n_armours"].sum())
     gathered = None
     if rank == 0:
@@ -447,6 +462,7 @@ def main():
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
                    "double_buffered_steps": ns, "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "pixel_groups_per_cu": 2 if ns >= 2 else 3, "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("software pipeline: pixel kernels alternate over %d streams, sparse stages on %d higher-priority streams, chained by events" % (len(sAs), len(sBs)) if pipelined else "alternating streams"),
                    "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad,
+                   "frames_slow_path": slow, "frames_mid_tier": mid,
                    "rccl_ranks": (dist.get_world_size() if use_dist else None), "gather": gather_note},
         "lone_batch_ms": {"median": round(lone[len(lone) // 2], 4), "min": round(lone[0], 4), "passes": len(lone),
                           "note": "one batch at a time on one stream, events around detect + compaction (latency, not the metric)"},
@@ -497,6 +513,40 @@ def main():
             out["detect_only_no_image"] = {"fps": round(n / d3, 1), "ms_per_step": round(d3 * 1e3, 4), "bytes_per_frame": 3 * W * H,
                                            "hbm_frac": round(n * 3 * W * H / d3 / 1e9 / HBM_PEAK_GBS, 4),
                                            "note": "same armour lists; the 0/255 image is not materialised"}
+
+    if args.density_sweep and world == 1:
+        # ---- throughput against scene density (beside the metric): the same pipelined loop on the plain stream, the four dense
+        # levels, and a plain batch with ONE dense4 frame in it (a camera frame with a lit window must not stall its launch)
+        sweep = []
+        region = max(100, 5 * args.steps)
+        for label, var, one in [("plain", 0, False), ("dense1", 11, False), ("dense2", 12, False), ("dense3", 13, False),
+                                ("dense4", 14, False), ("plain + one dense4 frame per batch", 0, True)]:
+            for k in range(ns):
+                hb = synth.batch(rank * n + k * 1000003, n, W, H, CAMP_BLUE, var, threads=nthreads)
+                if one:
+                    hb[n // 2] = synth.frame(rank * n + k * 1000003 + n // 2, W, H, CAMP_BLUE, 14)
+                frames_k[k].copy_(torch.from_numpy(hb))
+            torch.cuda.synchronize()
+            for _ in range(20):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(region):
+                step()
+            barrier()
+            dsw = (time.perf_counter() - t0) / region
+            st_ = ctx.counts()["status"]
+            cnt_ = ctx.counts()
+            sweep.append({"stream": label, "ms_per_step": round(dsw * 1e3, 4), "frames_per_s": round(n / dsw, 1),
+                          "contours_per_frame": round(float(cnt_["n_contours"].mean()), 1),
+                          "points_per_frame": round(float(cnt_["n_points"].mean()), 1),
+                          "frames_mid_tier": int(np.count_nonzero(st_ & 64)), "frames_slow_path": int(np.count_nonzero(st_ & 16)),
+                          "frames_over_capacity": int(np.count_nonzero(st_ & 15))})
+        out["density_sweep"] = {"steps_per_region": region, "levels": sweep,
+                                "note": "steady-state regions of the bench's own loop (4 batches in flight), rank-0 shard; not the metric"}
+        for k in range(ns):                                        # back to the run's own stream for what follows
+            frames_k[k].copy_(torch.from_numpy(host if k == 0 else synth.batch(rank * n + k * 1000003, n, W, H, CAMP_BLUE, args.variant, threads=nthreads)))
+        torch.cuda.synchronize()
 
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- the per-frame drop-in path (outside the timed region): the three C-ABI calls exactly as include/rmcv_shim.hpp issues
@@ -606,6 +656,21 @@ def main():
                                          "sample": "%d passes over all %d frames of the batch (%.1f s), one frame per task, %d threads (capped at "
                                                    "the 16-core share of a one-GPU box)" % (passes_all, n, dall, cores),
                                          "armours": tot_all}
+        # ... and with EVERY hardware thread the host shows (SURVEY 8d asks for all cores; a one-GPU box's share is 16, so this
+        # figure is what the whole host could do for one tenant, not what this tenant's quota sustains)
+        every = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if every > cores:
+            t0 = time.perf_counter()
+            passes_ev = 0
+            with ThreadPoolExecutor(every) as ex:
+                while passes_ev < 256 and (passes_ev == 0 or time.perf_counter() - t0 < 5.0):
+                    tot_ev = sum(ex.map(one, range(n)))
+                    passes_ev += 1
+            dev_ = time.perf_counter() - t0
+            out["cpu_baseline_every_hw_thread"] = {"value": round(passes_ev * n / dev_, 2), "unit": "frames/s", "cores": every, "kind": "port",
+                                                   "sample": "%d passes over all %d frames of the batch (%.1f s), one frame per task, %d threads = "
+                                                             "every hardware thread the host shows" % (passes_ev, n, dev_, every),
+                                                   "armours": tot_ev}
     if rank == 0:
         print(json.dumps(out), flush=True)
     for g_ in (abi_gathers or []):
