@@ -146,7 +146,7 @@ def main():
     import torch.distributed as dist
 
     from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_ARMOURS, STAGE_BINARY, STAGE_BLOBS,
-                          STAGE_IDENTITY, STAGE_NO_IMAGE, STAGE_POSE, OPT_PIXEL_GROUPS, OPT_SPARSE_WAVES, Context, LegacyParams, default_params, synth)
+                          STAGE_HANDOVER, STAGE_IDENTITY, STAGE_NO_IMAGE, STAGE_POSE, OPT_HANDOVER, OPT_PIXEL_GROUPS, OPT_SPARSE_WAVES, Context, LegacyParams, default_params, synth)
     from rmcv_amd import dist as rdist
 
     if not torch.cuda.is_available():
@@ -254,6 +254,10 @@ def main():
     ev_bin = [torch.cuda.Event() for _ in range(ns)]
     ev_done = [torch.cuda.Event() for _ in range(ns)]
     pipelined = args.mode == "pipeline" and ns > 1
+    handover = os.environ.get("RMCV_BENCH_HANDOVER", "1") != "0"   # dev knob for A/B runs
+    if not handover:
+        for c in ctxs:
+            c.set_option(OPT_HANDOVER, 0)
 
     cur_stages = [stages]
 
@@ -276,8 +280,13 @@ def main():
             ev_bin[k].record(sA)
         sB = sBs[k % len(sBs)]
         with torch.cuda.stream(sB):
-            sB.wait_event(ev_bin[k])
-            run_path(ctxs[k], cur_stages[0] & ~(STAGE_BINARY | STAGE_NO_IMAGE), sB.cuda_stream)
+            if handover:
+                # frame-level hand-over: the sparse kernel is enqueued beside its own pixel kernel and takes each frame when its last
+                # strip is written (RMCV_STAGE_HANDOVER: the library orders it after what preceded that pixel kernel, not after it)
+                run_path(ctxs[k], (cur_stages[0] & ~(STAGE_BINARY | STAGE_NO_IMAGE)) | STAGE_HANDOVER, sB.cuda_stream)
+            else:
+                sB.wait_event(ev_bin[k])
+                run_path(ctxs[k], cur_stages[0] & ~(STAGE_BINARY | STAGE_NO_IMAGE), sB.cuda_stream)
             if abi_gathers and not first_use:
                 sB.wait_event(ev_gath[k])                  # the record is rewritten: its previous gather (ns steps back) must be through
             if works[k] is not None:
@@ -463,7 +472,8 @@ def main():
                    "double_buffered_steps": ns, "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "pixel_groups_per_cu": 2 if ns >= 2 else 3, "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("software pipeline: pixel kernels alternate over %d streams, sparse stages on %d higher-priority streams, chained by events" % (len(sAs), len(sBs)) if pipelined else "alternating streams"),
                    "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad,
                    "frames_slow_path": slow, "frames_mid_tier": mid,
-                   "rccl_ranks": (dist.get_world_size() if use_dist else None), "gather": gather_note},
+                   "rccl_ranks": (dist.get_world_size() if use_dist else None), "gather": gather_note,
+                   "frame_level_handover": handover},
         "lone_batch_ms": {"median": round(lone[len(lone) // 2], 4), "min": round(lone[0], 4), "passes": len(lone),
                           "note": "one batch at a time on one stream, events around detect + compaction (latency, not the metric)"},
         "path_hbm_frac": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),

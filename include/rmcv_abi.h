@@ -107,6 +107,10 @@ typedef struct {            /* capacities of one context; 0 = default */
                                  src/imgproc.cpp:9-35, src/core.cpp:202-216, executable/main.cpp:180-181; needs rmcv_svm_load */
 
 /* per-frame status bits reported by rmcv_batch_counts */
+#define RMCV_STAGE_HANDOVER 128 /* modifier of a run WITHOUT RMCV_STAGE_BINARY: the pixel kernel of this batch has been ENQUEUED (an
+                                 * earlier rmcv_batch_run(..., RMCV_STAGE_BINARY, other_stream) on this context) and may still be running --
+                                 * do not wait for it as a whole; the sparse kernel takes each frame when its rows are complete
+                                 * (frame-level hand-over).  A full run handed ONE stream does the same by itself on a side stream. */
 #define RMCV_FRAME_OVF_CONTOURS 1
 #define RMCV_FRAME_OVF_POINTS 2
 #define RMCV_FRAME_OVF_BLOBS 4
@@ -116,6 +120,8 @@ typedef struct {            /* capacities of one context; 0 = default */
 #define RMCV_FRAME_MID_PATH 64  /* informational: findContours of this frame ran on the mid tier (tables in global memory: the frame is
                                  * beyond the LDS tables -- > 4096 border visits, > 1024 non-empty words, > 512 contours -- but was not
                                  * handed to the sequential scanner) */
+#define RMCV_FRAME_TIMEOUT 128  /* error: the frame's bit plane never arrived (frame-level hand-over: the pixel kernel this run was told
+                                 * to wait for did not run) */
 #define RMCV_FRAME_HULL 32      /* legacy matcher: a contour exceeded the hull tables (dimensions > 4096) or is not a closed border */
 
 typedef struct rmcv_ctx rmcv_ctx;
@@ -155,6 +161,9 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * RMCV_FRAME_SLOW_PATH); 1: the sequential scanner for every frame; 2: the mid tier for every frame.  A test / diagnosis knob:
  * results are identical. */
 #define RMCV_OPT_CONTOUR_TIER 5
+/* RMCV_OPT_HANDOVER: 1 (default): the per-frame sparse kernel of a batch runs beside the batch's own pixel kernel and takes each
+ * frame as soon as its last strip is written; 0: it starts when the whole pixel kernel is through.  Results are identical. */
+#define RMCV_OPT_HANDOVER 6
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */

@@ -35,7 +35,9 @@ OPT_PIXEL_GROUPS = 2
 OPT_FRAME_UPLOAD = 3
 OPT_RUN_AHEAD = 4
 OPT_CONTOUR_TIER = 5
+OPT_HANDOVER = 6
 STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE, STAGE_NO_IMAGE = 1, 2, 4, 8, 15, 16, 32, 64
+STAGE_HANDOVER = 128
 SVM_FEATURES = 1200
 FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_SLOW_PATH, FRAME_MID_PATH = 1, 2, 4, 8, 16, 64
 

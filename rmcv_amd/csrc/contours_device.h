@@ -251,6 +251,7 @@ struct ContoursLds {
     int nmulti;
     uint8_t kacc[KEPT_CAP]; // cycles_frame: outer border e is (still) accepted by the RETR_EXTERNAL rule
     int revoked;            // ... some acceptance was revoked in this round
+    int cur_ok;   // frame-level hand-over: the frame's planes arrived
     int wnext;    // fused tail: next entry of the sorted work list
     int sink[64]; // per-lane sinks: lanes != 0 add 0 here so that a wave-wide atomic stays convergent and does not serialise on one word
 };

@@ -44,6 +44,7 @@ namespace rmcv {
 #define RMCV_K1_LDAUX 2 // cache-policy bits of the frame loads that no other workgroup shares (2 = nt)
 #endif
 static constexpr int SR = RMCV_SR; // strip rows per workgroup
+static_assert(SR == STRIP_ROWS, "the sparse kernel's frame queues assume k_binary's strip height (rmcv_internal.h)");
 
 __device__ __forceinline__ uint32_t expand4(uint32_t nib)
 { // 4 mask bits -> 4 bytes of 0x00/0xFF
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
-                                                 int* __restrict__ strip_ctr, int taper_head, int taper_tail)
+                                                 int* __restrict__ strip_ctr, int taper_head, int taper_tail,
+                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq)
 {
     extern __shared__ uint64_t smem[];
 #ifdef RMCV_K1_PRIO
@@ -132,10 +134,26 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     __shared__ uint64_t s_lut[256];
     __shared__ uint16_t s_spare[256]; // where a lane without a place in the plane writes (no write sits behind a branch)
     if (FAST) s_lut[tid] = (uint64_t)expand4(tid) | ((uint64_t)expand4(tid >> 4) << 32);
+    // Frame-level hand-over to the sparse kernel (which may run beside this launch, rmcv_host.hip): when a strip's plane words and
+    // row masks are stored, its rows are added to frame_ready[f] under this launch's label; a frame whose word reads (seq, h) is
+    // complete.  Published after the barrier at the top of the NEXT iteration (every wave's stores are then acknowledged), by one
+    // thread: a release fence at agent scope, then the add.  A word that still carries an older label is restarted, so the words
+    // need no reset between launches and no host-side mirror.
+    int pub_f = -1, pub_rows = 0;
     for (;;) {
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
     __syncthreads(); // also: the LDS planes of the previous strip are free
+    if (frame_ready && pub_f >= 0 && tid == 0) {
+        __threadfence();
+        unsigned long long* wd = frame_ready + pub_f;
+        unsigned long long old = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            const unsigned long long nw = (uint32_t)(old >> 32) == seq ? old + (unsigned)pub_rows : (((unsigned long long)seq << 32) | (unsigned)pub_rows);
+            if (__hip_atomic_compare_exchange_strong(wd, &old, nw, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+    }
+    pub_f = -1;
     // Every launch finds the heads at 0: the workgroup that leaves last zeroes them (below), so there is no memset per step
     // and no host-side mirror of device state that a failed or foreign launch could put out of step.
     // Tapered queue: the first taper_head and the last taper_tail strips of an XCD's range are handed out as four 8-row
@@ -416,6 +434,8 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
             if (q >= wq) { q -= wq; s++; }
         }
     }
+    pub_f = f;
+    pub_rows = min(sr, h - y0);
     } // strip loop
     // Leaving: this workgroup has drawn its last index.  strip_ctr[8] counts the leavers; the last one of the launch knows that
     // nobody will draw again and zeroes the eight heads and the count for the next launch (launches of one context are ordered:
@@ -429,7 +449,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
 }
 
 template <int CA, int CB>
-static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, int groups, hipStream_t s)
+static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, int groups, uint32_t seq, hipStream_t s)
 {
     const int strips = (g.h + SR - 1) / SR;
     int lb = lower_bound, all_pass = 0;
@@ -476,7 +496,8 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
         }
 #define RMCV_K1_LAUNCH(F)                                                                                                          \
     launch(k_binary<CA, CB, F>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
-           morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail)
+           morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail,               \
+           b.frame_ready ? b.frame_ready + f0 : nullptr, seq)
         const hipError_t e = fast ? RMCV_K1_LAUNCH(true) : RMCV_K1_LAUNCH(false);
 #undef RMCV_K1_LAUNCH
         if (e != hipSuccess) return e;
@@ -484,12 +505,12 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     return hipSuccess;
 }
 
-hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s)
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, hipStream_t s)
 {
     // imgproc.cpp:56-65: GUIDELIGHT G-R; BLUE B-R; everything else (RED, NEUTRAL) R-B.  BGR byte order.
-    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, groups, s);
-    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, groups, s);
-    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, groups, s);
+    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, groups, seq, s);
+    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, groups, seq, s);
+    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, groups, seq, s);
 }
 
 // binary (0 / non-zero bytes) -> padded bit plane; used when a caller hands in its own binary image

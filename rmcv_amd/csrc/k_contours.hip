@@ -38,8 +38,14 @@ namespace rmcv {
 
 static_assert(sizeof(ContoursLds) >= (CT_THREADS_MAX / 64) * sizeof(WaveLds), "the fit rows reuse the contour tables");
 
-static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int waves, hipStream_t s)
+static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int waves, uint32_t wait_seq,
+                                    hipStream_t s)
 {
+    SparseSched Q;
+    Q.frame_ready = wait_seq ? b.frame_ready : nullptr;
+    Q.seq = wait_seq;
+    Q.order = b.frame_order;
+    const int grid = g.n_frames;
     static const int force_literal = getenv("RMCV_CONTOURS_LITERAL") ? atoi(getenv("RMCV_CONTOURS_LITERAL")) : 0; // dev/test knob
     static bool attr_set[MAX_DEVICES] = {}; // hipFuncSetAttribute applies to the current device only (a process may drive several)
     if (!attr_set[g.device]) {
@@ -49,22 +55,22 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
         attr_set[g.device] = true;
     }
     const int force = force_literal ? force_literal : g.contour_tier;
-    if (waves == 4) return launch_contours_w4(g, b, lim, X, force, s);
-    return launch(k_contours_w8, dim3(g.n_frames), dim3(512), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
+    if (waves == 4) return launch_contours_w4(g, b, lim, X, force, Q, grid, s);
+    return launch(k_contours_w8, dim3(grid), dim3(512), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
                        g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
                        lim.max_contours, lim.max_points, force, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy, b.mid, b.mid_stride,
-                       b.mid_slot_cap);
+                       b.mid_slot_cap, Q);
 }
 
-hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)
+hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, uint32_t wait_seq, hipStream_t s)
 {
     SparseTail X;
     memset(&X, 0, sizeof(X));
-    return launch_contours_x(g, b, lim, X, 8, s);
+    return launch_contours_x(g, b, lim, X, 8, wait_seq, s);
 }
 
 // findContours + filter_lightblobs (+ filter_armours) of every frame in ONE launch
-hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, int waves, hipStream_t s)
+hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, int waves, uint32_t wait_seq, hipStream_t s)
 {
     SparseTail X;
     memset(&X, 0, sizeof(X));
@@ -88,7 +94,7 @@ hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const 
     T.angle_diff_max = p.angle_diff_max;
     T.shear_max = p.shear_max;
     T.length_ratio_max = p.length_ratio_max;
-    return launch_contours_x(g, b, lim, X, waves, s);
+    return launch_contours_x(g, b, lim, X, waves, wait_seq, s);
 }
 
 // contours of every frame as CSR in findContours order (reverse discovery), for download

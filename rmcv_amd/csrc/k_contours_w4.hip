@@ -10,7 +10,8 @@ namespace rmcv {
 #undef KC_KERNEL
 #undef KC_THREADS
 
-hipError_t launch_contours_w4(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int force_literal, hipStream_t s)
+hipError_t launch_contours_w4(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int force_literal, const SparseSched& Q, int grid,
+                              hipStream_t s)
 {
     static bool attr_set[MAX_DEVICES] = {}; // hipFuncSetAttribute applies to the current device only (a process may drive several)
     if (!attr_set[g.device]) {
@@ -19,10 +20,10 @@ hipError_t launch_contours_w4(const Geom& g, const Bufs& b, const Limits& lim, c
         if (e != hipSuccess) return e;
         attr_set[g.device] = true;
     }
-    return launch(k_contours_w4, dim3(g.n_frames), dim3(256), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
+    return launch(k_contours_w4, dim3(grid), dim3(256), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
                        g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
                        lim.max_contours, lim.max_points, force_literal, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy, b.mid, b.mid_stride,
-                       b.mid_slot_cap);
+                       b.mid_slot_cap, Q);
 }
 
 } // namespace rmcv

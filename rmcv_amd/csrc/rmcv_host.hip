@@ -29,6 +29,7 @@ struct rmcv_ctx {
     int32_t* pack_offs = nullptr;
     hipStream_t last_stream = nullptr;
     int geom_w = -1, geom_h = -1; // geometry the planes were zeroed for
+    int order_n = -1, order_h = -1; // (n_frames, h) the frame order on the device was computed for
     hipEvent_t ev_order = nullptr; // recorded behind the work enqueued last: a call on ANOTHER stream first waits for it
     bool order_pending = false;
     // ---- per-frame drop-in path (rmcv_extract_color -> rmcv_filter_lightblobs -> rmcv_filter_armours, executable/main.cpp:172-176)
@@ -57,6 +58,13 @@ struct rmcv_ctx {
     struct ArParams { float angle_diff_max, shear_max, length_ratio_max; int enemy; } last_ar{};
     bool last_lb_valid = false, last_ar_valid = false; // what the previous frame's calls asked for
     bool ahead_lb = false, ahead_ar = false;           // this frame's extract_color has run them: headers + windows are in pinned memory
+    // Frame-level hand-over (k_binary -> the per-frame sparse kernel): the sparse kernel of a batch runs BESIDE the batch's own pixel
+    // kernel, on a side stream, and takes each frame when its last strip has been written.
+    int handover = 1;             // RMCV_OPT_HANDOVER
+    hipStream_t side = nullptr;   // the library's own second stream (full runs handed ONE stream are forked onto it and joined)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pre_binary = nullptr;
+    bool pre_binary_valid = false;
+    uint32_t binary_seq = 0;      // label of the last k_binary launch (the frame_ready words carry it)
     int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
     int pixel_groups = 3;         // RMCV_OPT_PIXEL_GROUPS
     char err[256] = {0};
@@ -145,6 +153,10 @@ void rmcv_ctx_destroy(rmcv_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_pre_binary) hipEventDestroy(c->ev_pre_binary);
     for (void* p : c->allocs) hipFree(p);
     if (c->own_frames) hipFree(c->own_frames);
     for (auto& r : c->registered) hipHostUnregister(const_cast<void*>(r.p));
@@ -183,6 +195,14 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pre_binary, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = the numerically lowest = the highest priority
+        e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi);
+    }
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         c->geom.device = device;
@@ -225,7 +245,10 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.armours, F * d.max_armours);
     if (e == hipSuccess) e = dalloc(c, &b.n_armours, F);
     if (e == hipSuccess) e = dalloc(c, &b.status, F);
+    if (e == hipSuccess) e = dalloc(c, &b.frame_order, F);
+    if (e == hipSuccess) e = dalloc(c, &b.frame_ready, F);
     if (e == hipSuccess) {
+        hipMemset(b.frame_ready, 0, F * sizeof(unsigned long long));
         hipMemset(b.strip_ctr, 0, 16 * sizeof(int));
         hipMemset(b.n_contours, 0, F * 4);
         hipMemset(b.n_points, 0, F * 4);
@@ -306,6 +329,45 @@ static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t
         c->geom_w = w;
         c->geom_h = h;
     }
+    if (c->order_n != n_frames || c->order_h != h) {
+        // The order in which the sparse kernel's workgroups take frames.  k_binary hands XCD q the strips [q * per_xcd, (q + 1) *
+        // per_xcd) in order, so XCD q completes the frames whose LAST strip lies in that range, one after the other; workgroups are
+        // dealt to the XCDs round-robin (workgroup b runs on XCD b & 7).  Round t therefore offers the t-th frame of every XCD's
+        // list; XCDs whose list is shorter leave holes that the remaining frames fill (any order is correct -- a workgroup waits
+        // for ITS frame; this one makes the waits short and the plane reads L2 hits).
+        const int strips = (h + STRIP_ROWS - 1) / STRIP_ROWS, per_xcd = (n_frames * strips + 7) >> 3;
+        std::vector<std::vector<int32_t>> lists(8);
+        for (int f = 0; f < n_frames; f++) lists[std::min(7, (f * strips + strips - 1) / per_xcd)].push_back(f);
+        std::vector<int32_t> order((size_t)n_frames, -1), rest;
+        size_t longest = 0;
+        for (auto& l : lists) longest = std::max(longest, l.size());
+        for (size_t t = 0; t < longest; t++)
+            for (int q = 0; q < 8; q++)
+                if (t < lists[q].size()) {
+                    const size_t b_ = t * 8 + q;
+                    if (b_ < (size_t)n_frames) order[b_] = lists[q][t];
+                    else rest.push_back(lists[q][t]);
+                }
+        // (slots t * 8 + q beyond n_frames -> `rest`; slots left empty by short lists take them in order)
+        size_t r = 0;
+        for (size_t b_ = 0; b_ < (size_t)n_frames; b_++)
+            if (order[b_] < 0) order[b_] = r < rest.size() ? rest[r++] : -1;
+        {   // slots of short lists that `rest` did not fill: whatever frames are still unassigned (keeps the map a bijection)
+            std::vector<char> used((size_t)n_frames, 0);
+            for (int32_t v : order) if (v >= 0) used[(size_t)v] = 1;
+            int nf = 0;
+            for (auto& v : order)
+                if (v < 0) {
+                    while (used[(size_t)nf]) nf++;
+                    v = nf;
+                    used[(size_t)nf] = 1;
+                }
+        }
+        { const int rcs = rmcv_batch_sync(c); if (rcs) return rcs; } // a batch of the previous shape may still be reading the old order
+        HIPCHK(c, hipMemcpy(c->bufs.frame_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice), "frame order");
+        c->order_n = n_frames;
+        c->order_h = h;
+    }
     return RMCV_OK;
 }
 
@@ -332,8 +394,15 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     const Bufs& b = c->bufs;
     int k = 0;
     resident_none(c);
-    int rc = order_begin(c, s);
-    if (rc) return rc;
+    const bool waits_per_frame = (stages & RMCV_STAGE_HANDOVER) != 0; // the caller enqueued this batch's pixel kernel elsewhere
+    stages &= ~RMCV_STAGE_HANDOVER;
+    int rc;
+    if (waits_per_frame) {
+        // everything this context did BEFORE that pixel kernel must be through; the pixel kernel itself need not be
+        if (!c->pre_binary_valid) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER without a preceding RMCV_STAGE_BINARY run");
+        if (stages & RMCV_STAGE_BINARY) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER goes with a run WITHOUT RMCV_STAGE_BINARY");
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_pre_binary, 0), "hand-over: wait for what preceded the pixel kernel");
+    } else if ((rc = order_begin(c, s))) return rc;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     // Status bits belong to the stage that sets them: k_contours rewrites the whole word; a run that starts at a later stage
     // clears only the bits of the stages it runs, so OVF_CONTOURS / OVF_POINTS / SLOW_PATH of the contour run it builds on survive.
@@ -342,14 +411,31 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
                         ((stages & RMCV_STAGE_ARMOURS) ? RMCV_FRAME_OVF_ARMOURS : 0);
         if (own) HIPCHK(c, launch_status_clear(g, b, own, s), "k_status_clear");
     }
-    if (stages & RMCV_STAGE_BINARY) HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, s), "k_binary");
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     // findContours + filter_lightblobs (+ filter_armours) as ONE per-frame kernel when the stages are asked for together;
     // the per-stage events of rmcv_batch_run_timed need per-stage launches (RMCV_FUSE_SPARSE=0: dev knob for A/B runs)
     static const bool fuse_ok = !(getenv("RMCV_FUSE_SPARSE") && atoi(getenv("RMCV_FUSE_SPARSE")) == 0);
     const bool one_sparse = fuse_ok && !timed && !lp && (stages & RMCV_STAGE_CONTOURS) && (stages & RMCV_STAGE_BLOBS);
-    if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, c->sparse_waves, s), "k_contours (fused)");
-    else if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
+    // A full run on ONE stream: the sparse kernel is forked onto the context's side stream, next to the pixel kernel, and joined
+    // back -- each frame's contours, fits and pairing start when the frame's last strip is written instead of the batch's.
+    const bool forked = one_sparse && c->handover && (stages & RMCV_STAGE_BINARY) && g.n_frames >= 4;
+    if (stages & RMCV_STAGE_BINARY) {
+        HIPCHK(c, hipEventRecord(c->ev_pre_binary, s), "hand-over: mark");
+        c->pre_binary_valid = true;
+        if (forked) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pre_binary, 0), "hand-over: fork");
+        c->binary_seq++;
+        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->binary_seq, s), "k_binary");
+    }
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
+    const bool per_frame = forked || (waits_per_frame && c->handover);
+    if (waits_per_frame && !c->handover) HIPCHK(c, hipStreamWaitEvent(s, c->ev_order, 0), "order: the pixel kernel"); // hand-over switched off: wait for the whole pixel kernel
+    const uint32_t wait_seq = per_frame ? c->binary_seq : 0;
+    hipStream_t ss = forked ? c->side : s;
+    if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, c->sparse_waves, wait_seq, ss), "k_contours (fused)");
+    else if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, wait_seq, s), "k_contours");
+    if (forked) {
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side), "hand-over: join");
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0), "hand-over: join");
+    }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     const bool fused = (stages & RMCV_STAGE_BLOBS) && (stages & RMCV_STAGE_ARMOURS); // one launch for both
     if (one_sparse) {
@@ -375,7 +461,7 @@ static int check_params(rmcv_ctx* c, const rmcv_params* p, int stages)
     if (!c) return RMCV_ERR_BAD_ARG;
     if (!p) return fail(c, RMCV_ERR_BAD_ARG, "null params");
     if (p->morph < RMCV_MORPH_NONE || p->morph > RMCV_MORPH_CLOSE) return fail(c, RMCV_ERR_BAD_ARG, "bad morph");
-    if (stages <= 0 || stages > (RMCV_STAGE_ALL | RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE | RMCV_STAGE_NO_IMAGE)) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
+    if (stages <= 0 || stages > (RMCV_STAGE_ALL | RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE | RMCV_STAGE_NO_IMAGE | RMCV_STAGE_HANDOVER)) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
     if (c->geom.n_frames <= 0 || !c->bufs.frames) {
         if (stages & RMCV_STAGE_BINARY) return fail(c, RMCV_ERR_BAD_ARG, "no frames bound");
     }
@@ -454,6 +540,10 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
     }
     if (option == RMCV_OPT_FRAME_UPLOAD && value >= 0 && value <= 2) {
         c->frame_upload = value;
+        return RMCV_OK;
+    }
+    if (option == RMCV_OPT_HANDOVER && (value == 0 || value == 1)) {
+        c->handover = value;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_CONTOUR_TIER && value >= 0 && value <= 2) {
@@ -586,6 +676,7 @@ int rmcv_batch_get_contours(rmcv_ctx* c, int frame, rmcv_point* pts_out, int pts
     HIPCHK(c, hipMemcpy(&total, c->pack_offs + nc, 4, hipMemcpyDeviceToHost), "D2H");
     if (n_contours) *n_contours = nc;
     if (n_points) *n_points = total;
+    if (st & RMCV_FRAME_TIMEOUT) return fail(c, RMCV_ERR_HIP, "frame-level hand-over timed out: the pixel kernel of this batch never delivered its planes");
     if (st & (RMCV_FRAME_OVF_CONTOURS | RMCV_FRAME_OVF_POINTS)) return fail(c, RMCV_ERR_CAPACITY, "context limits exceeded (max_contours/max_points)");
     if (nc > contours_cap || total > pts_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
     if (offs_out) HIPCHK(c, hipMemcpy(offs_out, c->pack_offs, (size_t)(nc + 1) * 4, hipMemcpyDeviceToHost), "D2H offs");
@@ -631,6 +722,8 @@ int rmcv_batch_get_armours(rmcv_ctx* c, rmcv_armour* armours_out, int cap, int32
     }
     if (frame_offs) frame_offs[nf] = (int32_t)total;
     if (n_total) *n_total = (int32_t)total;
+    for (int f = 0; f < nf; f++)
+        if (st[f] & RMCV_FRAME_TIMEOUT) return fail(c, RMCV_ERR_HIP, "frame-level hand-over timed out: the pixel kernel of this batch never delivered its planes");
     if (ovf) return fail(c, RMCV_ERR_CAPACITY, "context limits exceeded on at least one frame (see status)");
     if (total > cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
     if (armours_out && total) {
@@ -924,7 +1017,8 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     const Geom& g = c->geom;
     const Bufs& b = c->bufs;
     hipStream_t s = c->stream;
-    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, s), "k_binary");
+    c->binary_seq++;
+    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, c->binary_seq, s), "k_binary");
     // running ahead with both parameter sets known: the frame's whole sparse part is ONE kernel (the fused per-frame kernel of
     // the batch path: findContours, fits and pairing back to back), not three
     const bool fused_ahead = c->run_ahead && c->last_lb_valid && c->last_ar_valid && c->last_lb.enemy == c->last_ar.enemy;
@@ -940,9 +1034,9 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
         p.angle_diff_max = c->last_ar.angle_diff_max;
         p.shear_max = c->last_ar.shear_max;
         p.length_ratio_max = c->last_ar.length_ratio_max;
-        HIPCHK(c, launch_sparse(g, b, c->lim, p, true, 8, s), "k_contours (fused)");
+        HIPCHK(c, launch_sparse(g, b, c->lim, p, true, 8, 0, s), "k_contours (fused)");
     } else {
-        HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
+        HIPCHK(c, launch_contours(g, b, c->lim, 0, s), "k_contours");
     }
     HIPCHK(c, launch_pack_contours(g, b, c->lim, c->pack_pts, c->pack_offs, c->d_hdr, s), "k_pack_contours");
     HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");

@@ -28,6 +28,7 @@ struct Geom {
     int64_t plane_pitch; // words per frame = (h + 2) * prow
 };
 
+static constexpr int STRIP_ROWS = 32;   // rows of a k_binary strip (k_binary.hip: SR); the sparse kernel's frame queues follow its strip order
 static constexpr int VISIT_CAP = 4096; // border visits of one frame the contour stage holds in LDS (contours_device.h); more -> mid tier
 static constexpr int NN_MID = 1 << 17;   // border visits of one frame the mid tier holds (tables in global memory); more -> literal scanner
 static constexpr int CAND_MID = 1 << 15; // outer borders (before RETR_EXTERNAL drops the nested ones) the mid tier holds
@@ -75,6 +76,8 @@ struct Bufs {
     rmcv_armour* armours;  // [frame][max_armours]
     int32_t* n_armours;    // [frame]
     int32_t* status;       // [frame] RMCV_FRAME_* bits
+    int32_t* frame_order;  // [frame] the frames in k_binary's completion order, interleaved over the XCDs (SparseSched::order)
+    unsigned long long* frame_ready; // [frame] k_binary's per-frame progress word (SparseSched::frame_ready)
     // icon classifier (BASELINE config 5); allocated by rmcv_svm_load
     float* svm_w;          // [n_df][1200]
     double* svm_rho;       // [n_df]
@@ -86,6 +89,14 @@ struct Bufs {
     rmcv_pnp_config* pnp_cfg;
     double* base2gripper;  // [frame][16]
     double* poses;         // [frame][max_armours][9]  rvec | tvec | world position
+};
+
+// Frame-level hand-over from k_binary to the per-frame sparse kernel, and the order in which the latter's workgroups take frames.
+struct SparseSched {
+    const unsigned long long* frame_ready;  // [frame] (launch label << 32 | rows finished) written by k_binary; null: no hand-over --
+                                            // the planes are complete before this launch starts (stream order)
+    uint32_t seq;                           // the label of the k_binary launch whose planes this launch consumes
+    const int32_t* order;                   // [frame] workgroup b -> frame (Bufs::frame_order); null: identity
 };
 
 static constexpr int MAX_DEVICES = 64; // per-device launch state (hipFuncSetAttribute is per device) is kept in arrays of this size
@@ -111,10 +122,12 @@ inline hipError_t launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds
 // kernel launchers (each enqueues on `s` and returns the launch error)
 hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, const rmcv_legacy_params& lp,
                         int mode, bool with_frames, bool pairs, hipStream_t s);
-hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, int waves, hipStream_t s);
+// wait_seq != 0: frame-level hand-over -- the launch takes each frame when k_binary launch `wait_seq` has finished its rows
+hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, int waves, uint32_t wait_seq, hipStream_t s);
 hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
-hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s);
-hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
+// seq: the label this launch publishes its per-frame progress under (Bufs::frame_ready)
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, hipStream_t s);
+hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, uint32_t wait_seq, hipStream_t s);
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);

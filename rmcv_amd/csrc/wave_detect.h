@@ -530,6 +530,7 @@ struct SparseTail {
     FitTail T;
 };
 
-hipError_t launch_contours_w4(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int force_literal, hipStream_t s);
+hipError_t launch_contours_w4(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int force_literal, const SparseSched& Q, int grid,
+                              hipStream_t s);
 
 } // namespace rmcv

@@ -45,7 +45,7 @@ def test_dense_streams_full_batch_every_stage(oracle, level, waves):
     assert not (st & 15).any() and not (st & FRAME_SLOW_PATH).any()
     mid = int(np.count_nonzero(st & FRAME_MID_PATH))
     over = sum(1 for r in refs if len(r["offs"]) - 1 > 512)      # more contours than the LDS tier keeps: certainly beyond it
-    assert mid >= over and (level < 3 or mid == n) and (level > 1 or mid == 0)
+    assert mid >= over and (level < 3 or mid == n) and (level > 1 or mid < n // 4)
     c.close()
 
 
