@@ -116,7 +116,7 @@ def test_mid_tier_shapes(oracle):
     a[sp] = 255
     st, n = _check(c, a, oracle)
     assert st == FRAME_MID_PATH and n > 100
-    for density in (0.002, 0.02, 0.1):                       # salt at three densities (the densest: ~80 k border visits)
+    for density in (0.002, 0.01, 0.03):                      # salt at three densities (the densest: ~20 000 contours)
         e = ((rng.random((768, 1024)) < density) * 255).astype(np.uint8)
         st, n = _check(c, e, oracle)
         assert st == FRAME_MID_PATH, density
