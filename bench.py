@@ -443,7 +443,9 @@ def main():
     achieved = n * BYTES_PER_FRAME / (k1_ms * 1e-3) / 1e9
 
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "k_binary_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "k_binary_traffic_%s.json" % args.workload)   # per workload (frame size); c3's also under the old name
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "k_binary_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))

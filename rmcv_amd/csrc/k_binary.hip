@@ -103,9 +103,14 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
                                                  int* __restrict__ strip_ctr, int taper_head, int taper_tail,
-                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq)
+                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq, unsigned* started)
 {
     extern __shared__ uint64_t smem[];
+    // "this launch is RUNNING": the stream that carries the sparse kernel of the batch waits for this word (hipStreamWaitValue32,
+    // rmcv_host.hip) before it lets workgroups loose that spin for this launch's frames -- a spinning consumer must never be on
+    // the machine before its producer is (workgroups that wait for a kernel the dispatcher has not placed yet can keep it from
+    // being placed).  Every workgroup says so: whichever comes first.
+    if (started && threadIdx.x == 0) __hip_atomic_store(started, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef RMCV_K1_PRIO
     __builtin_amdgcn_s_setprio(RMCV_K1_PRIO); // dev knob (A/B of issue priorities against the sparse kernel's)
 #endif
@@ -497,12 +502,23 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
 #define RMCV_K1_LAUNCH(F)                                                                                                          \
     launch(k_binary<CA, CB, F>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
            morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail,               \
-           b.frame_ready ? b.frame_ready + f0 : nullptr, seq)
+           b.frame_ready ? b.frame_ready + f0 : nullptr, seq, b.started)
         const hipError_t e = fast ? RMCV_K1_LAUNCH(true) : RMCV_K1_LAUNCH(false);
 #undef RMCV_K1_LAUNCH
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// number of launches launch_binary makes for this geometry (the 32-bit buffer extents bound a launch's frames)
+int binary_launches(const Geom& g, const Bufs& b)
+{
+    const bool aligned = (g.w % 64 == 0) && (g.stride % 16 == 0) && (g.frame_pitch % 16 == 0) && ((uintptr_t)b.frames % 16 == 0);
+    if (!aligned) return 1;
+    const int64_t lim = 0xFFFFF000ll;
+    const int64_t per_frame = std::max<int64_t>(std::max<int64_t>(g.frame_pitch, g.plane_pitch * 8), (int64_t)g.w * g.h);
+    const int chunk = (int)std::min<int64_t>(g.n_frames, std::max<int64_t>(1, (lim - 1) / per_frame));
+    return (g.n_frames + chunk - 1) / chunk;
 }
 
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, hipStream_t s)

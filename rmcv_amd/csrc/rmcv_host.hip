@@ -158,6 +158,7 @@ void rmcv_ctx_destroy(rmcv_ctx* c)
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->ev_pre_binary) hipEventDestroy(c->ev_pre_binary);
     for (void* p : c->allocs) hipFree(p);
+    if (c->bufs.started) hipFree(c->bufs.started);
     if (c->own_frames) hipFree(c->own_frames);
     for (auto& r : c->registered) hipHostUnregister(const_cast<void*>(r.p));
     for (void* h : {(void*)c->h_frame, (void*)c->h_hdr, (void*)c->h_pts, (void*)c->h_offs, (void*)c->h_blobs,
@@ -199,9 +200,14 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pre_binary, hipEventDisableTiming);
     if (e == hipSuccess) {
+        // NORMAL priority, on purpose.  The sparse kernel's workgroups may spin for frames of a pixel kernel that has not been
+        // dispatched yet; on a high-priority queue, workgroups of theirs that are still PENDING (a batch of more frames than CUs)
+        // keep the dispatcher from placing lower-priority workgroups -- the pixel kernel's -- and the two wait for each other until
+        // the spin times out (seen once, with 300 frames: tests/test_gpu_round2.py::test_armour_list_compaction...).
+        static const int side_prio = getenv("RMCV_SIDE_PRIO") ? atoi(getenv("RMCV_SIDE_PRIO")) : 0; // dev knob: -1 = high
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = the numerically lowest = the highest priority
-        e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi);
+        e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, side_prio < 0 ? hi : 0);
     }
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
@@ -247,6 +253,15 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.status, F);
     if (e == hipSuccess) e = dalloc(c, &b.frame_order, F);
     if (e == hipSuccess) e = dalloc(c, &b.frame_ready, F);
+    if (e == hipSuccess) { // the "pixel kernel is running" word a stream can wait on; without it there is no frame-level hand-over
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) can = 0;
+        if (can && hipExtMallocWithFlags((void**)&b.started, 8, hipMallocSignalMemory) == hipSuccess) {
+            if (hipMemset(b.started, 0, 8) != hipSuccess) { hipFree(b.started); b.started = nullptr; }
+        } else b.started = nullptr;
+        (void)hipGetLastError();
+        if (!b.started) c->handover = 0;
+    }
     if (e == hipSuccess) {
         hipMemset(b.frame_ready, 0, F * sizeof(unsigned long long));
         hipMemset(b.strip_ctr, 0, 16 * sizeof(int));
@@ -417,7 +432,10 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     const bool one_sparse = fuse_ok && !timed && !lp && (stages & RMCV_STAGE_CONTOURS) && (stages & RMCV_STAGE_BLOBS);
     // A full run on ONE stream: the sparse kernel is forked onto the context's side stream, next to the pixel kernel, and joined
     // back -- each frame's contours, fits and pairing start when the frame's last strip is written instead of the batch's.
-    const bool forked = one_sparse && c->handover && (stages & RMCV_STAGE_BINARY) && g.n_frames >= 4;
+    // (not when the pixel kernel takes several launches -- batches beyond the 32-bit buffer extents --: the word the sparse stream
+    // waits on says that the FIRST of them runs)
+    const bool can_hand_over = c->handover && binary_launches(g, b) == 1;
+    const bool forked = one_sparse && can_hand_over && (stages & RMCV_STAGE_BINARY) && g.n_frames >= 4;
     if (stages & RMCV_STAGE_BINARY) {
         HIPCHK(c, hipEventRecord(c->ev_pre_binary, s), "hand-over: mark");
         c->pre_binary_valid = true;
@@ -426,10 +444,12 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
         HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->binary_seq, s), "k_binary");
     }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
-    const bool per_frame = forked || (waits_per_frame && c->handover);
-    if (waits_per_frame && !c->handover) HIPCHK(c, hipStreamWaitEvent(s, c->ev_order, 0), "order: the pixel kernel"); // hand-over switched off: wait for the whole pixel kernel
+    const bool per_frame = forked || (waits_per_frame && can_hand_over);
+    if (waits_per_frame && !can_hand_over) HIPCHK(c, hipStreamWaitEvent(s, c->ev_order, 0), "order: the pixel kernel"); // hand-over off: wait for the whole pixel kernel
     const uint32_t wait_seq = per_frame ? c->binary_seq : 0;
     hipStream_t ss = forked ? c->side : s;
+    // the spinning consumer goes on the machine only once its producer is there (k_binary.hip: `started`)
+    if (per_frame) HIPCHK(c, hipStreamWaitValue32(ss, b.started, c->binary_seq, hipStreamWaitValueEq, 0xFFFFFFFFu), "hand-over: wait for the pixel kernel to start");
     if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, c->sparse_waves, wait_seq, ss), "k_contours (fused)");
     else if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, wait_seq, s), "k_contours");
     if (forked) {
@@ -543,7 +563,7 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         return RMCV_OK;
     }
     if (option == RMCV_OPT_HANDOVER && (value == 0 || value == 1)) {
-        c->handover = value;
+        c->handover = (value && c->bufs.started) ? 1 : 0; // (needs hipStreamWaitValue32 on signal memory; without it: always off)
         return RMCV_OK;
     }
     if (option == RMCV_OPT_CONTOUR_TIER && value >= 0 && value <= 2) {

@@ -78,6 +78,7 @@ struct Bufs {
     int32_t* status;       // [frame] RMCV_FRAME_* bits
     int32_t* frame_order;  // [frame] the frames in k_binary's completion order, interleaved over the XCDs (SparseSched::order)
     unsigned long long* frame_ready; // [frame] k_binary's per-frame progress word (SparseSched::frame_ready)
+    unsigned* started;     // signal memory: the label of the k_binary launch that has started running (hipStreamWaitValue32 target)
     // icon classifier (BASELINE config 5); allocated by rmcv_svm_load
     float* svm_w;          // [n_df][1200]
     double* svm_rho;       // [n_df]
@@ -128,6 +129,7 @@ hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream
 // seq: the label this launch publishes its per-frame progress under (Bufs::frame_ready)
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, hipStream_t s);
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, uint32_t wait_seq, hipStream_t s);
+int binary_launches(const Geom& g, const Bufs& b); // launches launch_binary makes for this geometry (> 1: no frame-level hand-over)
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);

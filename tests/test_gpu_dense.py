@@ -120,10 +120,10 @@ def test_mid_tier_shapes(oracle):
         e = ((rng.random((768, 1024)) < density) * 255).astype(np.uint8)
         st, n = _check(c, e, oracle)
         assert st == FRAME_MID_PATH, density
-    s = np.zeros((1500, 2000), np.uint8)                     # one serpentine border of > 60 000 points
-    for k in range(0, 1480, 8):
-        s[k:k + 4, 10:1990] = 255
-        s[k + 4:k + 8, (10 if (k // 8) % 2 else 1986):(14 if (k // 8) % 2 else 1990)] = 255
+    s = np.zeros((400, 600), np.uint8)                        # one serpentine border of ~55 000 points
+    for k in range(0, 380, 8):
+        s[k:k + 4, 10:590] = 255
+        s[k + 4:k + 8, (10 if (k // 8) % 2 else 586):(14 if (k // 8) % 2 else 590)] = 255
     st, n = _check(c, s, oracle)
     assert st == FRAME_MID_PATH and n == 1
     z = ((rng.random((1024, 1280)) < 0.35) * 255).astype(np.uint8)   # beyond the mid tier too (> 131072 visits): the last resort, still exact
