@@ -38,7 +38,9 @@ namespace rmcv {
 #define RMCV_K1_STAUX 2 // cache-policy bits of the byte-image stores (2 = nt)
 #endif
 #ifndef RMCV_K1_PLAUX
-#define RMCV_K1_PLAUX 0 // cache-policy bits of the bit-plane stores (the sparse kernel of the same batch reads them back)
+#define RMCV_K1_PLAUX 16 // cache-policy bits of the bit-plane stores: sc1 = written through to the agent-coherent level, so that the
+                         // sparse kernel -- which may run BESIDE this launch, on another XCD with its own L2 -- sees a frame's words
+                         // as soon as the frame's progress word says so, without an L2 write-back (frame-level hand-over, below)
 #endif
 #ifndef RMCV_K1_LDAUX
 #define RMCV_K1_LDAUX 2 // cache-policy bits of the frame loads that no other workgroup shares (2 = nt)
@@ -142,20 +144,23 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     // Frame-level hand-over to the sparse kernel (which may run beside this launch, rmcv_host.hip): when a strip's plane words and
     // row masks are stored, its rows are added to frame_ready[f] under this launch's label; a frame whose word reads (seq, h) is
     // complete.  Published after the barrier at the top of the NEXT iteration (every wave's stores are then acknowledged), by one
-    // thread: a release fence at agent scope, then the add.  A word that still carries an older label is restarted, so the words
-    // need no reset between launches and no host-side mirror.
+    // thread.  A word that still carries an older label is restarted, so the words need no reset between launches and no
+    // host-side mirror.
     int pub_f = -1, pub_rows = 0;
     for (;;) {
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
     __syncthreads(); // also: the LDS planes of the previous strip are free
     if (frame_ready && pub_f >= 0 && tid == 0) {
-        __threadfence();
+        // No release FENCE here: at agent scope that is an L2 write-back (buffer_wbl2) -- per strip, 8192 times a launch, it made
+        // this kernel 12 x slower when first tried.  It is not needed either: the only data the consumer reads, the strip's plane
+        // words and row masks, are stored with sc1 (write-through to the agent-coherent level), every wave waited for its stores'
+        // acknowledgements before the barrier above, and the read-modify-write below is issued after it.
         unsigned long long* wd = frame_ready + pub_f;
         unsigned long long old = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (;;) {
             const unsigned long long nw = (uint32_t)(old >> 32) == seq ? old + (unsigned)pub_rows : (((unsigned long long)seq << 32) | (unsigned)pub_rows);
-            if (__hip_atomic_compare_exchange_strong(wd, &old, nw, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (__hip_atomic_compare_exchange_strong(wd, &old, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         }
     }
     pub_f = -1;
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     if (ww <= 32 && tid < sr && y0 + tid < h) {
         uint32_t m = 0;
         for (int k = 0; k < ww; k++) m |= (uint32_t)(R[(tid + halo) * ww + k] != 0) << k;
-        rowmask[(int64_t)f * h + y0 + tid] = m;
+        __hip_atomic_store(&rowmask[(int64_t)f * h + y0 + tid], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1, like the plane words)
     }
     // ---------------- phase 4: expand to bytes + bit plane
     if (FAST) {
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                         if (x < w) bin[(int64_t)y * w + x] = ((m >> p) & 1) ? 255 : 0;
                     }
                 }
-                if ((q & 3) == 0) plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)] = word;
+                if ((q & 3) == 0) __hip_atomic_store(&plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1)
             }
             s += dr;
             q += dq;

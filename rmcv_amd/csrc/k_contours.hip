@@ -70,7 +70,8 @@ hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, uint
 }
 
 // findContours + filter_lightblobs (+ filter_armours) of every frame in ONE launch
-hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, int waves, uint32_t wait_seq, hipStream_t s)
+hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, bool identity, int waves, uint32_t wait_seq,
+                         hipStream_t s)
 {
     SparseTail X;
     memset(&X, 0, sizeof(X));
@@ -94,6 +95,7 @@ hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const 
     T.angle_diff_max = p.angle_diff_max;
     T.shear_max = p.shear_max;
     T.length_ratio_max = p.length_ratio_max;
+    if (identity && pairs) X.C = classify_args(g, b);
     return launch_contours_x(g, b, lim, X, waves, wait_seq, s);
 }
 

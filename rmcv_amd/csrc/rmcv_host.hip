@@ -450,7 +450,10 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     hipStream_t ss = forked ? c->side : s;
     // the spinning consumer goes on the machine only once its producer is there (k_binary.hip: `started`)
     if (per_frame) HIPCHK(c, hipStreamWaitValue32(ss, b.started, c->binary_seq, hipStreamWaitValueEq, 0xFFFFFFFFu), "hand-over: wait for the pixel kernel to start");
-    if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, c->sparse_waves, wait_seq, ss), "k_contours (fused)");
+    if ((stages & RMCV_STAGE_IDENTITY) && !b.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
+    // the icon classifier rides in the per-frame kernel when the armours come from it (BASELINE config 5: no launch of its own)
+    const bool identity_fused = one_sparse && (stages & RMCV_STAGE_ARMOURS) && (stages & RMCV_STAGE_IDENTITY);
+    if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, identity_fused, c->sparse_waves, wait_seq, ss), "k_contours (fused)");
     else if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, wait_seq, s), "k_contours");
     if (forked) {
         HIPCHK(c, hipEventRecord(c->ev_join, c->side), "hand-over: join");
@@ -464,10 +467,7 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     else if (stages & RMCV_STAGE_BLOBS) HIPCHK(c, launch_blobs(g, b, c->lim, *p, s), "k_fit");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     if (!one_sparse && !fused && (stages & RMCV_STAGE_ARMOURS)) HIPCHK(c, launch_armours(g, b, c->lim, *p, s), "k_armours");
-    if (stages & RMCV_STAGE_IDENTITY) {
-        if (!b.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
-        HIPCHK(c, launch_classify(g, b, c->lim, s), "k_classify");
-    }
+    if ((stages & RMCV_STAGE_IDENTITY) && !identity_fused) HIPCHK(c, launch_classify(g, b, c->lim, s), "k_classify");
     if (stages & RMCV_STAGE_POSE) {
         if (!b.pnp_cfg) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_POSE needs rmcv_pnp_load first");
         HIPCHK(c, launch_pnp(g, b, c->lim, s), "k_pnp");
@@ -1054,7 +1054,7 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
         p.angle_diff_max = c->last_ar.angle_diff_max;
         p.shear_max = c->last_ar.shear_max;
         p.length_ratio_max = c->last_ar.length_ratio_max;
-        HIPCHK(c, launch_sparse(g, b, c->lim, p, true, 8, 0, s), "k_contours (fused)");
+        HIPCHK(c, launch_sparse(g, b, c->lim, p, true, false, 8, 0, s), "k_contours (fused)");
     } else {
         HIPCHK(c, launch_contours(g, b, c->lim, 0, s), "k_contours");
     }

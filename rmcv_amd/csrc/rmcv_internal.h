@@ -124,7 +124,9 @@ inline hipError_t launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds
 hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, const rmcv_legacy_params& lp,
                         int mode, bool with_frames, bool pairs, hipStream_t s);
 // wait_seq != 0: frame-level hand-over -- the launch takes each frame when k_binary launch `wait_seq` has finished its rows
-hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, int waves, uint32_t wait_seq, hipStream_t s);
+// identity: the frame's armours are classified by the same kernel (RMCV_STAGE_IDENTITY; needs pairs)
+hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, bool identity, int waves, uint32_t wait_seq,
+                         hipStream_t s);
 hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 // seq: the label this launch publishes its per-frame progress under (Bufs::frame_ready)
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, hipStream_t s);

@@ -2,6 +2,7 @@
 // stand-alone kernels of the stage-wise entry points) and k_contours.hip (the fused per-frame kernel): the ellipse fit of one
 // contour by one wavefront, the ordered compaction into the positive / negative lists and the pair loop.
 #pragma once
+#include "device_classify.h"
 #include "device_fit.h"
 #include "rmcv_internal.h"
 
@@ -528,6 +529,7 @@ struct SparseTail {
     FitGates G;
     rmcv_rrect* slot_ell;
     FitTail T;
+    ClassifyArgs C; // C.enabled: the frame's armours are classified by the same workgroup (RMCV_STAGE_IDENTITY)
 };
 
 hipError_t launch_contours_w4(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int force_literal, const SparseSched& Q, int grid,
