@@ -43,7 +43,7 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
 {
     SparseSched Q;
     Q.frame_ready = wait_seq ? b.frame_ready : nullptr;
-    Q.seq = wait_seq;
+    Q.target = (unsigned long long)wait_seq * (unsigned long long)g.h;
     Q.order = b.frame_order;
     const int grid = g.n_frames;
     static const int force_literal = getenv("RMCV_CONTOURS_LITERAL") ? atoi(getenv("RMCV_CONTOURS_LITERAL")) : 0; // dev/test knob

@@ -64,7 +64,8 @@ struct rmcv_ctx {
     hipStream_t side = nullptr;   // the library's own second stream (full runs handed ONE stream are forked onto it and joined)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pre_binary = nullptr;
     bool pre_binary_valid = false;
-    uint32_t binary_seq = 0;      // label of the last k_binary launch (the frame_ready words carry it)
+    uint32_t binary_seq = 0;      // k_binary launches since the geometry was bound (frame_ready words: launch L is through with a frame at L * h)
+    uint32_t launch_id = 0;       // k_binary launches of this context, never reset: the label the `started` word carries
     int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
     int pixel_groups = 3;         // RMCV_OPT_PIXEL_GROUPS
     char err[256] = {0};
@@ -92,7 +93,10 @@ static int fail(rmcv_ctx* c, int code, const char* what, hipError_t e = hipSucce
 // Every device buffer of a context lies between two GUARD-byte zones filled with a fixed pattern when the context is created;
 // rmcv_ctx_check_guards reads them back.  A kernel that stores one row, word or record past either end of its buffer -- the
 // partial last strip of a 1200-row frame, the ragged last block of a 1920-pixel row -- shows up there instead of in a neighbour.
-static constexpr size_t GUARD = 4096;
+#ifndef RMCV_GUARD
+#define RMCV_GUARD 4096
+#endif
+static constexpr size_t GUARD = RMCV_GUARD;
 static constexpr int GUARD_BYTE = 0xA5;
 template <typename T>
 static hipError_t dalloc_named(rmcv_ctx* c, T** p, size_t count, const char* name)
@@ -379,6 +383,10 @@ static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t
                 }
         }
         { const int rcs = rmcv_batch_sync(c); if (rcs) return rcs; } // a batch of the previous shape may still be reading the old order
+        // the progress words count rows since THIS binding: launch number L of the geometry is complete for a frame at L * h
+        HIPCHK(c, hipMemset(c->bufs.frame_ready, 0, (size_t)c->lim.max_frames * sizeof(unsigned long long)), "frame progress words");
+        c->binary_seq = 0;
+        c->pre_binary_valid = false;
         HIPCHK(c, hipMemcpy(c->bufs.frame_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice), "frame order");
         c->order_n = n_frames;
         c->order_h = h;
@@ -440,8 +448,9 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
         HIPCHK(c, hipEventRecord(c->ev_pre_binary, s), "hand-over: mark");
         c->pre_binary_valid = true;
         if (forked) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pre_binary, 0), "hand-over: fork");
+        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->launch_id + 1, s), "k_binary");
+        c->launch_id++;  // (counted once the launch is accepted: the device's words and these counters move together)
         c->binary_seq++;
-        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->binary_seq, s), "k_binary");
     }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     const bool per_frame = forked || (waits_per_frame && can_hand_over);
@@ -449,7 +458,7 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     const uint32_t wait_seq = per_frame ? c->binary_seq : 0;
     hipStream_t ss = forked ? c->side : s;
     // the spinning consumer goes on the machine only once its producer is there (k_binary.hip: `started`)
-    if (per_frame) HIPCHK(c, hipStreamWaitValue32(ss, b.started, c->binary_seq, hipStreamWaitValueEq, 0xFFFFFFFFu), "hand-over: wait for the pixel kernel to start");
+    if (per_frame) HIPCHK(c, hipStreamWaitValue32(ss, b.started, c->launch_id, hipStreamWaitValueEq, 0xFFFFFFFFu), "hand-over: wait for the pixel kernel to start");
     if ((stages & RMCV_STAGE_IDENTITY) && !b.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
     // the icon classifier rides in the per-frame kernel when the armours come from it (BASELINE config 5: no launch of its own)
     const bool identity_fused = one_sparse && (stages & RMCV_STAGE_ARMOURS) && (stages & RMCV_STAGE_IDENTITY);
@@ -1037,8 +1046,9 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     const Geom& g = c->geom;
     const Bufs& b = c->bufs;
     hipStream_t s = c->stream;
+    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, c->launch_id + 1, s), "k_binary");
+    c->launch_id++;
     c->binary_seq++;
-    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, c->binary_seq, s), "k_binary");
     // running ahead with both parameter sets known: the frame's whole sparse part is ONE kernel (the fused per-frame kernel of
     // the batch path: findContours, fits and pairing back to back), not three
     const bool fused_ahead = c->run_ahead && c->last_lb_valid && c->last_ar_valid && c->last_lb.enemy == c->last_ar.enemy;

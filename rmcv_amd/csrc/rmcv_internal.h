@@ -77,7 +77,7 @@ struct Bufs {
     int32_t* n_armours;    // [frame]
     int32_t* status;       // [frame] RMCV_FRAME_* bits
     int32_t* frame_order;  // [frame] the frames in k_binary's completion order, interleaved over the XCDs (SparseSched::order)
-    unsigned long long* frame_ready; // [frame] k_binary's per-frame progress word (SparseSched::frame_ready)
+    unsigned long long* frame_ready; // [frame] k_binary's per-frame progress: rows finished, summed over the launches since set_geom
     unsigned* started;     // signal memory: the label of the k_binary launch that has started running (hipStreamWaitValue32 target)
     // icon classifier (BASELINE config 5); allocated by rmcv_svm_load
     float* svm_w;          // [n_df][1200]
@@ -94,9 +94,9 @@ struct Bufs {
 
 // Frame-level hand-over from k_binary to the per-frame sparse kernel, and the order in which the latter's workgroups take frames.
 struct SparseSched {
-    const unsigned long long* frame_ready;  // [frame] (launch label << 32 | rows finished) written by k_binary; null: no hand-over --
-                                            // the planes are complete before this launch starts (stream order)
-    uint32_t seq;                           // the label of the k_binary launch whose planes this launch consumes
+    const unsigned long long* frame_ready;  // [frame] rows finished by all k_binary launches since the geometry was bound; null: no
+                                            // hand-over -- the planes are complete before this launch starts (stream order)
+    unsigned long long target;              // the value a frame's word has when the k_binary launch this launch consumes is through with it
     const int32_t* order;                   // [frame] workgroup b -> frame (Bufs::frame_order); null: identity
 };
 
