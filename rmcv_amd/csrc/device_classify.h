@@ -104,15 +104,18 @@ __device__ inline void classify_frame(int f, int lane, int wave, int nwaves, int
                                      {ic[0][0] - (float)bx, ic[0][1] - (float)by}};
             const float dst[3][2] = {{0, 0}, {(float)bw, 0}, {0, (float)bh}};
             LaneVec Am(lane), bv(lane);
-            { // row 2i: [x y 1 0 0 0], row 2i+1: [0 0 0 x y 1]
+            { // row 2i: [x y 1 0 0 0], row 2i+1: [0 0 0 x y 1]   (selects, not lane-dependent subscripts: those put the arrays in scratch memory)
                 const int r = lane / 6, c = lane - 6 * r, i = r >> 1;
+                const float sxi = i == 0 ? src[0][0] : (i == 1 ? src[1][0] : src[2][0]);
+                const float syi = i == 0 ? src[0][1] : (i == 1 ? src[1][1] : src[2][1]);
                 double v = 0.0;
                 if (lane < 36) {
                     const int cc = (r & 1) ? c - 3 : c;
-                    if (cc >= 0 && cc < 3) v = cc == 0 ? (double)src[i < 3 ? i : 0][0] : (cc == 1 ? (double)src[i < 3 ? i : 0][1] : 1.0);
+                    if (cc >= 0 && cc < 3) v = cc == 0 ? (double)sxi : (cc == 1 ? (double)syi : 1.0);
                 }
                 Am.reg = v;
-                bv.reg = lane < 6 ? (double)dst[(lane >> 1) < 3 ? (lane >> 1) : 0][lane & 1] : 0.0;
+                // b = (dst0.x, dst0.y, dst1.x, dst1.y, dst2.x, dst2.y) = (0, 0, bw, 0, 0, bh)
+                bv.reg = lane == 2 ? (double)dst[1][0] : (lane == 5 ? (double)dst[2][1] : 0.0);
             }
             bool ok = true;
             for (int i = 0; i < 6 && ok; i++) {

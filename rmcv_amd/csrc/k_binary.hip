@@ -113,6 +113,9 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     // the machine before its producer is (workgroups that wait for a kernel the dispatcher has not placed yet can keep it from
     // being placed).  Every workgroup says so: whichever comes first.
     if (started && threadIdx.x == 0) __hip_atomic_store(started, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef RMCV_PROFILE_HANDOVER
+    if (blockIdx.x == 0 && threadIdx.x == 0) printf("[kb start] %lld\n", (long long)wall_clock64());
+#endif
 #ifdef RMCV_K1_PRIO
     __builtin_amdgcn_s_setprio(RMCV_K1_PRIO); // dev knob (A/B of issue priorities against the sparse kernel's)
 #endif
@@ -453,6 +456,9 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
         if (tid == 0) left = atomicAdd(&strip_ctr[8], 1);
         left = __builtin_amdgcn_readfirstlane(left);
         if (left == (int)gridDim.x - 1 && tid < 9) atomicExch(&strip_ctr[tid], 0);
+#ifdef RMCV_PROFILE_HANDOVER
+        if (left == (int)gridDim.x - 1 && tid == 0) printf("[kb end] %lld\n", (long long)wall_clock64());
+#endif
     }
 }
 

@@ -5,6 +5,7 @@
 // rm::extract_color / rm::filter_lightblobs / rm::filter_armours (executable/main.cpp:172-176).
 // No CPU path exists here: every entry point enqueues hand-written HIP kernels.
 #include <math.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -417,6 +418,11 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     const Bufs& b = c->bufs;
     int k = 0;
     resident_none(c);
+    static const bool host_trace = getenv("RMCV_TRACE_HOST") && atoi(getenv("RMCV_TRACE_HOST")); // dev knob: host time of every enqueue below
+    static int host_trace_calls = 0;
+    double ht[12]; int hk = 0;
+    auto HT = [&]() { if (host_trace && hk < 12) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); ht[hk++] = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; } };
+    HT();
     const bool waits_per_frame = (stages & RMCV_STAGE_HANDOVER) != 0; // the caller enqueued this batch's pixel kernel elsewhere
     stages &= ~RMCV_STAGE_HANDOVER;
     int rc;
@@ -451,6 +457,7 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
         HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->launch_id + 1, s), "k_binary");
         c->launch_id++;  // (counted once the launch is accepted: the device's words and these counters move together)
         c->binary_seq++;
+        HT();
     }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     const bool per_frame = forked || (waits_per_frame && can_hand_over);
@@ -458,16 +465,21 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     const uint32_t wait_seq = per_frame ? c->binary_seq : 0;
     hipStream_t ss = forked ? c->side : s;
     // the spinning consumer goes on the machine only once its producer is there (k_binary.hip: `started`)
-    if (per_frame) HIPCHK(c, hipStreamWaitValue32(ss, b.started, c->launch_id, hipStreamWaitValueEq, 0xFFFFFFFFu), "hand-over: wait for the pixel kernel to start");
+    static const bool no_waitvalue = getenv("RMCV_NO_WAITVALUE") && atoi(getenv("RMCV_NO_WAITVALUE")); // dev knob (timing experiments only)
+    if (per_frame && !no_waitvalue) HIPCHK(c, hipStreamWaitValue32(ss, b.started, c->launch_id, hipStreamWaitValueEq, 0xFFFFFFFFu), "hand-over: wait for the pixel kernel to start");
     if ((stages & RMCV_STAGE_IDENTITY) && !b.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
     // the icon classifier rides in the per-frame kernel when the armours come from it (BASELINE config 5: no launch of its own)
     const bool identity_fused = one_sparse && (stages & RMCV_STAGE_ARMOURS) && (stages & RMCV_STAGE_IDENTITY);
     if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, identity_fused, c->sparse_waves, wait_seq, ss), "k_contours (fused)");
     else if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, wait_seq, s), "k_contours");
+    HT();
     if (forked) {
         HIPCHK(c, hipEventRecord(c->ev_join, c->side), "hand-over: join");
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0), "hand-over: join");
     }
+    HT();
+    if (host_trace && ++host_trace_calls % 8 == 0 && hk >= 4)
+        fprintf(stderr, "[rmcv host] run_stages: to k_binary enqueued %.1f us, to sparse enqueued %.1f us, join %.1f us (forked %d)\n", ht[1] - ht[0], ht[2] - ht[1], ht[3] - ht[2], (int)forked);
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     const bool fused = (stages & RMCV_STAGE_BLOBS) && (stages & RMCV_STAGE_ARMOURS); // one launch for both
     if (one_sparse) {
