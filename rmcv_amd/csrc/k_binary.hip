@@ -111,8 +111,10 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     // "this launch is RUNNING": the stream that carries the sparse kernel of the batch waits for this word (hipStreamWaitValue32,
     // rmcv_host.hip) before it lets workgroups loose that spin for this launch's frames -- a spinning consumer must never be on
     // the machine before its producer is (workgroups that wait for a kernel the dispatcher has not placed yet can keep it from
-    // being placed).  Every workgroup says so: whichever comes first.
-    if (started && threadIdx.x == 0) __hip_atomic_store(started, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // being placed).  ONE workgroup says so (the word lives in host-visible signal memory: when all 768 workgroups of a launch
+    // stored to it, the burst of system-scope stores held up the sparse kernel's own start by 0.2 us per store -- 60 / 108 / 175 us
+    // at 1 / 2 / 3 workgroups per CU); workgroup 0 is among the first the dispatcher places.
+    if (started && threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(started, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef RMCV_PROFILE_HANDOVER
     if (blockIdx.x == 0 && threadIdx.x == 0) printf("[kb start] %lld\n", (long long)wall_clock64());
 #endif

@@ -26,7 +26,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 
 import numpy as np
-for ho, g, w in ((1, 3, 4), (0, 3, 4), (1, 2, 8)):
+for ho, g, w in [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or ((1, 3, 4), (0, 3, 4), (1, 2, 8)):
     out = subprocess.run([sys.executable, __file__, "child", str(ho), str(g), str(w)], capture_output=True, text=True).stdout
     rep = out.split("== rep 3")[-1]
     kb0 = int(re.search(r"\[kb start\] (\d+)", rep).group(1))
