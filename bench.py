@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--variant", type=variant_id, default=0,
                     help="synthetic stream: plain (0, the metric's), stress (1), dense1..dense4 (11..14; dense = dense4: +2000 specks and 13 "
                          "bright windows per frame, 5 %% foreground -- frames beyond findContours' LDS tables; a workload beside the metric)")
+    ap.add_argument("--handover", action="store_true",
+                    help="frame-level hand-over: enqueue every step's sparse kernel beside its own pixel kernel (RMCV_STAGE_HANDOVER)")
     ap.add_argument("--density-sweep", action="store_true",
                     help="after the run: steady-state step time on every density level (plain, dense1..dense4), printed as `density_sweep`")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames per pass of the CPU-baseline sample (0 = skip)")
@@ -254,10 +256,11 @@ def main():
     ev_bin = [torch.cuda.Event() for _ in range(ns)]
     ev_done = [torch.cuda.Event() for _ in range(ns)]
     pipelined = args.mode == "pipeline" and ns > 1
-    handover = os.environ.get("RMCV_BENCH_HANDOVER", "1") != "0"   # dev knob for A/B runs
-    if not handover:
-        for c in ctxs:
-            c.set_option(OPT_HANDOVER, 0)
+    # frame-level hand-over (the sparse kernel beside its own pixel kernel): built, tested, measured equal on this schedule
+    # (tools/ab_vs_round2.sh: 0.2493 against 0.2502 ms per step, three alternating runs each) -- off unless asked for
+    handover = args.handover or os.environ.get("RMCV_BENCH_HANDOVER", "0") == "1"
+    for c in ctxs:
+        c.set_option(OPT_HANDOVER, 1 if handover else 0)
 
     cur_stages = [stages]
 

@@ -161,8 +161,10 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * RMCV_FRAME_SLOW_PATH); 1: the sequential scanner for every frame; 2: the mid tier for every frame.  A test / diagnosis knob:
  * results are identical. */
 #define RMCV_OPT_CONTOUR_TIER 5
-/* RMCV_OPT_HANDOVER: 1 (default): the per-frame sparse kernel of a batch runs beside the batch's own pixel kernel and takes each
- * frame as soon as its last strip is written; 0: it starts when the whole pixel kernel is through.  Results are identical. */
+/* RMCV_OPT_HANDOVER: 1: the per-frame sparse kernel of a batch runs beside the batch's own pixel kernel and takes each frame as
+ * soon as its last strip is written (full runs fork it onto a side stream of the context; RMCV_STAGE_HANDOVER is honoured);
+ * 0 (default): it starts when the whole pixel kernel is through (RMCV_STAGE_HANDOVER then simply waits for it).  Results are
+ * identical; so were the measured step rates, and a lone batch is slower with it -- see DESIGN.md.  Needs hipStreamWaitValue32. */
 #define RMCV_OPT_HANDOVER 6
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a

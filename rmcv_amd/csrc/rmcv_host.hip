@@ -61,7 +61,8 @@ struct rmcv_ctx {
     bool ahead_lb = false, ahead_ar = false;           // this frame's extract_color has run them: headers + windows are in pinned memory
     // Frame-level hand-over (k_binary -> the per-frame sparse kernel): the sparse kernel of a batch runs BESIDE the batch's own pixel
     // kernel, on a side stream, and takes each frame when its last strip has been written.
-    int handover = 1;             // RMCV_OPT_HANDOVER
+    int handover = 0;             // RMCV_OPT_HANDOVER (off by default: measured equal to the plain order on the pipelined bench and
+                                  // slower for a lone batch -- DESIGN.md section 5b)
     hipStream_t side = nullptr;   // the library's own second stream (full runs handed ONE stream are forked onto it and joined)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pre_binary = nullptr;
     bool pre_binary_valid = false;
@@ -265,7 +266,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
             if (hipMemset(b.started, 0, 8) != hipSuccess) { hipFree(b.started); b.started = nullptr; }
         } else b.started = nullptr;
         (void)hipGetLastError();
-        if (!b.started) c->handover = 0;
+        (void)0; // (without the word RMCV_OPT_HANDOVER = 1 is refused)
     }
     if (e == hipSuccess) {
         hipMemset(b.frame_ready, 0, F * sizeof(unsigned long long));
@@ -584,7 +585,8 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         return RMCV_OK;
     }
     if (option == RMCV_OPT_HANDOVER && (value == 0 || value == 1)) {
-        c->handover = (value && c->bufs.started) ? 1 : 0; // (needs hipStreamWaitValue32 on signal memory; without it: always off)
+        if (value && !c->bufs.started) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_OPT_HANDOVER needs hipStreamWaitValue32 on signal memory, which this device / runtime lacks");
+        c->handover = value;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_CONTOUR_TIER && value >= 0 && value <= 2) {

@@ -1,8 +1,8 @@
 """Frame-level hand-over: the per-frame sparse kernel of a batch runs BESIDE the batch's own pixel kernel and takes each frame
 when k_binary has written its last strip (per-frame progress words under a launch label, release/acquire at agent scope).
-A full run handed one stream is forked onto the context's side stream by the library (so the whole GPU suite exercises it); these
-tests drive the explicit form bench.py uses -- pixel kernel on one stream, sparse stages with RMCV_STAGE_HANDOVER on another,
-several batches in flight -- and the switch that turns it off."""
+Off by default (RMCV_OPT_HANDOVER: it measured equal on the pipelined bench and slower for a lone batch); these tests switch it on
+and drive both forms -- a full run handed one stream, which the library forks onto the context's side stream, and the explicit form
+bench.py --handover uses: pixel kernel on one stream, sparse stages with RMCV_STAGE_HANDOVER on another, several batches in flight."""
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -35,6 +35,7 @@ def test_pipelined_handover_equals_the_oracle(oracle, w, h, n):
     ctxs, frames = [], []
     for k in range(nctx):
         c = Context(device=0, max_frames=n, max_width=w, max_height=h)
+        c.set_option(OPT_HANDOVER, 1)
         c.set_option(OPT_SPARSE_WAVES, 4)
         c.set_option(OPT_PIXEL_GROUPS, 2)
         fr = synth.batch(4000 + 1000 * k, n, w, h, CAMP_BLUE, k % 2, threads=16)
@@ -90,6 +91,7 @@ def test_handover_off_and_on_agree():
 
 def test_handover_flag_needs_its_pixel_kernel():
     c = Context(device=0, max_frames=4, max_width=640, max_height=512)
+    c.set_option(OPT_HANDOVER, 1)
     c.upload(synth.batch(1, 4, 640, 512))
     with pytest.raises(RmcvError):
         c.run(default_params(), (STAGE_ALL & ~STAGE_BINARY) | STAGE_HANDOVER)       # no pixel kernel was ever enqueued on this context
