@@ -794,6 +794,13 @@ __device__ void cycles_frame_mid(ContoursLds& S, const MidTables& M, const uint6
                                  int max_points, int max_contours, int FL, int* nc_out, int* np_out)
 {
     const LabelStore LS = {S.rowmask, S.rowbase, nullptr, nullptr};
+#ifdef RMCV_PROFILE
+    long long tm_[12]; int tmi_ = 0;
+#define MSTAMP() do { __syncthreads(); if (tmi_ < 12) tm_[tmi_++] = wall_clock64(); } while (0)
+#else
+#define MSTAMP() do {} while (0)
+#endif
+    MSTAMP();
     for (int i = tid; i < 256; i += T) S.ringtab[i] = RINGTAB.v[i];
     if (tid == 0) { S.nnodes = 0; S.revoked = 0; }
     const int nslots = S.nslots;
@@ -815,49 +822,72 @@ __device__ void cycles_frame_mid(ContoursLds& S, const MidTables& M, const uint6
         }
     }
     __syncthreads();
+    // The loops below are LATENCY-bound: the tables live in global memory (L2 hits at best, ~1 us a round trip beside the streaming
+    // kernels) and one workgroup has few threads to hide that with.  So every loop handles U items per thread per trip, with all the
+    // loads of a dependency level issued before the first is used: a trip costs one round trip per LEVEL instead of one per item
+    // (first version, one item per trip: 700 us for a frame of 8 500 visits with 4 wavefronts).
     // ---- M1: per non-empty word: border pixels, pixels visited >= 2, >= 3, 4 times; node count
-    for (int slot = tid; slot < nslots; slot += T) {
-        const uint32_t sp = M.spos[slot];
-        const int y = sp & 2047, k = sp >> 11;
-        const int64_t base = (int64_t)(y + 1) * prow + 1;
-        const uint64_t mc = F[base + k];
-        const uint64_t ul = F[base - prow + k - 1], uc = F[base - prow + k], ur = F[base - prow + k + 1];
-        const uint64_t ml = F[base + k - 1], mr = F[base + k + 1];
-        const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
-        const uint64_t left = (mc << 1) | (ml >> 63), right = (mc >> 1) | (mr << 63);
-        const uint64_t B = mc & ~(uc & dc & left & right);
-        uint64_t E2 = 0, E3 = 0, E4 = 0, rem = B;
-        while (rem) {
-            const int b = __ffsll((long long)rem) - 1;
-            rem &= rem - 1;
-            const uint32_t cnt = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)] & 7u;
-            if (cnt >= 2) E2 |= 1ull << b;
-            if (cnt >= 3) E3 |= 1ull << b;
-            if (cnt >= 4) E4 |= 1ull << b;
+    for (int s0 = tid; s0 < nslots; s0 += 2 * T) {
+        uint32_t sp[2];
+        uint64_t wd[2][9];
+#pragma unroll
+        for (int u = 0; u < 2; u++) sp[u] = s0 + u * T < nslots ? M.spos[s0 + u * T] : 0u;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int y = sp[u] & 2047, k = sp[u] >> 11;
+            const int64_t base = (int64_t)(y + 1) * prow + 1 + k;
+            const bool ok = s0 + u * T < nslots;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) wd[u][3 * r + c] = ok ? F[base + (r - 1) * prow + (c - 1)] : 0ull;
         }
-        M.bmask[slot] = B;
-        M.e2[slot] = E2;
-        M.e3[slot] = E3;
-        M.e4[slot] = E4;
-        M.nbase[slot] = (uint32_t)(__popcll(B) + __popcll(E2) + __popcll(E3) + __popcll(E4));
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int slot = s0 + u * T;
+            if (slot >= nslots) continue;
+            const uint64_t ul = wd[u][0], uc = wd[u][1], ur = wd[u][2], ml = wd[u][3], mc = wd[u][4], mr = wd[u][5], dl = wd[u][6], dc = wd[u][7], dr = wd[u][8];
+            const uint64_t left = (mc << 1) | (ml >> 63), right = (mc >> 1) | (mr << 63);
+            const uint64_t B = mc & ~(uc & dc & left & right);
+            uint64_t E2 = 0, E3 = 0, E4 = 0, rem = B;
+            while (rem) {
+                const int b = __ffsll((long long)rem) - 1;
+                rem &= rem - 1;
+                const uint32_t cnt = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)] & 7u;
+                if (cnt >= 2) E2 |= 1ull << b;
+                if (cnt >= 3) E3 |= 1ull << b;
+                if (cnt >= 4) E4 |= 1ull << b;
+            }
+            M.bmask[slot] = B;
+            M.e2[slot] = E2;
+            M.e3[slot] = E3;
+            M.e4[slot] = E4;
+            M.nbase[slot] = (uint32_t)(__popcll(B) + __popcll(E2) + __popcll(E3) + __popcll(E4));
+        }
     }
     __syncthreads();
     int nn;
-    { // exclusive prefix of the node counts over the slots (raster order)
-        const int per = (nslots + T - 1) / T;
+    { // exclusive prefix of the node counts over the slots (raster order); a thread's slots are consecutive, read eight at a time
+        const int per = (nslots + T - 1) / T, lo = tid * per, hi = lo + per < nslots ? lo + per : nslots;
         int sum = 0;
-        for (int u = 0; u < per; u++) {
-            const int i = tid * per + u;
-            if (i < nslots) sum += (int)M.nbase[i];
+        for (int i0 = lo; i0 < hi; i0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = i0 + u < hi ? M.nbase[i0 + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) sum += (int)v[u];
         }
         int run = wg_scan_excl<T>(S.scan, tid, sum, &nn);
-        for (int u = 0; u < per; u++) {
-            const int i = tid * per + u;
-            if (i < nslots) {
-                const int c = (int)M.nbase[i];
-                M.nbase[i] = (uint32_t)run;
-                run += c;
-            }
+        for (int i0 = lo; i0 < hi; i0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = i0 + u < hi ? M.nbase[i0 + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + u < hi) {
+                    M.nbase[i0 + u] = (uint32_t)run;
+                    run += (int)v[u];
+                }
         }
     }
     if (nn > NN_MID) {
@@ -867,116 +897,276 @@ __device__ void cycles_frame_mid(ContoursLds& S, const MidTables& M, const uint6
     }
     if (tid == 0) S.nnodes = nn;
     __syncthreads();
+    MSTAMP(); // 1: M0 + M1 + prefix
     // ---- M2: the nodes
-    for (int slot = tid; slot < nslots; slot += T) {
-        const uint64_t B = M.bmask[slot];
-        if (!B) continue;
-        const uint32_t sp = M.spos[slot];
-        const int y = sp & 2047, k = sp >> 11;
-        const int64_t base = (int64_t)(y + 1) * prow + 1;
-        const uint64_t mc = F[base + k];
-        const uint64_t ul = F[base - prow + k - 1], uc = F[base - prow + k], ur = F[base - prow + k + 1];
-        const uint64_t ml = F[base + k - 1], mr = F[base + k + 1];
-        const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
-        uint32_t id = M.nbase[slot];
-        uint64_t rem = B;
-        while (rem) {
-            const int b = __ffsll((long long)rem) - 1;
-            rem &= rem - 1;
-            const uint32_t e = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)];
-            const int cnt = (int)(e & 7u);
-            const uint32_t xy = (uint32_t)(k * 64 + b) | ((uint32_t)y << 12);
-            for (int a = 0; a < cnt && a < 4; a++) {
-                const uint32_t back = (e >> (3 + 3 * a)) & 7u, nextd = (e >> (15 + 3 * a)) & 7u, ng = (e >> (28 + a)) & 1u;
-                const uint32_t west = a == 0 ? (e >> 27) & 1u : 0u;
-                M.pxy[id++] = xy | (back << 24) | (ng << 27) | (west << 28) | (nextd << 29);
+    for (int s0 = tid; s0 < nslots; s0 += 2 * T) {
+        uint32_t sp[2], idb[2];
+        uint64_t wd[2][9];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const bool ok = s0 + u * T < nslots;
+            sp[u] = ok ? M.spos[s0 + u * T] : 0u;
+            idb[u] = ok ? M.nbase[s0 + u * T] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int y = sp[u] & 2047, k = sp[u] >> 11;
+            const int64_t base = (int64_t)(y + 1) * prow + 1 + k;
+            const bool ok = s0 + u * T < nslots;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) wd[u][3 * r + c] = ok ? F[base + (r - 1) * prow + (c - 1)] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (s0 + u * T >= nslots) continue;
+            const uint64_t ul = wd[u][0], uc = wd[u][1], ur = wd[u][2], ml = wd[u][3], mc = wd[u][4], mr = wd[u][5], dl = wd[u][6], dc = wd[u][7], dr = wd[u][8];
+            const uint64_t left = (mc << 1) | (ml >> 63), right = (mc >> 1) | (mr << 63);
+            const int y = sp[u] & 2047, k = sp[u] >> 11;
+            uint32_t id = idb[u];
+            uint64_t rem = mc & ~(uc & dc & left & right);
+            while (rem) {
+                const int b = __ffsll((long long)rem) - 1;
+                rem &= rem - 1;
+                const uint32_t e = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)];
+                const int cnt = (int)(e & 7u);
+                const uint32_t xy = (uint32_t)(k * 64 + b) | ((uint32_t)y << 12);
+                for (int a2 = 0; a2 < cnt && a2 < 4; a2++) {
+                    const uint32_t back = (e >> (3 + 3 * a2)) & 7u, nextd = (e >> (15 + 3 * a2)) & 7u, ng = (e >> (28 + a2)) & 1u;
+                    const uint32_t west = a2 == 0 ? (e >> 27) & 1u : 0u;
+                    M.pxy[id++] = xy | (back << 24) | (ng << 27) | (west << 28) | (nextd << 29);
+                }
             }
         }
     }
     __syncthreads();
+    MSTAMP(); // 2: M2
     // ---- M3: successor of every node
-    for (int i = tid; i < nn; i += T) {
-        const uint32_t p = M.pxy[i];
-        const int x = (int)(p & 0xFFFu), y = (int)((p >> 12) & 0xFFFu), nd = (int)(p >> 29);
-        uint32_t succ = (uint32_t)i;
-        const int xs = x + dir_dx(nd), ys = y + dir_dy(nd);
-        const int ks = xs >> 6, bs = xs & 63;
-        bool ok = xs >= 0 && ys >= 0 && ys < h && ks < ww && ((S.rowmask[ys] >> ks) & 1u);
-        int slot2 = 0;
-        unsigned long long B2 = 0;
-        if (ok) {
-            slot2 = LS.slot(ys, ks);
-            B2 = M.bmask[slot2];
-            ok = (B2 >> bs) & 1ull;
+    for (int i0 = tid; i0 < nn; i0 += 4 * T) {
+        uint32_t p[4], id0[4], succ[4];
+        int slot2[4], cnt2[4];
+        unsigned long long B2[4], E2[4], E3[4], E4[4];
+        uint32_t nb[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = i0 + u * T < nn ? M.pxy[i0 + u * T] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = (int)(p[u] & 0xFFFu), y = (int)((p[u] >> 12) & 0xFFFu), nd = (int)(p[u] >> 29);
+            const int xs = x + dir_dx(nd), ys = y + dir_dy(nd);
+            const int ks = xs >> 6;
+            ok[u] = i0 + u * T < nn && xs >= 0 && ys >= 0 && ys < h && ks < ww && ((S.rowmask[ys < h && ys >= 0 ? ys : 0] >> ks) & 1u);
+            slot2[u] = ok[u] ? LS.slot(ys, ks) : 0;
+            B2[u] = M.bmask[slot2[u]];
+            E2[u] = M.e2[slot2[u]];
+            E3[u] = M.e3[slot2[u]];
+            E4[u] = M.e4[slot2[u]];
+            nb[u] = M.nbase[slot2[u]];
         }
-        if (ok) {
+        uint32_t alt[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = (int)(p[u] & 0xFFFu), nd = (int)(p[u] >> 29);
+            const int bs = (x + dir_dx(nd)) & 63;
+            ok[u] = ok[u] && ((B2[u] >> bs) & 1ull);
             const uint64_t below = (1ull << bs) - 1;
-            const unsigned long long E2 = M.e2[slot2], E3 = M.e3[slot2], E4 = M.e4[slot2];
-            const uint32_t id0 = M.nbase[slot2] + (uint32_t)(__popcll(B2 & below) + __popcll(E2 & below) + __popcll(E3 & below) + __popcll(E4 & below));
-            const int cnt2 = 1 + (int)((E2 >> bs) & 1ull) + (int)((E3 >> bs) & 1ull) + (int)((E4 >> bs) & 1ull);
-            const uint32_t back2 = (uint32_t)((nd + 4) & 7);
-            succ = id0; // the visit of the successor pixel whose back direction points here
-            for (int a = 1; a < cnt2; a++)
-                if (((M.pxy[id0 + a] >> 24) & 7u) == back2) succ = id0 + (uint32_t)a;
-        } else { // only an isolated pixel has no successor (it stays where it is); anything else contradicts the bijection
-            const int k0 = x >> 6;
-            const int64_t base = (int64_t)(y + 1) * prow + 1;
-            const uint32_t ring = ring_of(x & 63, F[base - prow + k0 - 1], F[base - prow + k0], F[base - prow + k0 + 1], F[base + k0 - 1],
-                                          F[base + k0], F[base + k0 + 1], F[base + prow + k0 - 1], F[base + prow + k0], F[base + prow + k0 + 1]);
-            if (ring != 0) atomicOr(&S.flags, FL);
+            id0[u] = nb[u] + (uint32_t)(__popcll(B2[u] & below) + __popcll(E2[u] & below) + __popcll(E3[u] & below) + __popcll(E4[u] & below));
+            cnt2[u] = 1 + (int)((E2[u] >> bs) & 1ull) + (int)((E3[u] >> bs) & 1ull) + (int)((E4[u] >> bs) & 1ull);
+            // the further visits of the successor pixel (almost never present: a pixel the border passes more than once)
+#pragma unroll
+            for (int a2 = 1; a2 < 4; a2++) alt[u][a2 - 1] = (ok[u] && a2 < cnt2[u]) ? M.pxy[id0[u] + a2] : 0u;
         }
-        M.succ[i] = succ;
-        M.link[i] = ((unsigned long long)(uint32_t)i << 32) | succ;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * T;
+            if (i >= nn) continue;
+            const int x = (int)(p[u] & 0xFFFu), y = (int)((p[u] >> 12) & 0xFFFu), nd = (int)(p[u] >> 29);
+            succ[u] = (uint32_t)i;
+            if (ok[u]) {
+                const uint32_t back2 = (uint32_t)((nd + 4) & 7);
+                succ[u] = id0[u]; // the visit of the successor pixel whose back direction points here
+#pragma unroll
+                for (int a2 = 1; a2 < 4; a2++)
+                    if (a2 < cnt2[u] && ((alt[u][a2 - 1] >> 24) & 7u) == back2) succ[u] = id0[u] + (uint32_t)a2;
+            } else { // only an isolated pixel has no successor (it stays where it is); anything else contradicts the bijection
+                const int k0 = x >> 6;
+                const int64_t base = (int64_t)(y + 1) * prow + 1;
+                const uint32_t ring = ring_of(x & 63, F[base - prow + k0 - 1], F[base - prow + k0], F[base - prow + k0 + 1], F[base + k0 - 1],
+                                              F[base + k0], F[base + k0 + 1], F[base + prow + k0 - 1], F[base + prow + k0], F[base + prow + k0 + 1]);
+                if (ring != 0) atomicOr(&S.flags, FL);
+            }
+            M.succ[i] = succ[u];
+            M.link[i] = ((unsigned long long)(uint32_t)i << 32) | succ[u];
+        }
     }
     __syncthreads();
     if (S.flags & FL) return;
+    MSTAMP(); // 3: M3
     // ---- M4: smallest node id of every cycle.  A word (mn, jp) always describes a true segment [i, jp) of the cycle with its
     // minimum, so a sweep may read words other threads have already advanced: after `rounds` sweeps every segment is at least
     // nn long, i.e. covers its whole cycle.
     int rounds = 0;
     while ((1 << rounds) < nn) rounds++;
+    // The doubling sweeps are rounds x 2 dependent accesses per node.  Up to NN_LDS nodes they run on a packed 32-bit word per node
+    // (mn or dist : 16 | jp : 16) in the LDS the tier-0 tables do not need here (bmask .. n_d, 44 KB) -- an LDS round trip is a tenth
+    // of an L2 one; the final values go to the global tables the later phases read.  Larger frames sweep the global tables.
+    static_assert(offsetof(ContoursLds, n_d) > offsetof(ContoursLds, bmask), "bmask .. n_d are laid out in this order");
+    constexpr int NN_LDS = (int)((offsetof(ContoursLds, n_d) + sizeof(uint16_t) * NN_CAP - offsetof(ContoursLds, bmask)) / 4);
+    uint32_t* const R = reinterpret_cast<uint32_t*>(S.bmask);
+    const bool in_lds = nn <= NN_LDS && nn <= 65535;
+    if (in_lds) {
+        for (int i0 = tid; i0 < nn; i0 += 8 * T) {
+            uint32_t sc[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) sc[u] = i0 + u * T < nn ? M.succ[i0 + u * T] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + u * T < nn) R[i0 + u * T] = ((uint32_t)(i0 + u * T) << 16) | sc[u];
+        }
+        __syncthreads();
+        for (int rd = 0; rd < rounds; rd++) {
+            for (int i0 = tid; i0 < nn; i0 += 8 * T) {
+                uint32_t w[8], wt[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) w[u] = i0 + u * T < nn ? R[i0 + u * T] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; u++) wt[u] = R[w[u] & 0xFFFFu];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (i0 + u * T < nn) R[i0 + u * T] = (((w[u] >> 16) < (wt[u] >> 16) ? (w[u] >> 16) : (wt[u] >> 16)) << 16) | (wt[u] & 0xFFFFu);
+            }
+            __syncthreads();
+        }
+        // mn -> the global table; the next array in R: dist | jp with the start absorbing
+        for (int i0 = tid; i0 < nn; i0 += 8 * T) {
+            uint32_t w[8], sc[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                w[u] = i0 + u * T < nn ? R[i0 + u * T] : 0u;
+                sc[u] = i0 + u * T < nn ? M.succ[i0 + u * T] : 0u;
+            }
+            // (a thread overwrites only the words it has just read: no barrier needed inside this loop)
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + u * T < nn) {
+                    const uint32_t i = (uint32_t)(i0 + u * T), mn = w[u] >> 16;
+                    M.link[i] = (unsigned long long)mn << 32;
+                    R[i] = mn == i ? i : ((1u << 16) | sc[u]);
+                }
+        }
+        __syncthreads();
+        MSTAMP(); // 4: M4
+        for (int rd = 0; rd < rounds; rd++) {
+            for (int i0 = tid; i0 < nn; i0 += 8 * T) {
+                uint32_t w[8], wt[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) w[u] = i0 + u * T < nn ? R[i0 + u * T] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; u++) wt[u] = R[w[u] & 0xFFFFu];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (i0 + u * T < nn) R[i0 + u * T] = (((w[u] >> 16) + (wt[u] >> 16)) << 16) | (wt[u] & 0xFFFFu);
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < nn; i += T) M.dist[i] = (unsigned long long)(R[i] >> 16) << 32;
+        __syncthreads();
+    } else {
     for (int rd = 0; rd < rounds; rd++) {
-        for (int i = tid; i < nn; i += T) {
-            const unsigned long long w = ld64(M.link + i);
-            const unsigned long long wt = ld64(M.link + (uint32_t)w);
-            const unsigned long long mn = (w >> 32) < (wt >> 32) ? (w >> 32) : (wt >> 32);
-            st64(M.link + i, (mn << 32) | (uint32_t)wt);
+        for (int i0 = tid; i0 < nn; i0 += 8 * T) {
+            unsigned long long w[8], wt[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) w[u] = i0 + u * T < nn ? ld64(M.link + i0 + u * T) : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; u++) wt[u] = ld64(M.link + (uint32_t)w[u]);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + u * T < nn) {
+                    const unsigned long long mn = (w[u] >> 32) < (wt[u] >> 32) ? (w[u] >> 32) : (wt[u] >> 32);
+                    st64(M.link + i0 + u * T, (mn << 32) | (uint32_t)wt[u]);
+                }
         }
         __syncthreads();
     }
+    MSTAMP(); // 4: M4
     // ---- M5: steps from every node FORWARD to its cycle's start (the start absorbs)
-    for (int i = tid; i < nn; i += T) {
-        const bool start = (uint32_t)(ld64(M.link + i) >> 32) == (uint32_t)i;
-        M.dist[i] = start ? (unsigned long long)(uint32_t)i : ((1ull << 32) | M.succ[i]);
+    for (int i0 = tid; i0 < nn; i0 += 8 * T) {
+        unsigned long long w[8];
+        uint32_t sc[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            w[u] = i0 + u * T < nn ? ld64(M.link + i0 + u * T) : 0ull;
+            sc[u] = i0 + u * T < nn ? M.succ[i0 + u * T] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + u * T < nn) {
+                const uint32_t i = (uint32_t)(i0 + u * T);
+                M.dist[i] = (uint32_t)(w[u] >> 32) == i ? (unsigned long long)i : ((1ull << 32) | sc[u]);
+            }
     }
     __syncthreads();
     for (int rd = 0; rd < rounds; rd++) {
-        for (int i = tid; i < nn; i += T) {
-            const unsigned long long w = ld64(M.dist + i);
-            const unsigned long long wt = ld64(M.dist + (uint32_t)w);
-            st64(M.dist + i, (((w >> 32) + (wt >> 32)) << 32) | (uint32_t)wt);
+        for (int i0 = tid; i0 < nn; i0 += 8 * T) {
+            unsigned long long w[8], wt[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) w[u] = i0 + u * T < nn ? ld64(M.dist + i0 + u * T) : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; u++) wt[u] = ld64(M.dist + (uint32_t)w[u]);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + u * T < nn) st64(M.dist + i0 + u * T, (((w[u] >> 32) + (wt[u] >> 32)) << 32) | (uint32_t)wt[u]);
         }
         __syncthreads();
     }
+    }
+    MSTAMP(); // 5: M5
     // ---- M6: candidates = cycles whose start visit contains the west neighbour, numbered in node order (raster order of the starts)
     int ncand;
     {
         const int per = (nn + T - 1) / T;
         const int lo = tid * per, hi = (lo + per < nn) ? lo + per : nn;
         int cnt = 0;
-        for (int i = lo; i < hi; i++)
-            cnt += ((uint32_t)(M.link[i] >> 32) == (uint32_t)i) && ((M.pxy[i] >> 28) & 1u);
+        for (int i0 = lo; i0 < hi; i0 += 8) {
+            unsigned long long w[8];
+            uint32_t p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                w[u] = i0 + u < hi ? M.link[i0 + u] : ~0ull;
+                p[u] = i0 + u < hi ? M.pxy[i0 + u] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) cnt += (i0 + u < hi) && ((uint32_t)(w[u] >> 32) == (uint32_t)(i0 + u)) && ((p[u] >> 28) & 1u);
+        }
         int e = wg_scan_excl<T>(S.scan, tid, cnt, &ncand);
         if (ncand <= CAND_MID) {
-            for (int i = lo; i < hi; i++) {
-                if ((uint32_t)(M.link[i] >> 32) != (uint32_t)i) continue;
-                if ((M.pxy[i] >> 28) & 1u) {
-                    M.cand[e] = (uint32_t)i;
-                    M.klen[e] = (uint32_t)(M.dist[M.succ[i]] >> 32) + 1u;
-                    M.kacc[e] = 1u;
-                    M.succ[i] = (uint32_t)e; // from here on: start node -> candidate index
-                    e++;
-                } else M.succ[i] = 0xFFFFFFFFu; // a hole border
+            for (int i0 = lo; i0 < hi; i0 += 8) {
+                unsigned long long w[8], dl_[8];
+                uint32_t p[8], sc[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    w[u] = i0 + u < hi ? M.link[i0 + u] : ~0ull;
+                    p[u] = i0 + u < hi ? M.pxy[i0 + u] : 0u;
+                    sc[u] = i0 + u < hi ? M.succ[i0 + u] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { // (only the starts' successors matter; the others read a harmless word)
+                    const bool start = (i0 + u < hi) && (uint32_t)(w[u] >> 32) == (uint32_t)(i0 + u);
+                    dl_[u] = M.dist[start ? sc[u] : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u;
+                    if (i >= hi || (uint32_t)(w[u] >> 32) != (uint32_t)i) continue;
+                    if ((p[u] >> 28) & 1u) {
+                        M.cand[e] = (uint32_t)i;
+                        M.klen[e] = (uint32_t)(dl_[u] >> 32) + 1u;
+                        M.kacc[e] = 1u;
+                        M.succ[i] = (uint32_t)e; // from here on: start node -> candidate index
+                        e++;
+                    } else M.succ[i] = 0xFFFFFFFFu; // a hole border
+                }
             }
         }
     }
@@ -986,41 +1176,70 @@ __device__ void cycles_frame_mid(ContoursLds& S, const MidTables& M, const uint6
         return;
     }
     __syncthreads();
+    MSTAMP(); // 6: M6
     // ---- M7: RETR_EXTERNAL as the fixed point of "label the accepted borders, revoke the starts whose nearest labelled pixel to
     // the left is positive" (see cycles_frame)
     for (int round = 0;; round++) {
         if (tid == 0) S.revoked = 0;
         for (int i = tid; i < nslots; i += T) { M.lab[i] = 0; M.neg[i] = 0; }
         __syncthreads();
-        for (int i = tid; i < nn; i += T) {
-            const uint32_t e = M.succ[(uint32_t)(M.link[i] >> 32)];
-            if (e == 0xFFFFFFFFu || !M.kacc[e]) continue;
-            const uint32_t p = M.pxy[i];
-            const int x = (int)(p & 0xFFFu), y = (int)((p >> 12) & 0xFFFu);
-            const int slot = LS.slot(y, x >> 6);
-            atomicOr(&M.lab[slot], 1ull << (x & 63));
-            if ((p >> 27) & 1u) atomicOr(&M.neg[slot], 1ull << (x & 63));
+        for (int i0 = tid; i0 < nn; i0 += 4 * T) {
+            unsigned long long w[4];
+            uint32_t p[4], e[4], ka[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                w[u] = i0 + u * T < nn ? M.link[i0 + u * T] : 0ull;
+                p[u] = i0 + u * T < nn ? M.pxy[i0 + u * T] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = M.succ[(uint32_t)(w[u] >> 32)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) ka[u] = e[u] != 0xFFFFFFFFu ? M.kacc[e[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (i0 + u * T >= nn || !ka[u]) continue;
+                const int x = (int)(p[u] & 0xFFFu), y = (int)((p[u] >> 12) & 0xFFFu);
+                const int slot = LS.slot(y, x >> 6);
+                atomicOr(&M.lab[slot], 1ull << (x & 63));
+                if ((p[u] >> 27) & 1u) atomicOr(&M.neg[slot], 1ull << (x & 63));
+            }
         }
         __syncthreads();
-        for (int e = tid; e < ncand; e += T) {
-            if (!M.kacc[e]) continue;
-            const uint32_t p = M.pxy[M.cand[e]];
-            const int x0 = (int)(p & 0xFFFu), y0 = (int)((p >> 12) & 0xFFFu);
-            const uint32_t occ = S.rowmask[y0];
-            int k = x0 >> 6;
-            // (the labels were OR-ed in by L2 atomics: read them past the vector L1, like the literal scanner does)
-            unsigned long long l = ld_l2(M.lab + LS.slot(y0, k)) & ((1ull << (x0 & 63)) - 1);
-            uint32_t left = occ & ((1u << k) - 1u);
-            while (!l && left) {
-                k = 31 - __clz((int)left);
-                left &= ~(1u << k);
-                l = ld_l2(M.lab + LS.slot(y0, k));
+        for (int e0 = tid; e0 < ncand; e0 += 2 * T) {
+            uint32_t ka[2], cn[2], p[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                ka[u] = e0 + u * T < ncand ? M.kacc[e0 + u * T] : 0u;
+                cn[u] = e0 + u * T < ncand ? M.cand[e0 + u * T] : 0u;
             }
-            if (l) {
-                const int top = 63 - __clzll((long long)l);
-                if (!((ld_l2(M.neg + LS.slot(y0, k)) >> top) & 1ull)) { // positive: inside a hole of that border
-                    M.kacc[e] = 0u;
-                    S.revoked = 1;
+#pragma unroll
+            for (int u = 0; u < 2; u++) p[u] = M.pxy[cn[u]];
+            unsigned long long l[2];
+            int kk[2];
+            uint32_t left[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int x0 = (int)(p[u] & 0xFFFu), y0 = (int)((p[u] >> 12) & 0xFFFu);
+                kk[u] = x0 >> 6;
+                // (the labels were OR-ed in by L2 atomics: read them past the vector L1, like the literal scanner does)
+                l[u] = ka[u] ? (ld_l2(M.lab + LS.slot(y0, kk[u])) & ((1ull << (x0 & 63)) - 1)) : 0ull;
+                left[u] = ka[u] ? (S.rowmask[y0] & ((1u << kk[u]) - 1u)) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (!ka[u]) continue;
+                const int y0 = (int)((p[u] >> 12) & 0xFFFu);
+                while (!l[u] && left[u]) {
+                    kk[u] = 31 - __clz((int)left[u]);
+                    left[u] &= ~(1u << kk[u]);
+                    l[u] = ld_l2(M.lab + LS.slot(y0, kk[u]));
+                }
+                if (l[u]) {
+                    const int top = 63 - __clzll((long long)l[u]);
+                    if (!((ld_l2(M.neg + LS.slot(y0, kk[u])) >> top) & 1ull)) { // positive: inside a hole of that border
+                        M.kacc[e0 + u * T] = 0u;
+                        S.revoked = 1;
+                    }
                 }
             }
         }
@@ -1034,25 +1253,44 @@ __device__ void cycles_frame_mid(ContoursLds& S, const MidTables& M, const uint6
             return;
         }
     }
+    MSTAMP(); // 7: M7
     // ---- M8: discovery rank and point offset of every accepted border (prefix sums in candidate order), then the points
     int nacc, npts;
     {
         const int per = (ncand + T - 1) / T;
         const int lo = tid * per, hi = (lo + per < ncand) ? lo + per : ncand;
         int cnt = 0, plen = 0;
-        for (int e = lo; e < hi; e++)
-            if (M.kacc[e]) { cnt++; plen += (int)M.klen[e]; }
+        for (int e0 = lo; e0 < hi; e0 += 8) {
+            uint32_t ka[8], kl[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                ka[u] = e0 + u < hi ? M.kacc[e0 + u] : 0u;
+                kl[u] = e0 + u < hi ? M.klen[e0 + u] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (ka[u]) { cnt++; plen += (int)kl[u]; }
+        }
         int rank = wg_scan_excl<T>(S.scan, tid, cnt, &nacc);
         int off = wg_scan_excl<T>(S.scan, tid, plen, &npts);
         if (nacc <= max_contours && npts <= max_points) {
-            for (int e = lo; e < hi; e++)
-                if (M.kacc[e]) {
-                    M.koff[e] = (uint32_t)off;
-                    cs[rank] = off;
-                    cl[rank] = (int32_t)M.klen[e];
-                    off += (int)M.klen[e];
-                    rank++;
+            for (int e0 = lo; e0 < hi; e0 += 8) {
+                uint32_t ka[8], kl[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    ka[u] = e0 + u < hi ? M.kacc[e0 + u] : 0u;
+                    kl[u] = e0 + u < hi ? M.klen[e0 + u] : 0u;
                 }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (ka[u]) {
+                        M.koff[e0 + u] = (uint32_t)off;
+                        cs[rank] = off;
+                        cl[rank] = (int32_t)kl[u];
+                        off += (int)kl[u];
+                        rank++;
+                    }
+            }
         }
     }
     if (nacc > max_contours || npts > max_points) { // the literal scanner reports the overflow the way it always did
@@ -1061,16 +1299,36 @@ __device__ void cycles_frame_mid(ContoursLds& S, const MidTables& M, const uint6
         return;
     }
     __syncthreads();
-    for (int i = tid; i < nn; i += T) {
-        const uint32_t e = M.succ[(uint32_t)(M.link[i] >> 32)];
-        if (e == 0xFFFFFFFFu || !M.kacc[e]) continue;
-        const uint32_t p = M.pxy[i];
-        rmcv_point q;
-        q.x = (int)(p & 0xFFFu);
-        q.y = (int)((p >> 12) & 0xFFFu);
-        const int len = (int)M.klen[e], d = (int)(M.dist[i] >> 32), pos = d ? len - d : 0;
-        if (pos >= 0 && pos < len) pts[M.koff[e] + pos] = q;
+    for (int i0 = tid; i0 < nn; i0 += 4 * T) {
+        unsigned long long w[4], dd[4];
+        uint32_t p[4], e[4], ka[4], kl[4], ko[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool ok = i0 + u * T < nn;
+            w[u] = ok ? M.link[i0 + u * T] : 0ull;
+            p[u] = ok ? M.pxy[i0 + u * T] : 0u;
+            dd[u] = ok ? M.dist[i0 + u * T] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = M.succ[(uint32_t)(w[u] >> 32)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t ee = e[u] != 0xFFFFFFFFu ? e[u] : 0u;
+            ka[u] = e[u] != 0xFFFFFFFFu ? M.kacc[ee] : 0u;
+            kl[u] = M.klen[ee];
+            ko[u] = M.koff[ee];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (i0 + u * T >= nn || !ka[u]) continue;
+            rmcv_point q;
+            q.x = (int)(p[u] & 0xFFFu);
+            q.y = (int)((p[u] >> 12) & 0xFFFu);
+            const int len = (int)kl[u], d = (int)(dd[u] >> 32), pos = d ? len - d : 0;
+            if (pos >= 0 && pos < len) pts[ko[u] + pos] = q;
+        }
     }
+    MSTAMP(); // 8: M8
     // ---- V2 on the final labels: every unlabelled run start would have been rejected by the scanner (nearest labelled pixel to
     // its left positive).  (V1 -- every accepted start acceptable -- is what the last round of M7 established.)
     for (int r = tid; r < nrows; r += T) {
@@ -1102,6 +1360,13 @@ __device__ void cycles_frame_mid(ContoursLds& S, const MidTables& M, const uint6
         }
     }
     __syncthreads();
+    MSTAMP(); // 9: V2
+#ifdef RMCV_PROFILE
+    if (tid == 0 && blockIdx.x < 2)
+        printf("[mid b%d nn=%d slots=%d cand=%d acc=%d rounds=%d] M0-1 %.1f M2 %.1f M3 %.1f M4 %.1f M5 %.1f M6 %.1f M7 %.1f M8 %.1f V2 %.1f us\n", (int)blockIdx.x, nn,
+               nslots, ncand, nacc, rounds, (tm_[1] - tm_[0]) / 100.0, (tm_[2] - tm_[1]) / 100.0, (tm_[3] - tm_[2]) / 100.0, (tm_[4] - tm_[3]) / 100.0,
+               (tm_[5] - tm_[4]) / 100.0, (tm_[6] - tm_[5]) / 100.0, (tm_[7] - tm_[6]) / 100.0, (tm_[8] - tm_[7]) / 100.0, (tm_[9] - tm_[8]) / 100.0);
+#endif
     *nc_out = nacc;
     *np_out = npts;
 }

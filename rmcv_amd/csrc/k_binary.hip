@@ -497,6 +497,13 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
         const int per_xcd = (n_blocks + 7) >> 3;
         int taper_head = 0, taper_tail = 0;
         if (taper_on && per_xcd >= 192) { taper_head = 16; taper_tail = 32; }
+        // A launch with fewer strips than half the CUs (one camera frame = 32 strips on 256 CUs: the per-frame drop-in chain) hands
+        // EVERY strip out as four 8-row pieces: four times the workgroups, a quarter of the rows each (15 -> 7 us for one frame).
+        if (n_blocks * 2 <= (g.n_cu > 0 ? g.n_cu : 256)) {
+            taper_head = per_xcd;
+            taper_tail = 0;
+            grid = (4 * n_blocks + 7) & ~7;
+        }
         const uint8_t* frames = b.frames + (int64_t)f0 * g.frame_pitch;
         uint8_t* binary = image ? b.binary + (int64_t)f0 * g.w * g.h : nullptr;
         uint64_t* bits = b.bits + (int64_t)f0 * g.plane_pitch;

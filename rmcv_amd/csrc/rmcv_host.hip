@@ -1036,7 +1036,10 @@ int rmcv_extract_color(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride
                                       contours_cap, n_contours, n_points);
     // The body enqueues an upload FROM the caller's frame and a download INTO the caller's `binary_out`.  An error return after
     // the first of them must not leave either in flight: the caller owns those buffers again the moment this function returns.
-    if (rc != RMCV_OK && c) (void)hipStreamSynchronize(c->stream);
+    if (rc != RMCV_OK && c) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->side) (void)hipStreamSynchronize(c->side);
+    }
     return rc;
 }
 
@@ -1063,6 +1066,7 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, c->launch_id + 1, s), "k_binary");
     c->launch_id++;
     c->binary_seq++;
+    if (binary_out) HIPCHK(c, hipEventRecord(c->ev_fork, s), "image download: mark");
     // running ahead with both parameter sets known: the frame's whole sparse part is ONE kernel (the fused per-frame kernel of
     // the batch path: findContours, fits and pairing back to back), not three
     const bool fused_ahead = c->run_ahead && c->last_lb_valid && c->last_ar_valid && c->last_lb.enemy == c->last_ar.enemy;
@@ -1088,7 +1092,6 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     HIPCHK(c, hipMemcpyAsync(c->h_pts, c->pack_pts, (size_t)std::min(SF_PTS_WIN, c->lim.max_points) * sizeof(rmcv_point), hipMemcpyDeviceToHost, s), "D2H pts");
     // the byte image goes straight to the caller's buffer (the runtime's pageable path: 37 us for 1.3 MB); through the pinned
     // staging buffer it cost a 65 us CPU copy on top of the DMA
-    if (binary_out) HIPCHK(c, hipMemcpyAsync(binary_out, b.binary, (size_t)w * h, hipMemcpyDeviceToHost, s), "D2H binary");
     bool ahead_lb = false, ahead_ar = false;
     if (c->last_lb_valid && c->run_ahead) { // the filters of this frame, with the previous frame's parameters (see rmcv_ctx::last_lb)
         if ((rc = enqueue_blobs(c, c->last_lb, !fused_ahead))) return rc;
@@ -1097,6 +1100,14 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
             if ((rc = enqueue_armours(c, c->last_ar, !fused_ahead))) return rc;
             ahead_ar = true;
         }
+    }
+    // The byte image is complete when k_binary is: its download (1.3 MB, 37 us) runs on the side stream BESIDE the sparse kernels
+    // instead of behind them.  Enqueued last: the runtime's pageable copy may keep this thread busy, and by now everything else of
+    // the frame is on the GPU's queues.
+    if (binary_out) {
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0), "image download: fork");
+        HIPCHK(c, hipMemcpyAsync(binary_out, b.binary, (size_t)w * h, hipMemcpyDeviceToHost, c->side), "D2H binary");
+        HIPCHK(c, hipStreamSynchronize(c->side), "sync (image)");
     }
     HIPCHK(c, hipStreamSynchronize(s), "sync");
     const int32_t nc = c->h_hdr[0], total = c->h_hdr[1], st = c->h_hdr[2];
