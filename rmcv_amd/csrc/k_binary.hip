@@ -208,10 +208,21 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
         // wave-uniform: its address arithmetic runs on the scalar unit.
         const int lane = tid & 63;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int nb = (w + 255) >> 8, nq = (srh + 3) >> 2, n_it = nq * nb;
-        const uint32_t r_nb = (uint32_t)((0x100000000ull + nb - 1) / nb);
+        const int nb = (w + 255) >> 8, nq = (srh + 3) >> 2;
+        // A row whose last 256-pixel block is at most half full (1920 = 7.5 blocks: BASELINE config 5) does not spend a whole
+        // wavefront on it per row quad: TWO row quads share one item, lanes 0..31 taking the block's pixels of the first, lanes
+        // 32..63 those of the second (6.7 % fewer load instructions at 1920, none of them half empty).
+        const int rem = w & 255;                              // pixels in the ragged last block (0: every block is full)
+        const bool packed = rem != 0 && rem <= 128;
+        const int nbf = packed ? nb - 1 : nb;                 // blocks handled one row quad per item
+        const int n_full = nq * nbf, n_it = n_full + (packed ? (nq + 1) >> 1 : 0);
+        const uint32_t r_nb = (uint32_t)((0x100000000ull + nbf - 1) / (nbf > 0 ? nbf : 1));
         const uint32_t lane_off = (uint32_t)lane * 12u;
         const uint32_t lds_lane = (uint32_t)__umul24(lane & 3, ww) * 8u + (uint32_t)(lane >> 2) * 2u;
+        // the same for a lane of a packed item: pixel group (lane & 31), row quad selected by lane >> 5
+        const uint32_t lane_off_p = (uint32_t)(lane & 31) * 12u;
+        const uint32_t lds_lane_p = (uint32_t)__umul24(lane & 3, ww) * 8u + (uint32_t)((lane & 31) >> 2) * 2u;
+        const bool hi_half = lane >= 32;
         const uint32_t M1 = (lane & 1) ? 0xF0F0u : 0x0F0Fu, S1 = (lane & 1) ? 12u : 4u;
         const uint32_t P2 = (lane & 2) ? 0x0c0c0105u : 0x0c0c0400u;
         constexpr uint32_t OOB_S = 0xFFFFFC00u; // scalar part of an offset that moves nothing (+ 63 * 12 stays out of extent)
@@ -234,18 +245,22 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
         } else
         for (int it0 = wv; it0 < n_it; it0 += 4 * U) {
             // One batch = U items of the wave: all 4 * U loads are issued, then thresholded.  CHK = false is the common case (a strip
-            // with every row inside the image, whole row quads, a full batch): no validity selects.
+            // with every row inside the image, whole row quads, a full batch of one-quad items): no validity selects.
             auto batch = [&](auto chk) {
                 constexpr bool CHK = decltype(chk)::value;
                 u32x3v v[U][4];
-                int info[U]; // LDS byte offset of the item's (row quad, block) | ragged-block flag; -1: beyond the strip's items
+                int info[U]; // LDS byte offset of the item's (row quad, block) | ragged-block flag | packed flag << 1; -1: beyond the strip's items
+                int qd[U];   // packed items: row quads from the first half's to the second half's (+1 / -1; 0: there is no second)
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const int it = it0 + 4 * u; // wave-uniform: everything up to the four vector adds runs on the scalar unit
-                    const int jq0 = div_r(it, r_nb), b = it - jq0 * nb;
+                    const bool pk = CHK && it >= n_full; // (packed items always take the checked form)
+                    const int itp = it - n_full;
+                    const int jq0 = pk ? 2 * itp : div_r(it, r_nb), b = pk ? nb - 1 : it - jq0 * nbf;
                     const int jq = (L & 1) ? jq0 : nq - 1 - jq0; // sweep direction, see below
+                    qd[u] = (pk && 2 * itp + 1 < nq) ? ((L & 1) ? 1 : -1) : 0;
                     const int rr0 = 4 * jq;
-                    info[u] = (int)(__umul24(rr0, ww) * 8u + (uint32_t)b * 32u) | (b == nb - 1 ? ragged : 0); // bit 0: ragged block
+                    info[u] = (int)(__umul24(rr0, ww) * 8u + (uint32_t)b * 32u) | (b == nb - 1 ? ragged : 0) | (pk ? 2 : 0); // bit 0: ragged block
                     if (CHK && it >= n_it) info[u] = -1;
 #ifdef RMCV_K1_NOLOAD
                     const uint32_t base = OOB_S - dk3; // ablation build: nothing is read
@@ -256,12 +271,23 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                     uint32_t vo[4];
                     // rows rr_lo <= rr < rr_hi of the strip are inside the image; the others (and a whole item beyond the
                     // strip's) are "loaded" from beyond the extent: zeros, no traffic
-                    const uint32_t t0 = (uint32_t)(rr0 - rr_lo), span = it < n_it ? rr_span : 0u;
+                    const uint32_t span = it < n_it ? rr_span : 0u;
+                    if (pk) { // the second half's rows lie one row quad further (in the sweep's direction); a lane beyond the row's
+                              // pixels, or in a half without a row quad, loads nothing
+                        const int q4 = hi_half ? 4 * qd[u] : 0;
+                        const bool live = (lane & 31) * 4 < rem && (!hi_half || qd[u] != 0);
+                        const uint32_t t0 = (uint32_t)(rr0 + q4 - rr_lo);
+                        const uint32_t shift = (uint32_t)(q4 * stride);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) vo[k] = (!CHK || t0 + (uint32_t)k < span ? rowk[k] : OOB_S) + lane_off;
+                        for (int k = 0; k < 4; k++) vo[k] = (live && t0 + (uint32_t)k < span) ? rowk[k] + shift + lane_off_p : OOB_S + lane_off;
+                    } else {
+                        const uint32_t t0 = (uint32_t)(rr0 - rr_lo);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) vo[k] = (!CHK || t0 + (uint32_t)k < span ? rowk[k] : OOB_S) + lane_off;
+                    }
                     // the first and the last row quad hold the rows this strip shares with its neighbours: those stay
                     // cacheable (the neighbour finds them in L2), everything else is read once and says so
-                    if (halo && (jq == 0 || jq == nq - 1)) {
+                    if (halo && (jq == 0 || jq == nq - 1 || (pk && (jq + qd[u] == 0 || jq + qd[u] == nq - 1)))) {
 #pragma unroll
                         for (int k = 0; k < 4; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b96(r_in, vo[k], 0, 0);
                     } else {
@@ -275,21 +301,30 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                                             v[u][2].x, v[u][2].y, v[u][2].z, v[u][3].x, v[u][3].y, v[u][3].z};
                     uint32_t m = thresh16<CA, CB>(d, lb);
                     const bool last_ragged = (info[u] & 1) != 0; // wave-uniform: the row's last block when w % 256 != 0
-                    // pixels beyond the row's end: the lane has read the next row's bytes
-                    if (last_ragged && lane * 4 >= w - ((nb - 1) << 8)) m = 0;
+                    const bool pk = CHK && info[u] >= 0 && (info[u] & 2) != 0;
+                    // pixels beyond the row's end: the lane has read the next row's bytes (a packed item's lanes read nothing there)
+                    if (last_ragged && !pk && lane * 4 >= w - ((nb - 1) << 8)) m = 0;
                     // 4x4 nibble transpose within the quad: exchange with lane^1 (nibbles), then with lane^2 (bytes)
                     const uint32_t p1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xF, 0xF, true);
                     const uint32_t t1 = (m & M1) | (((p1 << 8) >> S1) & ~M1);
                     const uint32_t p2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)t1, 0x4E, 0xF, 0xF, true);
                     const uint32_t t2 = __builtin_amdgcn_perm(p2, t1, P2);
-                    uint16_t* dst = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(T) + ((uint32_t)info[u] & ~1u) + lds_lane);
-                    if (CHK && info[u] < 0) dst = s_spare + tid; // an item beyond the strip's
-                    // the quad's 16 pixels of the last block may lie beyond the row: those go to a spare word
-                    if (last_ragged && (lane >> 2) * 16 >= w - ((nb - 1) << 8)) dst = s_spare + tid;
+                    uint16_t* dst;
+                    if (pk) {
+                        const int q4 = hi_half ? 4 * qd[u] : 0;
+                        dst = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(T) + ((uint32_t)info[u] & ~3u) + (uint32_t)(q4 * ww * 8) + lds_lane_p);
+                        // a quad of lanes whose 16 pixels lie beyond the row, and the half without a row quad: to a spare word
+                        if (((lane & 31) >> 2) * 16 >= rem || (hi_half && qd[u] == 0)) dst = s_spare + tid;
+                    } else {
+                        dst = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(T) + ((uint32_t)info[u] & ~3u) + lds_lane);
+                        if (CHK && info[u] < 0) dst = s_spare + tid; // an item beyond the strip's
+                        // the quad's 16 pixels of the last block may lie beyond the row: those go to a spare word
+                        if (last_ragged && (lane >> 2) * 16 >= w - ((nb - 1) << 8)) dst = s_spare + tid;
+                    }
                     *dst = (uint16_t)t2;
                 }
             };
-            if (plain && it0 + 4 * (U - 1) < n_it) batch(std::false_type{});
+            if (plain && it0 + 4 * (U - 1) < n_full) batch(std::false_type{});
             else batch(std::true_type{});
         }
     } else {

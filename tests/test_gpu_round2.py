@@ -385,9 +385,10 @@ def test_pixel_kernel_coalesced_loader_geometries(oracle, morph):
     from rmcv_amd import (CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL, CAMP_RED, STAGE_BINARY, Context, default_params)
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(4242 + morph)
-    widths = [64, 128, 192, 256, 320, 448, 512, 576, 768, 832, 1280, 1344]
-    heights = [1, 2, 3, 5, 31, 32, 33, 34, 63, 64, 65, 100]
-    cases = [(widths[i % len(widths)], heights[(i * 5 + morph) % len(heights)]) for i in range(24)]
+    # (a last block of at most 128 pixels -- 64, 128, 320, 384, 576, 640, 832, 1344, 1920 -- shares its wavefront between TWO row quads)
+    widths = [64, 128, 192, 256, 320, 448, 512, 576, 768, 832, 1280, 1344, 384, 640, 1920]
+    heights = [1, 2, 3, 5, 31, 32, 33, 34, 63, 64, 65, 100, 7, 36, 41]
+    cases = [(widths[i % len(widths)], heights[(i * 5 + morph) % len(heights)]) for i in range(30)]
     for ci, (w, h) in enumerate(cases):
         n = 1 + ci % 3
         pad_row, pad_frame = [(0, 0), (16, 0), (48, 64), (0, 4096)][ci % 4]
