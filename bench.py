@@ -514,7 +514,7 @@ def main():
         out["c2_binary_only"] = ex
         # detection only: the byte image `binary` is not written (RMCV_STAGE_NO_IMAGE; only the reference's debug view reads it,
         # executable/main.cpp:200-201).  NOT the metric: 3 B/px of algorithmic traffic instead of 4.
-        if legacy is None:
+        if legacy is None and world == 1:       # (the loop below calls step(), which gathers: a collective only rank 0 entered would hang)
             cur_stages[0] = stages | STAGE_NO_IMAGE
             for _ in range(args.warmup):
                 step()
@@ -691,6 +691,7 @@ def main():
     for g_ in (abi_gathers or []):
         g_.close()
     if use_dist:
+        barrier()                                   # rank 0 has the extras and the CPU baseline to itself: leave together
         dist.destroy_process_group()
 
 

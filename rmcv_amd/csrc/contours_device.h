@@ -331,6 +331,26 @@ __device__ __forceinline__ uint32_t ring_of(int b, uint64_t ul, uint64_t uc, uin
            (((d >> 1) & 1u) << 6) | (((d >> 2) & 1u) << 7);
 }
 
+// The border pixels of a word and how often the follower visits each, 64 pixels per operation.  A pixel is visited once per
+// maximal run of background neighbours (counter-clockwise round its 8-ring) that contains a 4-neighbour; such a run is counted at
+// its FIRST background 4-neighbour a, i.e. where not both a - 1 and a - 2 are background too:
+//   visits = [~E & (SE | S)] + [~N & (NE | E)] + [~W & (NW | N)] + [~S & (SW | W)]        (an isolated pixel: 1)
+// -- equal to ringtab's count for every ring of a border pixel (checked exhaustively).  Replaces a loop over
+// the word's border pixels with a table lookup each: a wavefront ran as long as the fullest of its 64 words needed.
+__device__ __forceinline__ void visit_masks(uint64_t ul, uint64_t uc, uint64_t ur, uint64_t ml, uint64_t mc, uint64_t mr, uint64_t dl,
+                                            uint64_t dc, uint64_t dr, uint64_t* B, uint64_t* E2, uint64_t* E3, uint64_t* E4)
+{
+    const uint64_t W = (mc << 1) | (ml >> 63), E = (mc >> 1) | (mr << 63), N = uc, S = dc;
+    const uint64_t NW = (uc << 1) | (ul >> 63), NE = (uc >> 1) | (ur << 63), SW = (dc << 1) | (dl >> 63), SE = (dc >> 1) | (dr << 63);
+    const uint64_t b = mc & ~(N & S & W & E);
+    const uint64_t cE = ~E & (SE | S), cN = ~N & (NE | E), cW = ~W & (NW | N), cS = ~S & (SW | W);
+    const uint64_t t1 = cE ^ cN, c1 = cE & cN, t2 = cW ^ cS, c2 = cW & cS;
+    *B = b;
+    *E2 = b & (c1 | c2 | (t1 & t2));
+    *E3 = b & ((c1 & (cW | cS)) | (c2 & (cE | cN)));
+    *E4 = b & c1 & c2;
+}
+
 // nodes beyond two of the listed 3-/4-visit pixels of `slot` below bit position `bit` (64: the whole word), and the count of the
 // pixel at `bit` itself (0 if it is not listed)
 __device__ __forceinline__ int multi_extra(const ContoursLds& S, int slot, int bit, int* own)
@@ -395,20 +415,18 @@ __device__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int
         const uint64_t ul = F[base - prow + k - 1], uc = F[base - prow + k], ur = F[base - prow + k + 1];
         const uint64_t ml = F[base + k - 1], mr = F[base + k + 1];
         const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
-        const uint64_t left = (mc << 1) | (ml >> 63), right = (mc >> 1) | (mr << 63);
-        uint64_t B = mc & ~(uc & dc & left & right), E2 = 0, rem = B;
+        uint64_t B, E2, E3, E4;
+        visit_masks(ul, uc, ur, ml, mc, mr, dl, dc, dr, &B, &E2, &E3, &E4);
         int extra = 0;
+        uint64_t rem = E3; // junctions of 1-pixel lines (visited 3 or 4 times): listed on the side
         while (rem) {
             const int b = __ffsll((long long)rem) - 1;
             rem &= rem - 1;
-            const uint32_t cnt = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)] & 7u;
-            if (cnt >= 2) E2 |= 1ull << b;
-            if (cnt >= 3) { // a junction of 1-pixel lines: listed on the side
-                const int m = atomicAdd(&S.nmulti, 1);
-                if (m < MULTI_CAP) S.multi[m] = (uint32_t)slot | ((uint32_t)b << 16) | (cnt << 24);
-                else atomicOr(&S.flags, FLCAP);
-                extra += (int)cnt - 2;
-            }
+            const uint32_t cnt = 3u + (uint32_t)((E4 >> b) & 1ull);
+            const int m = atomicAdd(&S.nmulti, 1);
+            if (m < MULTI_CAP) S.multi[m] = (uint32_t)slot | ((uint32_t)b << 16) | (cnt << 24);
+            else atomicOr(&S.flags, FLCAP);
+            extra += (int)cnt - 2;
         }
         S.bmask[slot] = B;
         S.e2mask[slot] = E2;
@@ -847,17 +865,8 @@ __device__ void cycles_frame_mid(ContoursLds& S, const MidTables& M, const uint6
             const int slot = s0 + u * T;
             if (slot >= nslots) continue;
             const uint64_t ul = wd[u][0], uc = wd[u][1], ur = wd[u][2], ml = wd[u][3], mc = wd[u][4], mr = wd[u][5], dl = wd[u][6], dc = wd[u][7], dr = wd[u][8];
-            const uint64_t left = (mc << 1) | (ml >> 63), right = (mc >> 1) | (mr << 63);
-            const uint64_t B = mc & ~(uc & dc & left & right);
-            uint64_t E2 = 0, E3 = 0, E4 = 0, rem = B;
-            while (rem) {
-                const int b = __ffsll((long long)rem) - 1;
-                rem &= rem - 1;
-                const uint32_t cnt = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)] & 7u;
-                if (cnt >= 2) E2 |= 1ull << b;
-                if (cnt >= 3) E3 |= 1ull << b;
-                if (cnt >= 4) E4 |= 1ull << b;
-            }
+            uint64_t B, E2, E3, E4;
+            visit_masks(ul, uc, ur, ml, mc, mr, dl, dc, dr, &B, &E2, &E3, &E4);
             M.bmask[slot] = B;
             M.e2[slot] = E2;
             M.e3[slot] = E3;
