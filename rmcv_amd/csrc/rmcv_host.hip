@@ -65,7 +65,8 @@ struct rmcv_ctx {
                                   // slower for a lone batch -- DESIGN.md section 5b)
     hipStream_t side = nullptr;   // the library's own second stream (full runs handed ONE stream are forked onto it and joined)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pre_binary = nullptr;
-    bool pre_binary_valid = false;
+    bool pre_binary_valid = false; // ev_pre_binary marks the point in front of the last pixel kernel
+    bool binary_enqueued = false;  // a pixel kernel has been enqueued on this geometry
     uint32_t binary_seq = 0;      // k_binary launches since the geometry was bound (frame_ready words: launch L is through with a frame at L * h)
     uint32_t launch_id = 0;       // k_binary launches of this context, never reset: the label the `started` word carries
     int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
@@ -389,6 +390,7 @@ static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t
         HIPCHK(c, hipMemset(c->bufs.frame_ready, 0, (size_t)c->lim.max_frames * sizeof(unsigned long long)), "frame progress words");
         c->binary_seq = 0;
         c->pre_binary_valid = false;
+        c->binary_enqueued = false;
         HIPCHK(c, hipMemcpy(c->bufs.frame_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice), "frame order");
         c->order_n = n_frames;
         c->order_h = h;
@@ -428,9 +430,11 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     stages &= ~RMCV_STAGE_HANDOVER;
     int rc;
     if (waits_per_frame) {
-        // everything this context did BEFORE that pixel kernel must be through; the pixel kernel itself need not be
-        if (!c->pre_binary_valid) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER without a preceding RMCV_STAGE_BINARY run");
+        if (!c->binary_enqueued) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER without a preceding RMCV_STAGE_BINARY run");
         if (stages & RMCV_STAGE_BINARY) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER goes with a run WITHOUT RMCV_STAGE_BINARY");
+    }
+    if (waits_per_frame && c->handover && c->pre_binary_valid) {
+        // everything this context did BEFORE that pixel kernel must be through; the pixel kernel itself need not be
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_pre_binary, 0), "hand-over: wait for what preceded the pixel kernel");
     } else if ((rc = order_begin(c, s))) return rc;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
@@ -452,8 +456,12 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     const bool can_hand_over = c->handover && binary_launches(g, b) == 1;
     const bool forked = one_sparse && can_hand_over && (stages & RMCV_STAGE_BINARY) && g.n_frames >= 4;
     if (stages & RMCV_STAGE_BINARY) {
-        HIPCHK(c, hipEventRecord(c->ev_pre_binary, s), "hand-over: mark");
-        c->pre_binary_valid = true;
+        c->binary_enqueued = true;
+        c->pre_binary_valid = false;
+        if (c->handover) { // (only then: a marker in front of every pixel kernel costs the next launch a few microseconds)
+            HIPCHK(c, hipEventRecord(c->ev_pre_binary, s), "hand-over: mark");
+            c->pre_binary_valid = true;
+        }
         if (forked) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pre_binary, 0), "hand-over: fork");
         HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->launch_id + 1, s), "k_binary");
         c->launch_id++;  // (counted once the launch is accepted: the device's words and these counters move together)
@@ -461,8 +469,8 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
         HT();
     }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
-    const bool per_frame = forked || (waits_per_frame && can_hand_over);
-    if (waits_per_frame && !can_hand_over) HIPCHK(c, hipStreamWaitEvent(s, c->ev_order, 0), "order: the pixel kernel"); // hand-over off: wait for the whole pixel kernel
+    const bool per_frame = forked || (waits_per_frame && can_hand_over && c->pre_binary_valid);
+    // (RMCV_STAGE_HANDOVER with the hand-over switched off went through order_begin above: it waits for the whole pixel kernel)
     const uint32_t wait_seq = per_frame ? c->binary_seq : 0;
     hipStream_t ss = forked ? c->side : s;
     // the spinning consumer goes on the machine only once its producer is there (k_binary.hip: `started`)
