@@ -32,6 +32,12 @@ for ho, g, w in [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or (
     kb0 = int(re.search(r"\[kb start\] (\d+)", rep).group(1))
     kb1 = int(re.search(r"\[kb end\] (\d+)", rep).group(1))
     sp = np.array([[int(x) for x in m.groups()] for m in re.finditer(r"\[sp\] (\d+) (\d+) (\d+) (\d+)", rep)], dtype=np.int64)
+    ph = np.array([[float(x) for x in m.groups()] for m in re.finditer(r"\[sp\] \d+ \d+ \d+ \d+ \| ([\d.]+) ([\d.]+) ([\d.]+) ([\d.]+) ([\d.]+) \| elig (\d+)", rep)])
+    if len(ph):
+        tot = ph[:, :5].sum(1)
+        order = np.argsort(tot)
+        for name, idx in (("median frame", order[len(order) // 2]), ("p90 frame", order[9 * len(order) // 10]), ("slowest frame", order[-1])):
+            print("   %-14s tables %.1f  cycles %.1f  verify+rank %.1f  fits %.1f (%d eligible)  compaction+pairing %.1f  = %.1f us" % ((name,) + tuple(ph[idx, :4]) + (int(ph[idx, 5]), ph[idx, 4], tot[idx])))
     us = lambda t: (t - kb0) / 100.0
     print("hand-over %d groups %d waves %d: pixel kernel 0 .. %.1f us; %d sparse workgroups" % (ho, g, w, us(kb1), len(sp)))
     for name, col in (("start", 1), ("frame ready", 2), ("done", 3)):
