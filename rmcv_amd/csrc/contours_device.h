@@ -373,56 +373,26 @@ __device__ __forceinline__ int multi_extra(const ContoursLds& S, int slot, int b
 // label store.
 // FLCAP is OR-ed into S.flags when a capacity of the LDS tables is exceeded (the frame then takes the mid tier), FL when the
 // formulation met something it cannot express (the literal scanner settles it).
-// exclusive prefix of one value per thread over the workgroup: a wave-level scan (shuffles) + one hop over the wave totals
-// (scan[] holds at least T / 64 ints): two barriers where the step-by-step form takes two per doubling step
-template <int T>
-__device__ __forceinline__ int wg_scan_excl_fast(int* scan, int tid, int v, int* total)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-    if (lane == 63) scan[wave] = incl;
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < T / 64; w++) {
-        const int x = scan[w];
-        if (w < wave) base += x;
-        tot += x;
-    }
-    __syncthreads(); // scan[] is free again
-    *total = tot;
-    return base + incl - v;
-}
-
 template <int T>
 __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int prow, int h, int ww, int nrows, int tid,
                              rmcv_point* __restrict__ pts, int max_points, int max_contours, int FL, int FLCAP, uint32_t* __restrict__ pxy)
 {
-    // Round 3: a frame's global round trips and barriers are what this function costs (it is latency-bound, and beside the
-    // streaming kernels a round trip is 2-3 us): the 3x3 word neighbourhoods of a thread's words are loaded together (one round
-    // trip per pass over the words instead of one per word), a thread's visits (packed coordinates) are loaded once and kept for the four passes over the visits, the
-    // prefix sums are wave-level scans, and the pointer doubling runs on one packed word per visit (smallest id or distance : 16 |
-    // pointer : 16), read and written whole, so a sweep needs one barrier instead of a read-all / write-all pair.
-    constexpr int NPT = NN_CAP / T;               // visits per thread
-    constexpr int SPT = (SLOT_CAP + T - 1) / T;   // non-empty words per thread
+    constexpr int NPT = NN_CAP / T; // nodes per thread in the doubling rounds
     const LabelStore LS = {S.rowmask, S.rowbase, S.lab, S.neg};
-    uint16_t* const mn = S.n_a;                                   // the successor; after the doubling: smallest visit id of the cycle
-    uint32_t* const W = reinterpret_cast<uint32_t*>(S.n_b);       // n_b + n_d: one packed word per visit
-    static_assert(offsetof(ContoursLds, n_d) == offsetof(ContoursLds, n_b) + sizeof(uint16_t) * NN_CAP, "n_b and n_d are adjacent");
+    uint16_t* const nxt = S.n_a; // successor, later the distance from the cycle's start
+    uint16_t* const mn = S.n_b;  // smallest node id of the cycle
+    uint16_t* const jp = S.n_d;  // doubling pointer, later the kept-contour slot of a start node
 #ifdef RMCV_PROFILE
     long long tc_[10]; int tci_ = 0;
-#define CSTAMP() do { __syncthreads(); if (tci_ < 10) tc_[tci_++] = wall_clock64(); } while (0)
+#define CSTAMP() do { __syncthreads(); tc_[tci_++] = wall_clock64(); } while (0)
 #else
 #define CSTAMP() do {} while (0)
 #endif
     CSTAMP();
     for (int i = tid; i < 256; i += T) S.ringtab[i] = RINGTAB.v[i];
     if (tid == 0) { S.nnodes = 0; S.nmulti = 0; }
+    __syncthreads();
+    CSTAMP();
     // slot -> (row, word): y | k << 11
     for (int r = tid; r < nrows; r += T) {
         const int y = S.rows[r];
@@ -436,27 +406,17 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
     }
     __syncthreads();
     CSTAMP();
-    // ---- N1: per non-empty word: border pixels, pixels visited twice, node count.  The nine words round it stay in registers.
+    // ---- N1: per non-empty word: border pixels, pixels visited twice, node count
     const int nslots = S.nslots;
-    {
-    uint64_t wd[SPT][9];
-#pragma unroll
-    for (int u = 0; u < SPT; u++) {
-        const int slot = tid + u * T;
-        const bool ok = slot < nslots;
-        const int sp = ok ? S.spos[slot] : 0;
-        const int64_t base = (int64_t)((sp & 2047) + 1) * prow + 1 + (sp >> 11);
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) wd[u][3 * r + c] = ok ? F[base + (r - 1) * prow + (c - 1)] : 0ull;
-    }
-#pragma unroll
-    for (int u = 0; u < SPT; u++) {
-        const int slot = tid + u * T;
-        if (slot >= nslots) continue;
+    for (int slot = tid; slot < nslots; slot += T) {
+        const int y = S.spos[slot] & 2047, k = S.spos[slot] >> 11;
+        const int64_t base = (int64_t)(y + 1) * prow + 1;
+        const uint64_t mc = F[base + k];
+        const uint64_t ul = F[base - prow + k - 1], uc = F[base - prow + k], ur = F[base - prow + k + 1];
+        const uint64_t ml = F[base + k - 1], mr = F[base + k + 1];
+        const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
         uint64_t B, E2, E3, E4;
-        visit_masks(wd[u][0], wd[u][1], wd[u][2], wd[u][3], wd[u][4], wd[u][5], wd[u][6], wd[u][7], wd[u][8], &B, &E2, &E3, &E4);
+        visit_masks(ul, uc, ur, ml, mc, mr, dl, dc, dr, &B, &E2, &E3, &E4);
         int extra = 0;
         uint64_t rem = E3; // junctions of 1-pixel lines (visited 3 or 4 times): listed on the side
         while (rem) {
@@ -472,7 +432,6 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
         S.e2mask[slot] = E2;
         S.nbase[slot] = (uint16_t)(__popcll(B) + __popcll(E2) + extra);
     }
-    }
     __syncthreads();
     { // exclusive prefix of the node counts over the slots (raster order): node ids ascend in raster order
         const int ns = nslots, per = (ns + T - 1) / T;
@@ -481,8 +440,15 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
             const int i = tid * per + u;
             if (i < ns) sum += S.nbase[i];
         }
-        int total;
-        int run = wg_scan_excl_fast<T>(S.scan, tid, sum, &total);
+        S.scan[tid] = sum;
+        __syncthreads();
+        for (int d = 1; d < T; d <<= 1) {
+            const int v = tid >= d ? S.scan[tid - d] : 0;
+            __syncthreads();
+            S.scan[tid] += v;
+            __syncthreads();
+        }
+        int run = S.scan[tid] - sum;
         for (int u = 0; u < per; u++) {
             const int i = tid * per + u;
             if (i < ns) {
@@ -491,42 +457,31 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
                 run += c;
             }
         }
-        if (tid == 0) {
-            S.nnodes = total;
-            if (total > NN_CAP) S.flags |= FLCAP;
+        if (tid == T - 1) {
+            S.nnodes = S.scan[tid];
+            if (S.scan[tid] > NN_CAP) S.flags |= FLCAP;
         }
     }
     __syncthreads();
     if (S.flags) return;
     const int nn = S.nnodes;
     CSTAMP();
-    // ---- N2: the nodes (the words once more, all of a thread's loads issued together: one round trip)
-    {
-    uint64_t wd[SPT][9];
-#pragma unroll
-    for (int u = 0; u < SPT; u++) {
-        const int slot = tid + u * T;
-        const bool ok = slot < nslots && S.bmask[slot < nslots ? slot : 0] != 0;
-        const int sp = ok ? S.spos[slot] : 0;
-        const int64_t base = (int64_t)((sp & 2047) + 1) * prow + 1 + (sp >> 11);
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) wd[u][3 * r + c] = ok ? F[base + (r - 1) * prow + (c - 1)] : 0ull;
-    }
-#pragma unroll
-    for (int u = 0; u < SPT; u++) {
-        const int slot = tid + u * T;
-        if (slot >= nslots) continue;
+    // ---- N2: the nodes
+    for (int slot = tid; slot < nslots; slot += T) {
         const uint64_t B = S.bmask[slot];
         if (!B) continue;
         const int y = S.spos[slot] & 2047, k = S.spos[slot] >> 11;
+        const int64_t base = (int64_t)(y + 1) * prow + 1;
+        const uint64_t mc = F[base + k];
+        const uint64_t ul = F[base - prow + k - 1], uc = F[base - prow + k], ur = F[base - prow + k + 1];
+        const uint64_t ml = F[base + k - 1], mr = F[base + k + 1];
+        const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
         int id = S.nbase[slot];
         uint64_t rem = B;
         while (rem) {
             const int b = __ffsll((long long)rem) - 1;
             rem &= rem - 1;
-            const uint32_t e = S.ringtab[ring_of(b, wd[u][0], wd[u][1], wd[u][2], wd[u][3], wd[u][4], wd[u][5], wd[u][6], wd[u][7], wd[u][8])];
+            const uint32_t e = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)];
             const int cnt = (int)(e & 7u);
             const uint32_t xy = (uint32_t)(k * 64 + b) | ((uint32_t)y << 12);
             for (int a = 0; a < cnt && a < 4; a++) {
@@ -537,17 +492,11 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
             }
         }
     }
-    }
     __syncthreads();
     CSTAMP();
-    // a thread's visits (x:12 | y:12 | back:3 | neg:1 | west:1 | next:3) are fetched together and parked in the words the doubling
-    // will use (a visit's word is its own until N3 has replaced it): one global round trip for the pass instead of one per visit
-#pragma unroll
-    for (int u = 0; u < NPT; u++)
-        if (tid + u * T < nn) W[tid + u * T] = pxy[tid + u * T];
-    // ---- N3: successor of every node
+    // ---- N3: successor and predecessor of every node
     for (int i = tid; i < nn; i += T) {
-        const uint32_t p = W[i];
+        const uint32_t p = pxy[i];
         const int x = (int)(p & 0xFFFu), y = (int)((p >> 12) & 0xFFFu), nd = (int)(p >> 29);
         int succ = i;
         const int xs = x + dir_dx(nd), ys = y + dir_dy(nd);
@@ -581,86 +530,102 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
                                           F[base + k0], F[base + k0 + 1], F[base + prow + k0 - 1], F[base + prow + k0], F[base + prow + k0 + 1]);
             if (ring != 0) atomicOr(&S.flags, FL);
         }
-        mn[i] = (uint16_t)succ;
-        W[i] = ((uint32_t)i << 16) | (uint32_t)succ;
+        nxt[i] = (uint16_t)succ;
     }
     __syncthreads();
     if (S.flags) return;
     CSTAMP();
-    // ---- N4: smallest node id of every cycle, by pointer doubling.  A word (mn, jp) always describes a true segment [i, jp) of
-    // the cycle with its minimum, so a sweep may read words other threads have already advanced.
+    // ---- N4: smallest node id of every cycle, by pointer doubling
     int rounds = 0;
     while ((1 << rounds) < nn) rounds++;
-    for (int rd = 0; rd < rounds; rd++) {
-        uint32_t w[NPT], wt[NPT];
-#pragma unroll
-        for (int u = 0; u < NPT; u++) w[u] = tid + u * T < nn ? W[tid + u * T] : 0u;
-#pragma unroll
-        for (int u = 0; u < NPT; u++) wt[u] = W[w[u] & 0xFFFFu];
-#pragma unroll
-        for (int u = 0; u < NPT; u++)
-            if (tid + u * T < nn) W[tid + u * T] = (((w[u] >> 16) < (wt[u] >> 16) ? (w[u] >> 16) : (wt[u] >> 16)) << 16) | (wt[u] & 0xFFFFu);
-        __syncthreads();
-    }
-    CSTAMP();
-    // ---- N5: number of steps from every node FORWARD to its cycle's start (the smallest id; it absorbs); a node's position in the
-    // contour is the cycle length minus that.  The smallest ids move to their own array first.
-    uint16_t succ0[NPT]; // the successor of a start node: the last node of its contour
-    {
-        uint32_t m0[NPT];
-#pragma unroll
-        for (int u = 0; u < NPT; u++) {
-            const int i = tid + u * T;
-            m0[u] = i < nn ? W[i] >> 16 : 0u;
-            succ0[u] = i < nn ? mn[i] : (uint16_t)0; // (still the successor)
-        }
-        // (a thread overwrites only the words it has just read)
-#pragma unroll
-        for (int u = 0; u < NPT; u++) {
-            const int i = tid + u * T;
-            if (i >= nn) continue;
-            mn[i] = (uint16_t)m0[u];
-            W[i] = m0[u] == (uint32_t)i ? (uint32_t)i : ((1u << 16) | succ0[u]);
-        }
+    for (int i = tid; i < nn; i += T) {
+        mn[i] = (uint16_t)i;
+        jp[i] = nxt[i];
     }
     __syncthreads();
     for (int rd = 0; rd < rounds; rd++) {
-        uint32_t w[NPT], wt[NPT];
+        uint16_t m2[NPT], j2[NPT];
 #pragma unroll
-        for (int u = 0; u < NPT; u++) w[u] = tid + u * T < nn ? W[tid + u * T] : 0u;
+        for (int u = 0; u < NPT; u++) {
+            const int i = tid + u * T;
+            if (i < nn) {
+                const int t = jp[i];
+                m2[u] = mn[t];
+                j2[u] = jp[t];
+            }
+        }
+        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < NPT; u++) wt[u] = W[w[u] & 0xFFFFu];
-#pragma unroll
-        for (int u = 0; u < NPT; u++)
-            if (tid + u * T < nn) W[tid + u * T] = (((w[u] >> 16) + (wt[u] >> 16)) << 16) | (wt[u] & 0xFFFFu);
+        for (int u = 0; u < NPT; u++) {
+            const int i = tid + u * T;
+            if (i < nn) {
+                if (m2[u] < mn[i]) mn[i] = m2[u];
+                jp[i] = j2[u];
+            }
+        }
         __syncthreads();
     }
     CSTAMP();
-    // a thread's visits once more, fetched together and kept in registers for the three short passes that follow
-    uint32_t pc[NPT];
-#pragma unroll
-    for (int u = 0; u < NPT; u++) pc[u] = tid + u * T < nn ? pxy[tid + u * T] : 0u;
-    // ---- N6: every cycle whose start visit contains the west neighbour is an outer border: a candidate contour.  The low half of a
-    // START node's word (its pointer, no longer needed) takes the candidate's slot (0xFFFF: a hole border); its distance is 0.
+    // ---- N5: number of steps from every node FORWARD to its cycle's start (the smallest id); a node's position in the contour is
+    // the cycle length minus that.  The doubling pointers are the successors with the start made absorbing.
+    uint16_t* const dist = nxt; // in place: the successors are read into the doubling pointers first
+    uint16_t succ0[NPT]; // the successor of a start node: the last node of its contour
 #pragma unroll
     for (int u = 0; u < NPT; u++) {
         const int i = tid + u * T;
-        if (i >= nn || mn[i] != i) continue;
-        uint32_t ks = 0xFFFFu;
-        if ((pc[u] >> 28) & 1u) {
-            const int len = (int)(W[succ0[u]] >> 16) + 1;
+        succ0[u] = 0;
+        if (i < nn) {
+            const bool start = mn[i] == i;
+            succ0[u] = nxt[i];
+            jp[i] = start ? (uint16_t)i : nxt[i];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nn; i += T) dist[i] = mn[i] == i ? 0 : 1;
+    __syncthreads();
+    for (int rd = 0; rd < rounds; rd++) {
+        uint16_t d2[NPT], j2[NPT];
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int i = tid + u * T;
+            if (i < nn) {
+                const int t = jp[i];
+                d2[u] = dist[t];
+                j2[u] = jp[t];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int i = tid + u * T;
+            if (i < nn) {
+                dist[i] = (uint16_t)(dist[i] + d2[u]);
+                jp[i] = j2[u];
+            }
+        }
+        __syncthreads();
+    }
+    CSTAMP();
+    // ---- N6: every cycle whose start visit contains the west neighbour is an outer border: a candidate contour
+#pragma unroll
+    for (int u = 0; u < NPT; u++) {
+        const int i = tid + u * T;
+        if (i >= nn) continue;
+        uint16_t ks = 0xFFFF;
+        if (mn[i] == i && ((pxy[i] >> 28) & 1u)) {
+            const int len = dist[succ0[u]] + 1;
             const int slot = atomicAdd(&S.nkept, 1);
             if (slot >= KEPT_CAP || slot >= max_contours) {
                 atomicOr(&S.flags, FLCAP);
             } else {
-                const uint32_t p = pc[u];
+                const uint32_t p = pxy[i];
                 S.kkey[slot] = ((p >> 12) & 0xFFFu) << 16 | (p & 0xFFFu);
                 S.klen[slot] = len;
                 S.kacc[slot] = 1;
-                ks = (uint32_t)slot;
+                ks = (uint16_t)slot;
             }
         }
-        W[i] = ks; // (distance 0 : slot)
+        if (mn[i] == i) jp[i] = ks;
     }
     __syncthreads();
     if (S.flags) return;
@@ -671,18 +636,14 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
     // (such a start lies inside a hole of the labelled border), an acceptance may be revoked once a wrongly accepted neighbour
     // lost its labels.  Frames without nested components -- the usual case -- take one round.
     const int ncand = S.nkept;
-    uint16_t ksn[NPT]; // the candidate slot of every visit's border
-#pragma unroll
-    for (int u = 0; u < NPT; u++) ksn[u] = tid + u * T < nn ? (uint16_t)(W[mn[tid + u * T]] & 0xFFFFu) : (uint16_t)0xFFFF;
     for (int round = 0;; round++) {
         if (tid == 0) S.revoked = 0;
         for (int i = tid; i < S.nslots; i += T) { S.lab[i] = 0; S.neg[i] = 0; }
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < NPT; u++) {
-            const int ks = ksn[u];
+        for (int i = tid; i < nn; i += T) {
+            const int ks = jp[mn[i]];
             if (ks == 0xFFFF || !S.kacc[ks]) continue; // a hole border, or a border that is not (or no longer) accepted
-            const uint32_t p = pc[u];
+            const uint32_t p = pxy[i];
             const int x = (int)(p & 0xFFFu), y = (int)((p >> 12) & 0xFFFu);
             const int slot = LS.slot(y, x >> 6);
             atomicOr(&S.lab[slot], 1ull << (x & 63));
@@ -729,16 +690,14 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
         }
     __syncthreads();
     if (S.flags) return;
-#pragma unroll
-    for (int u = 0; u < NPT; u++) {
-        const int i = tid + u * T;
-        const int ks = ksn[u];
-        if (i >= nn || ks == 0xFFFF || !S.kacc[ks]) continue;
-        const uint32_t p = pc[u];
+    for (int i = tid; i < nn; i += T) {
+        const int ks = jp[mn[i]];
+        if (ks == 0xFFFF || !S.kacc[ks]) continue;
+        const uint32_t p = pxy[i];
         rmcv_point q;
         q.x = (int)(p & 0xFFFu);
         q.y = (int)((p >> 12) & 0xFFFu);
-        const int len = S.klen[ks], d = (int)(W[i] >> 16), pos = (mn[i] == i || !d) ? 0 : len - d;
+        const int len = S.klen[ks], pos = dist[i] ? len - dist[i] : 0;
         if (pos >= 0 && pos < len) pts[S.koff[ks] + pos] = q; // (always, for a consistent plane)
     }
     __syncthreads();
@@ -766,11 +725,12 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
 #ifdef RMCV_PROFILE
     CSTAMP();
     if (tid == 0 && (blockIdx.x == 100))
-        printf("[cycles f%d nn=%d rounds=%d] tables %.1f N1+scan %.1f N2 %.1f N3 %.1f N4 %.1f N5 %.1f N6-N8 %.1f us\n", (int)blockIdx.x, nn, rounds,
+        printf("[cycles f%d nn=%d rounds=%d] ringtab %.1f N1+scan %.1f N2 %.1f N3 %.1f N4 %.1f N5 %.1f N6+N7 %.1f us\n", (int)blockIdx.x, nn, rounds,
                (tc_[1] - tc_[0]) / 100.0, (tc_[2] - tc_[1]) / 100.0, (tc_[3] - tc_[2]) / 100.0, (tc_[4] - tc_[3]) / 100.0,
                (tc_[5] - tc_[4]) / 100.0, (tc_[6] - tc_[5]) / 100.0, (tc_[7] - tc_[6]) / 100.0);
 #endif
 }
+
 
 // ---- mid tier: the same cycle formulation with its tables in GLOBAL memory ---------------------------------------------------
 // cv::findContours has no bound (src/imgproc.cpp:71-72).  A frame beyond what the LDS tables hold (VISIT_CAP visits, SLOT_CAP
