@@ -234,27 +234,51 @@ static constexpr int NN_CAP = VISIT_CAP;    // border visits (nodes) of a frame 
 #endif
 static constexpr int CT_MAXH = RMCV_CT_MAXH;   // rows covered by the LDS row tables (taller/wider frames take the literal path)
 
+// The workgroup's LDS: this struct, followed by the ROW TABLES (RowTabs below), which are sized by the frame's height at launch:
+// a row costs 8 bytes (mask of its non-empty words, its place in the list of non-empty rows, its slot base), 2048 rows 16 KB but the
+// 1200 rows of a 1920x1200 frame 9.6 KB -- and with 16 KB the workgroup did not fit a CU's 160 KB beside the four pixel-kernel
+// workgroups (4 x 19.8 KB) of two batches at that width (round 3: C5 +4-6 % once it does, tools/ab_r3_c5_lds.sh).
+// Layout: what the fused tail may overlay with its wave-private rows comes first (exactly 8 x sizeof(WaveLds) = 30 720 bytes: tables
+// that are dead once the contours are out), then what it needs (the work-list copies in bmask / e2mask, the node tables), then the
+// scalars.
 struct ContoursLds {
     unsigned long long lab[SLOT_CAP], neg[SLOT_CAP];
-    uint32_t rowmask[CT_MAXH];
     uint32_t kkey[KEPT_CAP];
     int32_t koff[KEPT_CAP], klen[KEPT_CAP];
-    uint16_t rows[CT_MAXH], rowbase[CT_MAXH];
     int scan[CT_THREADS_MAX];
-    // cycle formulation (cycles_frame): border pixels / two-visit pixels per slot, node-id base and (row, word) per slot, node tables
-    unsigned long long bmask[SLOT_CAP], e2mask[SLOT_CAP];
-    uint16_t nbase[SLOT_CAP], spos[SLOT_CAP];
-    uint16_t n_a[NN_CAP], n_b[NN_CAP], n_d[NN_CAP];
+    uint16_t nbase[SLOT_CAP], spos[SLOT_CAP]; // cycle formulation: node-id base and (row, word) per slot
     uint32_t ringtab[256];
-    int nnodes, nkept, cursor, flags, nrows, nslots, nelig, lit[3];
     uint32_t multi[MULTI_CAP]; // cycles_frame: pixels the border visits 3 or 4 times: slot:16 | bit:6 << 16 | count << 24
+    uint8_t kacc[KEPT_CAP];    // cycles_frame: outer border e is (still) accepted by the RETR_EXTERNAL rule
+    uint8_t pad_front[384];    // (brings the part above to 8 x sizeof(WaveLds))
+    // cycle formulation (cycles_frame): border pixels / two-visit pixels per slot, node tables
+    unsigned long long bmask[SLOT_CAP], e2mask[SLOT_CAP];
+    uint16_t n_a[NN_CAP], n_b[NN_CAP], n_d[NN_CAP];
+    int nnodes, nkept, cursor, flags, nrows, nslots, nelig, lit[3];
     int nmulti;
-    uint8_t kacc[KEPT_CAP]; // cycles_frame: outer border e is (still) accepted by the RETR_EXTERNAL rule
-    int revoked;            // ... some acceptance was revoked in this round
+    int revoked;  // cycles_frame: some acceptance was revoked in this round
     int cur_ok;   // frame-level hand-over: the frame's planes arrived
     int wnext;    // fused tail: next entry of the sorted work list
     int sink[64]; // per-lane sinks: lanes != 0 add 0 here so that a wave-wide atomic stays convergent and does not serialise on one word
 };
+static_assert(offsetof(ContoursLds, bmask) == (CT_THREADS_MAX / 64) * 3840, "the part the fused tail overlays is exactly its wave-private rows (sizeof(WaveLds) = 3840)");
+
+// the row tables behind the struct: `rows_cap` rows (the frame's height rounded up to 64, at most CT_MAXH)
+struct RowTabs {
+    uint32_t* rowmask; // [row] bit k: word k of the row is non-empty
+    uint16_t* rows;    // the non-empty rows
+    uint16_t* rowbase; // [row] slot of the row's first non-empty word
+};
+__host__ __device__ inline int lds_rows_cap(int h) { const int r = (h + 63) & ~63; return r < CT_MAXH ? r : CT_MAXH; }
+__host__ __device__ inline size_t lds_bytes(int h) { return sizeof(ContoursLds) + (size_t)lds_rows_cap(h) * 8; }
+__device__ __forceinline__ RowTabs row_tabs(void* smem, int rows_cap)
+{
+    RowTabs R;
+    R.rowmask = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(smem) + sizeof(ContoursLds));
+    R.rows = reinterpret_cast<uint16_t*>(R.rowmask + rows_cap);
+    R.rowbase = R.rows + rows_cap;
+    return R;
+}
 
 // ---- cycle formulation of the border following --------------------------------------------------------------------------
 // Every VISIT of Suzuki's follower to a pixel is a node: (pixel, maximal arc of consecutive background neighbours that contains
@@ -374,11 +398,11 @@ __device__ __forceinline__ int multi_extra(const ContoursLds& S, int slot, int b
 // FLCAP is OR-ed into S.flags when a capacity of the LDS tables is exceeded (the frame then takes the mid tier), FL when the
 // formulation met something it cannot express (the literal scanner settles it).
 template <int T>
-__device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __restrict__ F, int prow, int h, int ww, int nrows, int tid,
+__device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, const uint64_t* __restrict__ F, int prow, int h, int ww, int nrows, int tid,
                              rmcv_point* __restrict__ pts, int max_points, int max_contours, int FL, int FLCAP, uint32_t* __restrict__ pxy)
 {
     constexpr int NPT = NN_CAP / T; // nodes per thread in the doubling rounds
-    const LabelStore LS = {S.rowmask, S.rowbase, S.lab, S.neg};
+    const LabelStore LS = {RT.rowmask, RT.rowbase, S.lab, S.neg};
     uint16_t* const nxt = S.n_a; // successor, later the distance from the cycle's start
     uint16_t* const mn = S.n_b;  // smallest node id of the cycle
     uint16_t* const jp = S.n_d;  // doubling pointer, later the kept-contour slot of a start node
@@ -395,9 +419,9 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
     CSTAMP();
     // slot -> (row, word): y | k << 11
     for (int r = tid; r < nrows; r += T) {
-        const int y = S.rows[r];
-        uint32_t occ = S.rowmask[y];
-        int slot = S.rowbase[y];
+        const int y = RT.rows[r];
+        uint32_t occ = RT.rowmask[y];
+        int slot = RT.rowbase[y];
         while (occ) {
             const int k = __ffs((int)occ) - 1;
             occ &= occ - 1;
@@ -501,7 +525,7 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
         int succ = i;
         const int xs = x + dir_dx(nd), ys = y + dir_dy(nd);
         const int ks = xs >> 6, bs = xs & 63;
-        bool ok = xs >= 0 && ys >= 0 && ys < h && ks < ww && ((S.rowmask[ys] >> ks) & 1u);
+        bool ok = xs >= 0 && ys >= 0 && ys < h && ks < ww && ((RT.rowmask[ys] >> ks) & 1u);
         int slot2 = 0;
         if (ok) {
             slot2 = LS.slot(ys, ks);
@@ -654,7 +678,7 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const uint64_t* __r
             if (!S.kacc[e]) continue;
             const uint32_t key = S.kkey[e];
             const int x0 = (int)(key & 0xFFFFu), y0 = (int)(key >> 16);
-            const uint32_t occ = S.rowmask[y0];
+            const uint32_t occ = RT.rowmask[y0];
             int k = x0 >> 6;
             unsigned long long l = S.lab[LS.slot(y0, k)] & ((1ull << (x0 & 63)) - 1);
             uint32_t left = occ & ((1u << k) - 1u);
@@ -807,11 +831,11 @@ __device__ __forceinline__ int wg_scan_excl(int* scan, int tid, int v, int* tota
 // findContours of one frame on the mid tier.  On success (no FL in S.flags): points, cs[rank], cl[rank] (discovery order) are
 // written, *nc_out / *np_out hold the counts.  FL is OR-ed into S.flags when the frame is beyond this tier too.
 template <int T>
-__device__ __forceinline__ void cycles_frame_mid(ContoursLds& S, const MidTables& M, const uint64_t* __restrict__ F, int prow, int h, int ww, int nrows,
+__device__ __forceinline__ void cycles_frame_mid(ContoursLds& S, const RowTabs& RT, const MidTables& M, const uint64_t* __restrict__ F, int prow, int h, int ww, int nrows,
                                  int tid, rmcv_point* __restrict__ pts, int32_t* __restrict__ cs, int32_t* __restrict__ cl,
                                  int max_points, int max_contours, int FL, int* nc_out, int* np_out)
 {
-    const LabelStore LS = {S.rowmask, S.rowbase, nullptr, nullptr};
+    const LabelStore LS = {RT.rowmask, RT.rowbase, nullptr, nullptr};
 #ifdef RMCV_PROFILE
     long long tm_[12]; int tmi_ = 0;
 #define MSTAMP() do { __syncthreads(); if (tmi_ < 12) tm_[tmi_++] = wall_clock64(); } while (0)
@@ -830,9 +854,9 @@ __device__ __forceinline__ void cycles_frame_mid(ContoursLds& S, const MidTables
     __syncthreads();
     // slot -> (row, word)
     for (int r = tid; r < nrows; r += T) {
-        const int y = S.rows[r];
-        uint32_t occ = S.rowmask[y];
-        int slot = S.rowbase[y];
+        const int y = RT.rows[r];
+        uint32_t occ = RT.rowmask[y];
+        int slot = RT.rowbase[y];
         while (occ) {
             const int k = __ffs((int)occ) - 1;
             occ &= occ - 1;
@@ -965,7 +989,7 @@ __device__ __forceinline__ void cycles_frame_mid(ContoursLds& S, const MidTables
             const int x = (int)(p[u] & 0xFFFu), y = (int)((p[u] >> 12) & 0xFFFu), nd = (int)(p[u] >> 29);
             const int xs = x + dir_dx(nd), ys = y + dir_dy(nd);
             const int ks = xs >> 6;
-            ok[u] = i0 + u * T < nn && xs >= 0 && ys >= 0 && ys < h && ks < ww && ((S.rowmask[ys < h && ys >= 0 ? ys : 0] >> ks) & 1u);
+            ok[u] = i0 + u * T < nn && xs >= 0 && ys >= 0 && ys < h && ks < ww && ((RT.rowmask[ys < h && ys >= 0 ? ys : 0] >> ks) & 1u);
             slot2[u] = ok[u] ? LS.slot(ys, ks) : 0;
             B2[u] = M.bmask[slot2[u]];
             E2[u] = M.e2[slot2[u]];
@@ -1232,7 +1256,7 @@ __device__ __forceinline__ void cycles_frame_mid(ContoursLds& S, const MidTables
                 kk[u] = x0 >> 6;
                 // (the labels were OR-ed in by L2 atomics: read them past the vector L1, like the literal scanner does)
                 l[u] = ka[u] ? (ld_l2(M.lab + LS.slot(y0, kk[u])) & ((1ull << (x0 & 63)) - 1)) : 0ull;
-                left[u] = ka[u] ? (S.rowmask[y0] & ((1u << kk[u]) - 1u)) : 0u;
+                left[u] = ka[u] ? (RT.rowmask[y0] & ((1u << kk[u]) - 1u)) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -1341,10 +1365,10 @@ __device__ __forceinline__ void cycles_frame_mid(ContoursLds& S, const MidTables
     // ---- V2 on the final labels: every unlabelled run start would have been rejected by the scanner (nearest labelled pixel to
     // its left positive).  (V1 -- every accepted start acceptable -- is what the last round of M7 established.)
     for (int r = tid; r < nrows; r += T) {
-        const int y = S.rows[r];
+        const int y = RT.rows[r];
         const int64_t base = (int64_t)(y + 1) * prow + 1;
-        uint32_t rem = S.rowmask[y];
-        int slot = S.rowbase[y];
+        uint32_t rem = RT.rowmask[y];
+        int slot = RT.rowbase[y];
         uint64_t carry = 0;
         bool last_pos = false;
         int kprev = -2;

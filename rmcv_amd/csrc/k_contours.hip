@@ -50,16 +50,16 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
     static bool attr_set[MAX_DEVICES] = {}; // hipFuncSetAttribute applies to the current device only (a process may drive several)
     if (!attr_set[g.device]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_w8), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(ContoursLds));
+                                           (int)lds_bytes(CT_MAXH));
         if (e != hipSuccess) return e;
         attr_set[g.device] = true;
     }
     const int force = force_literal ? force_literal : g.contour_tier;
     if (waves == 4) return launch_contours_w4(g, b, lim, X, force, Q, grid, s);
-    return launch(k_contours_w8, dim3(grid), dim3(512), sizeof(ContoursLds), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
+    return launch(k_contours_w8, dim3(grid), dim3(512), lds_bytes(g.h), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
                        g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
                        lim.max_contours, lim.max_points, force, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy, b.mid, b.mid_stride,
-                       b.mid_slot_cap, Q);
+                       b.mid_slot_cap, Q, lds_rows_cap(g.h));
 }
 
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, uint32_t wait_seq, hipStream_t s)
