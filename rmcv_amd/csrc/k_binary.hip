@@ -488,6 +488,9 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     // Leaving: this workgroup has drawn its last index.  strip_ctr[8] counts the leavers; the last one of the launch knows that
     // nobody will draw again and zeroes the eight heads and the count for the next launch (launches of one context are ordered:
     // rmcv_host.hip chains them with an event when the caller changes streams).
+#ifdef RMCV_PROFILE_HANDOVER
+    if (tid == 0) printf("[kbx] %d %lld\n", xcd, (long long)wall_clock64()); // when this workgroup left: the XCDs' tails
+#endif
     if (tid < 64) {
         int left = 0;
         if (tid == 0) left = atomicAdd(&strip_ctr[8], 1);
