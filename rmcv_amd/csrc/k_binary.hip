@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     if (ww <= 32 && tid < sr && y0 + tid < h) {
         uint32_t m = 0;
         for (int k = 0; k < ww; k++) m |= (uint32_t)(R[(tid + halo) * ww + k] != 0) << k;
-        __hip_atomic_store(&rowmask[(int64_t)f * h + y0 + tid], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1, like the plane words)
+        if (frame_ready) __hip_atomic_store(&rowmask[(int64_t)f * h + y0 + tid], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1, like the plane words)
+        else rowmask[(int64_t)f * h + y0 + tid] = m;
     }
     // ---------------- phase 4: expand to bytes + bit plane
     if (FAST) {
@@ -430,8 +431,12 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                 const bool ok = it < nw && y < h;
                 uint64_t word = 0;
                 if (ok) word = R[__umul24(s_ + halo, ww) + k];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane,
-                                                      ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB, 0, RMCV_K1_PLAUX);
+                // written through (sc1) only when this launch publishes per-frame progress (the consumer may then read the words
+                // from another XCD while the launch still runs); otherwise plain: the sparse kernel of the same batch finds them
+                // in L2 (same-box A/B of the whole bench: plain is 0-4 % faster, tools/ab_r3_pl.sh)
+                const uint32_t po = ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB;
+                if (frame_ready) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, RMCV_K1_PLAUX);
+                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, 0);
                 k += k_step;
                 s_ += s_step;
                 if (k >= ww) { k -= ww; s_++; }
@@ -475,7 +480,10 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                         if (x < w) bin[(int64_t)y * w + x] = ((m >> p) & 1) ? 255 : 0;
                     }
                 }
-                if ((q & 3) == 0) __hip_atomic_store(&plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1)
+                if ((q & 3) == 0) {
+                    if (frame_ready) __hip_atomic_store(&plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1)
+                    else plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)] = word;
+                }
             }
             s += dr;
             q += dq;
@@ -503,7 +511,8 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
 }
 
 template <int CA, int CB>
-static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, int groups, uint32_t seq, hipStream_t s)
+static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, int groups, uint32_t seq, bool publish,
+                                  hipStream_t s)
 {
     const int strips = (g.h + SR - 1) / SR;
     int lb = lower_bound, all_pass = 0;
@@ -559,7 +568,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
 #define RMCV_K1_LAUNCH(F)                                                                                                          \
     launch(k_binary<CA, CB, F>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
            morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail,               \
-           (b.frame_ready && !nopub) ? b.frame_ready + f0 : nullptr, seq, nopub ? nullptr : b.started)
+           (b.frame_ready && publish && !nopub) ? b.frame_ready + f0 : nullptr, seq, (publish && !nopub) ? b.started : nullptr)
         const hipError_t e = fast ? RMCV_K1_LAUNCH(true) : RMCV_K1_LAUNCH(false);
 #undef RMCV_K1_LAUNCH
         if (e != hipSuccess) return e;
@@ -578,12 +587,13 @@ int binary_launches(const Geom& g, const Bufs& b)
     return (g.n_frames + chunk - 1) / chunk;
 }
 
-hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, hipStream_t s)
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, bool publish,
+                         hipStream_t s)
 {
     // imgproc.cpp:56-65: GUIDELIGHT G-R; BLUE B-R; everything else (RED, NEUTRAL) R-B.  BGR byte order.
-    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, groups, seq, s);
-    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, groups, seq, s);
-    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, groups, seq, s);
+    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, groups, seq, publish, s);
+    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, groups, seq, publish, s);
+    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, groups, seq, publish, s);
 }
 
 // binary (0 / non-zero bytes) -> padded bit plane; used when a caller hands in its own binary image

@@ -463,9 +463,10 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
             c->pre_binary_valid = true;
         }
         if (forked) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pre_binary, 0), "hand-over: fork");
-        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->launch_id + 1, s), "k_binary");
+        const bool publish = c->handover != 0;
+        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->launch_id + 1, publish, s), "k_binary");
         c->launch_id++;  // (counted once the launch is accepted: the device's words and these counters move together)
-        c->binary_seq++;
+        if (publish) c->binary_seq++;
         HT();
     }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
@@ -1071,9 +1072,8 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     const Geom& g = c->geom;
     const Bufs& b = c->bufs;
     hipStream_t s = c->stream;
-    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, c->launch_id + 1, s), "k_binary");
+    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, c->launch_id + 1, false, s), "k_binary");
     c->launch_id++;
-    c->binary_seq++;
     if (binary_out) HIPCHK(c, hipEventRecord(c->ev_fork, s), "image download: mark");
     // running ahead with both parameter sets known: the frame's whole sparse part is ONE kernel (the fused per-frame kernel of
     // the batch path: findContours, fits and pairing back to back), not three

@@ -128,8 +128,10 @@ hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const r
 hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, bool identity, int waves, uint32_t wait_seq,
                          hipStream_t s);
 hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
-// seq: the label this launch publishes its per-frame progress under (Bufs::frame_ready)
-hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, hipStream_t s);
+// publish: the launch adds its finished rows to Bufs::frame_ready, writes plane words and row masks through (sc1) and says under
+// label `seq` when it runs (Bufs::started) -- what the frame-level hand-over needs; without it the stores are plain
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, bool publish,
+                         hipStream_t s);
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, uint32_t wait_seq, hipStream_t s);
 int binary_launches(const Geom& g, const Bufs& b); // launches launch_binary makes for this geometry (> 1: no frame-level hand-over)
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
