@@ -99,7 +99,7 @@ static constexpr int RSRC3 = 0x00020000;     // raw buffer descriptor word 3, gf
 // Register budget: 6 waves per SIMD = at most 80 VGPRs.  Two launches of consecutive batches overlap (2 workgroups per CU each = 4
 // waves per SIMD) next to one wave of the 4-wavefront sparse kernel (168 VGPRs): 4 x 80 + 168 <= 512.  At 88 the sparse kernel
 // would no longer fit beside them and the batches in flight would take turns instead of sharing the CUs.
-template <int CA, int CB, bool FAST>
+template <int CA, int CB, bool FAST, bool PUB>
 __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride, int n_frames,
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     // being placed).  ONE workgroup says so (the word lives in host-visible signal memory: when all 768 workgroups of a launch
     // stored to it, the burst of system-scope stores held up the sparse kernel's own start by 0.2 us per store -- 60 / 108 / 175 us
     // at 1 / 2 / 3 workgroups per CU); workgroup 0 is among the first the dispatcher places.
-    if (started && threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(started, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (PUB && started && threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(started, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef RMCV_PROFILE_HANDOVER
     if (blockIdx.x == 0 && threadIdx.x == 0) printf("[kb start] %lld\n", (long long)wall_clock64());
 #endif
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
     __syncthreads(); // also: the LDS planes of the previous strip are free
-    if (frame_ready && pub_f >= 0 && tid == 0) {
+    if (PUB && frame_ready && pub_f >= 0 && tid == 0) {
         // A fire-and-forget add: nothing waits for its result (its acknowledgement is awaited together with the ticket fetch below).
         // Two earlier forms were measured and dropped: a release FENCE before the add -- at agent scope that is an L2 write-back
         // (buffer_wbl2), per strip, 8192 times a launch: the kernel ran 12 x slower --, and a load + compare-and-swap that
@@ -208,21 +208,10 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
         // wave-uniform: its address arithmetic runs on the scalar unit.
         const int lane = tid & 63;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int nb = (w + 255) >> 8, nq = (srh + 3) >> 2;
-        // A row whose last 256-pixel block is at most half full (1920 = 7.5 blocks: BASELINE config 5) does not spend a whole
-        // wavefront on it per row quad: TWO row quads share one item, lanes 0..31 taking the block's pixels of the first, lanes
-        // 32..63 those of the second (6.7 % fewer load instructions at 1920, none of them half empty).
-        const int rem = w & 255;                              // pixels in the ragged last block (0: every block is full)
-        const bool packed = rem != 0 && rem <= 128;
-        const int nbf = packed ? nb - 1 : nb;                 // blocks handled one row quad per item
-        const int n_full = nq * nbf, n_it = n_full + (packed ? (nq + 1) >> 1 : 0);
-        const uint32_t r_nb = (uint32_t)((0x100000000ull + nbf - 1) / (nbf > 0 ? nbf : 1));
+        const int nb = (w + 255) >> 8, nq = (srh + 3) >> 2, n_it = nq * nb;
+        const uint32_t r_nb = (uint32_t)((0x100000000ull + nb - 1) / nb);
         const uint32_t lane_off = (uint32_t)lane * 12u;
         const uint32_t lds_lane = (uint32_t)__umul24(lane & 3, ww) * 8u + (uint32_t)(lane >> 2) * 2u;
-        // the same for a lane of a packed item: pixel group (lane & 31), row quad selected by lane >> 5
-        const uint32_t lane_off_p = (uint32_t)(lane & 31) * 12u;
-        const uint32_t lds_lane_p = (uint32_t)__umul24(lane & 3, ww) * 8u + (uint32_t)((lane & 31) >> 2) * 2u;
-        const bool hi_half = lane >= 32;
         const uint32_t M1 = (lane & 1) ? 0xF0F0u : 0x0F0Fu, S1 = (lane & 1) ? 12u : 4u;
         const uint32_t P2 = (lane & 2) ? 0x0c0c0105u : 0x0c0c0400u;
         constexpr uint32_t OOB_S = 0xFFFFFC00u; // scalar part of an offset that moves nothing (+ 63 * 12 stays out of extent)
@@ -245,22 +234,18 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
         } else
         for (int it0 = wv; it0 < n_it; it0 += 4 * U) {
             // One batch = U items of the wave: all 4 * U loads are issued, then thresholded.  CHK = false is the common case (a strip
-            // with every row inside the image, whole row quads, a full batch of one-quad items): no validity selects.
+            // with every row inside the image, whole row quads, a full batch): no validity selects.
             auto batch = [&](auto chk) {
                 constexpr bool CHK = decltype(chk)::value;
                 u32x3v v[U][4];
-                int info[U]; // LDS byte offset of the item's (row quad, block) | ragged-block flag | packed flag << 1; -1: beyond the strip's items
-                int qd[U];   // packed items: row quads from the first half's to the second half's (+1 / -1; 0: there is no second)
+                int info[U]; // LDS byte offset of the item's (row quad, block) | ragged-block flag; -1: beyond the strip's items
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const int it = it0 + 4 * u; // wave-uniform: everything up to the four vector adds runs on the scalar unit
-                    const bool pk = CHK && it >= n_full; // (packed items always take the checked form)
-                    const int itp = it - n_full;
-                    const int jq0 = pk ? 2 * itp : div_r(it, r_nb), b = pk ? nb - 1 : it - jq0 * nbf;
+                    const int jq0 = div_r(it, r_nb), b = it - jq0 * nb;
                     const int jq = (L & 1) ? jq0 : nq - 1 - jq0; // sweep direction, see below
-                    qd[u] = (pk && 2 * itp + 1 < nq) ? ((L & 1) ? 1 : -1) : 0;
                     const int rr0 = 4 * jq;
-                    info[u] = (int)(__umul24(rr0, ww) * 8u + (uint32_t)b * 32u) | (b == nb - 1 ? ragged : 0) | (pk ? 2 : 0); // bit 0: ragged block
+                    info[u] = (int)(__umul24(rr0, ww) * 8u + (uint32_t)b * 32u) | (b == nb - 1 ? ragged : 0); // bit 0: ragged block
                     if (CHK && it >= n_it) info[u] = -1;
 #ifdef RMCV_K1_NOLOAD
                     const uint32_t base = OOB_S - dk3; // ablation build: nothing is read
@@ -271,23 +256,12 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                     uint32_t vo[4];
                     // rows rr_lo <= rr < rr_hi of the strip are inside the image; the others (and a whole item beyond the
                     // strip's) are "loaded" from beyond the extent: zeros, no traffic
-                    const uint32_t span = it < n_it ? rr_span : 0u;
-                    if (pk) { // the second half's rows lie one row quad further (in the sweep's direction); a lane beyond the row's
-                              // pixels, or in a half without a row quad, loads nothing
-                        const int q4 = hi_half ? 4 * qd[u] : 0;
-                        const bool live = (lane & 31) * 4 < rem && (!hi_half || qd[u] != 0);
-                        const uint32_t t0 = (uint32_t)(rr0 + q4 - rr_lo);
-                        const uint32_t shift = (uint32_t)(q4 * stride);
+                    const uint32_t t0 = (uint32_t)(rr0 - rr_lo), span = it < n_it ? rr_span : 0u;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) vo[k] = (live && t0 + (uint32_t)k < span) ? rowk[k] + shift + lane_off_p : OOB_S + lane_off;
-                    } else {
-                        const uint32_t t0 = (uint32_t)(rr0 - rr_lo);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) vo[k] = (!CHK || t0 + (uint32_t)k < span ? rowk[k] : OOB_S) + lane_off;
-                    }
+                    for (int k = 0; k < 4; k++) vo[k] = (!CHK || t0 + (uint32_t)k < span ? rowk[k] : OOB_S) + lane_off;
                     // the first and the last row quad hold the rows this strip shares with its neighbours: those stay
                     // cacheable (the neighbour finds them in L2), everything else is read once and says so
-                    if (halo && (jq == 0 || jq == nq - 1 || (pk && (jq + qd[u] == 0 || jq + qd[u] == nq - 1)))) {
+                    if (halo && (jq == 0 || jq == nq - 1)) {
 #pragma unroll
                         for (int k = 0; k < 4; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b96(r_in, vo[k], 0, 0);
                     } else {
@@ -301,30 +275,21 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                                             v[u][2].x, v[u][2].y, v[u][2].z, v[u][3].x, v[u][3].y, v[u][3].z};
                     uint32_t m = thresh16<CA, CB>(d, lb);
                     const bool last_ragged = (info[u] & 1) != 0; // wave-uniform: the row's last block when w % 256 != 0
-                    const bool pk = CHK && info[u] >= 0 && (info[u] & 2) != 0;
-                    // pixels beyond the row's end: the lane has read the next row's bytes (a packed item's lanes read nothing there)
-                    if (last_ragged && !pk && lane * 4 >= w - ((nb - 1) << 8)) m = 0;
+                    // pixels beyond the row's end: the lane has read the next row's bytes
+                    if (last_ragged && lane * 4 >= w - ((nb - 1) << 8)) m = 0;
                     // 4x4 nibble transpose within the quad: exchange with lane^1 (nibbles), then with lane^2 (bytes)
                     const uint32_t p1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xF, 0xF, true);
                     const uint32_t t1 = (m & M1) | (((p1 << 8) >> S1) & ~M1);
                     const uint32_t p2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)t1, 0x4E, 0xF, 0xF, true);
                     const uint32_t t2 = __builtin_amdgcn_perm(p2, t1, P2);
-                    uint16_t* dst;
-                    if (pk) {
-                        const int q4 = hi_half ? 4 * qd[u] : 0;
-                        dst = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(T) + ((uint32_t)info[u] & ~3u) + (uint32_t)(q4 * ww * 8) + lds_lane_p);
-                        // a quad of lanes whose 16 pixels lie beyond the row, and the half without a row quad: to a spare word
-                        if (((lane & 31) >> 2) * 16 >= rem || (hi_half && qd[u] == 0)) dst = s_spare + tid;
-                    } else {
-                        dst = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(T) + ((uint32_t)info[u] & ~3u) + lds_lane);
-                        if (CHK && info[u] < 0) dst = s_spare + tid; // an item beyond the strip's
-                        // the quad's 16 pixels of the last block may lie beyond the row: those go to a spare word
-                        if (last_ragged && (lane >> 2) * 16 >= w - ((nb - 1) << 8)) dst = s_spare + tid;
-                    }
+                    uint16_t* dst = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(T) + ((uint32_t)info[u] & ~1u) + lds_lane);
+                    if (CHK && info[u] < 0) dst = s_spare + tid; // an item beyond the strip's
+                    // the quad's 16 pixels of the last block may lie beyond the row: those go to a spare word
+                    if (last_ragged && (lane >> 2) * 16 >= w - ((nb - 1) << 8)) dst = s_spare + tid;
                     *dst = (uint16_t)t2;
                 }
             };
-            if (plain && it0 + 4 * (U - 1) < n_full) batch(std::false_type{});
+            if (plain && it0 + 4 * (U - 1) < n_it) batch(std::false_type{});
             else batch(std::true_type{});
         }
     } else {
@@ -415,7 +380,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     if (ww <= 32 && tid < sr && y0 + tid < h) {
         uint32_t m = 0;
         for (int k = 0; k < ww; k++) m |= (uint32_t)(R[(tid + halo) * ww + k] != 0) << k;
-        if (frame_ready) __hip_atomic_store(&rowmask[(int64_t)f * h + y0 + tid], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1, like the plane words)
+        if (PUB) __hip_atomic_store(&rowmask[(int64_t)f * h + y0 + tid], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1, like the plane words)
         else rowmask[(int64_t)f * h + y0 + tid] = m;
     }
     // ---------------- phase 4: expand to bytes + bit plane
@@ -435,8 +400,8 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                 // from another XCD while the launch still runs); otherwise plain: the sparse kernel of the same batch finds them
                 // in L2 (same-box A/B of the whole bench: plain is 0-4 % faster, tools/ab_r3_pl.sh)
                 const uint32_t po = ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB;
-                if (frame_ready) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, RMCV_K1_PLAUX);
-                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, 0);
+                // (PUB is a template parameter: as a run-time branch the two stores cost the 80-register kernel five spilled dwords)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, PUB ? RMCV_K1_PLAUX : 0);
                 k += k_step;
                 s_ += s_step;
                 if (k >= ww) { k -= ww; s_++; }
@@ -481,7 +446,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                     }
                 }
                 if ((q & 3) == 0) {
-                    if (frame_ready) __hip_atomic_store(&plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1)
+                    if (PUB) __hip_atomic_store(&plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1)
                     else plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)] = word;
                 }
             }
@@ -556,20 +521,22 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
         uint64_t* bits = b.bits + (int64_t)f0 * g.plane_pitch;
         uint32_t* rowmask = b.rowmask + (int64_t)f0 * g.h;
         // beyond 64 KiB of dynamic LDS (frames wider than ~6700 pixels) the kernel has to be told; per device and instantiation
-        static size_t lds_set[MAX_DEVICES][2] = {};
-        if (planes > 60 * 1024 && planes > lds_set[g.device][fast ? 1 : 0]) {
-            const hipError_t ea = fast ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_binary<CA, CB, true>),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes)
-                                       : hipFuncSetAttribute(reinterpret_cast<const void*>(k_binary<CA, CB, false>),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes);
+        const bool pub = publish && !nopub && b.frame_ready != nullptr;
+        static size_t lds_set[MAX_DEVICES][4] = {};
+        const int inst = (fast ? 1 : 0) | (pub ? 2 : 0);
+        if (planes > 60 * 1024 && planes > lds_set[g.device][inst]) {
+            const void* fn = fast ? (pub ? reinterpret_cast<const void*>(k_binary<CA, CB, true, true>) : reinterpret_cast<const void*>(k_binary<CA, CB, true, false>))
+                                  : (pub ? reinterpret_cast<const void*>(k_binary<CA, CB, false, true>) : reinterpret_cast<const void*>(k_binary<CA, CB, false, false>));
+            const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes);
             if (ea != hipSuccess) return ea;
-            lds_set[g.device][fast ? 1 : 0] = planes;
+            lds_set[g.device][inst] = planes;
         }
-#define RMCV_K1_LAUNCH(F)                                                                                                          \
-    launch(k_binary<CA, CB, F>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
+#define RMCV_K1_LAUNCH(F, P)                                                                                                          \
+    launch(k_binary<CA, CB, F, P>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
            morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail,               \
-           (b.frame_ready && publish && !nopub) ? b.frame_ready + f0 : nullptr, seq, (publish && !nopub) ? b.started : nullptr)
-        const hipError_t e = fast ? RMCV_K1_LAUNCH(true) : RMCV_K1_LAUNCH(false);
+           pub ? b.frame_ready + f0 : nullptr, seq, pub ? b.started : nullptr)
+        const hipError_t e = fast ? (pub ? RMCV_K1_LAUNCH(true, true) : RMCV_K1_LAUNCH(true, false))
+                                  : (pub ? RMCV_K1_LAUNCH(false, true) : RMCV_K1_LAUNCH(false, false));
 #undef RMCV_K1_LAUNCH
         if (e != hipSuccess) return e;
     }
