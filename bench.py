@@ -536,6 +536,9 @@ def main():
         region = max(100, 5 * args.steps)
         for label, var, one in [("plain", 0, False), ("dense1", 11, False), ("dense2", 12, False), ("dense3", 13, False),
                                 ("dense4", 14, False), ("plain + one dense4 frame per batch", 0, True)]:
+            if os.environ.get("RMCV_BENCH_SWEEP_LEVELS") and label.split()[0] not in os.environ["RMCV_BENCH_SWEEP_LEVELS"].split(",") \
+                    and not (one and "one" in os.environ["RMCV_BENCH_SWEEP_LEVELS"].split(",")):
+                continue                                           # dev knob (tools/ab_r3_one_dense.sh): a subset of the levels
             for k in range(ns):
                 hb = synth.batch(rank * n + k * 1000003, n, W, H, CAMP_BLUE, var, threads=nthreads)
                 if one:
@@ -559,6 +562,24 @@ def main():
                           "frames_over_capacity": int(np.count_nonzero(st_ & 15))})
         out["density_sweep"] = {"steps_per_region": region, "levels": sweep,
                                 "note": "steady-state regions of the bench's own loop (4 batches in flight), rank-0 shard; not the metric"}
+        if not os.environ.get("RMCV_BENCH_SWEEP_LEVELS"):
+            # The dense frame of a batch keeps ONE workgroup busy for 0.5-1 ms after the batch's other frames are through; with 4
+            # batches in flight over 2 sparse streams the launches behind it wait for it.  A deeper schedule -- 8 batches in flight,
+            # a sparse stream each -- hides it (at 2-3 % on the plain stream, which is why it is not the default): the same two levels
+            # under that schedule, in a child process (the schedule is fixed when the streams are created).
+            import subprocess
+            env = dict(os.environ, RMCV_BENCH_SWEEP_LEVELS="plain,one", GPU_MAX_HW_QUEUES="12")
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-frames", "0",
+                   "--no-extras", "--density-sweep", "--streams", "8", "--sparse-streams", "8", "--frames", str(n), "--workload", args.workload]
+            try:
+                cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                dj = json.loads(cp.stdout.strip().splitlines()[-1])
+                out["density_sweep"]["deep_schedule"] = {
+                    "batches_in_flight": 8, "sparse_streams": 8, "gpu_max_hw_queues": 12, "ms_per_step_20_step_regions": dj["ms_per_step"],
+                    "levels": dj["density_sweep"]["levels"],
+                    "note": "the same loop with 8 batches in flight and one sparse stream per batch (child process): one dense frame per batch no longer holds up the launches behind it"}
+            except Exception as e:  # noqa: BLE001 -- a side measurement: report, never fail the bench line
+                out["density_sweep"]["deep_schedule"] = {"error": repr(e)[:200]}
         for k in range(ns):                                        # back to the run's own stream for what follows
             frames_k[k].copy_(torch.from_numpy(host if k == 0 else synth.batch(rank * n + k * 1000003, n, W, H, CAMP_BLUE, args.variant, threads=nthreads)))
         torch.cuda.synchronize()

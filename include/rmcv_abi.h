@@ -166,6 +166,11 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * 0 (default): it starts when the whole pixel kernel is through (RMCV_STAGE_HANDOVER then simply waits for it).  Results are
  * identical; so were the measured step rates, and a lone batch is slower with it -- see DESIGN.md.  Needs hipStreamWaitValue32. */
 #define RMCV_OPT_HANDOVER 6
+/* RMCV_OPT_DENSE_DEFER: 1: with RMCV_OPT_SPARSE_WAVES = 4, a frame beyond the LDS tables of findContours (hundreds of borders:
+ * RMCV_FRAME_MID_PATH) is left to a second launch with 8 wavefronts per frame right behind the first; 0 (default): every frame is
+ * finished by the first launch.  Results are identical.  Measured: worth 14 % where EVERY frame is that dense, costs
+ * 20-30 % where a few frames per batch are (they then run after the others instead of beside them). */
+#define RMCV_OPT_DENSE_DEFER 7
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */

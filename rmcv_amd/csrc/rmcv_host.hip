@@ -219,6 +219,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         c->geom.device = device;
+        c->geom.dense_defer = getenv("RMCV_DENSE_DEFER") ? atoi(getenv("RMCV_DENSE_DEFER")) : 0; // RMCV_OPT_DENSE_DEFER (env: dev A/B knob)
         c->geom.n_cu = (device < MAX_DEVICES && hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
         if (device >= MAX_DEVICES) e = hipErrorInvalidDevice;
     }
@@ -596,6 +597,10 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
     if (option == RMCV_OPT_HANDOVER && (value == 0 || value == 1)) {
         if (value && !c->bufs.started) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_OPT_HANDOVER needs hipStreamWaitValue32 on signal memory, which this device / runtime lacks");
         c->handover = value;
+        return RMCV_OK;
+    }
+    if (option == RMCV_OPT_DENSE_DEFER && (value == 0 || value == 1)) {
+        c->geom.dense_defer = value;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_CONTOUR_TIER && value >= 0 && value <= 2) {

@@ -18,6 +18,7 @@ namespace rmcv {
 struct Geom {
     int device;          // HIP device of the owning context: per-device launch state (function attributes) is indexed by it
     int n_cu;            // compute units of that device (sizes the persistent grid of k_binary)
+    int dense_defer;     // RMCV_OPT_DENSE_DEFER: frames beyond the LDS tables are left to a second launch with 8 wavefronts per frame
     int contour_tier;    // RMCV_OPT_CONTOUR_TIER: 0 = per frame (LDS tables, else mid tier, else literal scanner), 1 = literal, 2 = mid tier
     int n_frames;
     int w, h;
@@ -91,6 +92,10 @@ struct Bufs {
     double* base2gripper;  // [frame][16]
     double* poses;         // [frame][max_armours][9]  rvec | tvec | world position
 };
+
+// internal value of a frame's status word BETWEEN the two launches of the sparse stage (never seen by a caller: the second launch
+// rewrites the word of every frame that carries it)
+#define RMCV_FRAME_DEFERRED_ (1 << 30)
 
 // Frame-level hand-over from k_binary to the per-frame sparse kernel, and the order in which the latter's workgroups take frames.
 struct SparseSched {

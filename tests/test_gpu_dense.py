@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import pytest
 
-from rmcv_amd import (CAMP_BLUE, FRAME_MID_PATH, FRAME_SLOW_PATH, MORPH_NONE, OPT_CONTOUR_TIER, OPT_SPARSE_WAVES, STAGE_ALL, Context,
+from rmcv_amd import (CAMP_BLUE, FRAME_MID_PATH, FRAME_SLOW_PATH, MORPH_NONE, OPT_CONTOUR_TIER, OPT_DENSE_DEFER, OPT_SPARSE_WAVES, STAGE_ALL, Context,
                       default_params, synth)
 
 pytestmark = pytest.mark.gpu
@@ -28,14 +28,15 @@ def compare_batch(c, frames, refs):
     return cnt["status"]
 
 
-@pytest.mark.parametrize("level,waves", [(1, 4), (2, 8), (3, 4), (4, 8), (4, 4)])
-def test_dense_streams_full_batch_every_stage(oracle, level, waves):
+@pytest.mark.parametrize("level,waves,defer", [(1, 4, 0), (2, 8, 0), (3, 4, 0), (4, 8, 0), (4, 4, 0), (1, 4, 1), (4, 4, 1)])
+def test_dense_streams_full_batch_every_stage(oracle, level, waves, defer):
     """256 x 1280x1024 frames of a dense stream through the whole path, every stage of every frame against the oracle; no frame
     may need the sequential scanner, and the levels whose frames exceed the LDS tables must have taken the mid tier"""
     n = 256
     frames = synth.batch(7000 * level, n, 1280, 1024, CAMP_BLUE, 10 + level, threads=16)
     c = Context(device=0, max_frames=n, max_width=1280, max_height=1024, max_contours=4096)
     c.set_option(OPT_SPARSE_WAVES, waves)
+    c.set_option(OPT_DENSE_DEFER, defer)
     c.upload(frames)
     c.run(default_params(), STAGE_ALL)
     c.sync()
@@ -66,12 +67,17 @@ def test_mid_tier_forced_on_the_ordinary_streams(oracle, variant):
     c.close()
 
 
-def test_one_dense_frame_does_not_change_its_neighbours(oracle):
-    """a clean batch with ONE dense frame in the middle: that frame takes the mid tier, the others stay on the LDS tables"""
+@pytest.mark.parametrize("waves,defer", [(8, 1), (4, 1), (4, 0)])
+def test_one_dense_frame_does_not_change_its_neighbours(oracle, waves, defer):
+    """a clean batch with ONE dense frame in the middle: that frame takes the mid tier, the others stay on the LDS tables -- with
+    8 wavefronts per frame, and with 4 both ways: the dense frame left to the second launch (RMCV_OPT_DENSE_DEFER) or finished by
+    the first (the default)"""
     n = 16
     frames = synth.batch(52000, n, 1280, 1024, CAMP_BLUE, 0, threads=16)
     frames[7] = synth.frame(52007, 1280, 1024, CAMP_BLUE, 14)
     c = Context(device=0, max_frames=n, max_width=1280, max_height=1024)
+    c.set_option(OPT_SPARSE_WAVES, waves)
+    c.set_option(OPT_DENSE_DEFER, defer)
     c.upload(frames)
     c.run(default_params(), STAGE_ALL)
     c.sync()
