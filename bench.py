@@ -261,7 +261,6 @@ def main():
     handover = args.handover or os.environ.get("RMCV_BENCH_HANDOVER", "0") == "1"
     for c in ctxs:
         c.set_option(OPT_HANDOVER, 1 if handover else 0)
-    chain = pipelined and len(sAs) > 1 and os.environ.get("RMCV_BENCH_CHAIN", "0") == "1"
 
     cur_stages = [stages]
 
@@ -280,10 +279,6 @@ def main():
         with torch.cuda.stream(sA):
             if not first_use:
                 sA.wait_event(ev_done[k])
-            if chain and step_no[0] > 1:
-                # tail-to-head: this pixel kernel is let loose when the previous step's (on the other pixel stream) has handed out
-                # its last strip, instead of sharing every CU with it from the start (rmcv_ctx_chain_pixel_kernel)
-                ctxs[k].chain_pixel_kernel(ctxs[(step_no[0] - 2) % ns])
             ctxs[k].run(params, cur_stages[0] & (STAGE_BINARY | STAGE_NO_IMAGE), sA.cuda_stream)
             ev_bin[k].record(sA)
         sB = sBs[k % len(sBs)]

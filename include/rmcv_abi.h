@@ -172,13 +172,6 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * 20-30 % where a few frames per batch are (they then run after the others instead of beside them). */
 #define RMCV_OPT_DENSE_DEFER 7
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
-/* Scheduling hint for callers that keep several batches in flight on several streams (bench.py's pipelined loop): the NEXT pixel
- * kernel `ctx` launches is held, on the stream it is launched on, until the pixel kernel `after` has enqueued LAST is in its tail
- * (its strip queue is empty: what is left are the strips in flight, ~20 us).  Two pixel kernels on two streams then follow each
- * other tail-to-head at full speed instead of sharing every CU from start to end.  Call it AFTER `after`'s run has been enqueued
- * and BEFORE `ctx`'s; it is consumed by that one launch.  No data dependency is expressed or implied (order buffers with events as
- * before); `after` must not be destroyed before the held launch has started.  Needs hipStreamWaitValue64 (else RMCV_ERR_BAD_ARG). */
-int  rmcv_ctx_chain_pixel_kernel(rmcv_ctx* ctx, rmcv_ctx* after);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */
 int  rmcv_ctx_check_guards(rmcv_ctx* ctx, int32_t* n_damaged);

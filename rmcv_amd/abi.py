@@ -44,7 +44,7 @@ FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_
 
 EXPORTS = [
     "rmcv_abi_version", "rmcv_default_params", "rmcv_default_limits", "rmcv_ctx_create", "rmcv_ctx_destroy",
-    "rmcv_last_error", "rmcv_ctx_set_option", "rmcv_ctx_forget_frame_buffer", "rmcv_ctx_check_guards", "rmcv_ctx_chain_pixel_kernel", "rmcv_extract_color", "rmcv_filter_lightblobs", "rmcv_filter_armours", "rmcv_fit_ellipse",
+    "rmcv_last_error", "rmcv_ctx_set_option", "rmcv_ctx_forget_frame_buffer", "rmcv_ctx_check_guards", "rmcv_extract_color", "rmcv_filter_lightblobs", "rmcv_filter_armours", "rmcv_fit_ellipse",
     "rmcv_batch_upload", "rmcv_batch_set_device_frames", "rmcv_batch_run", "rmcv_batch_sync", "rmcv_batch_run_timed",
     "rmcv_batch_counts", "rmcv_batch_get_binary", "rmcv_batch_get_contours", "rmcv_batch_get_blobs",
     "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_batch_compact_armours", "rmcv_synth_frame", "rmcv_synth_checksum",

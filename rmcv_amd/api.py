@@ -110,12 +110,6 @@ class Context:
         """tuning knobs (abi.OPT_SPARSE_WAVES: 8 = latency of a lone batch, 4 = throughput with several batches in flight)"""
         self._chk(lib().rmcv_ctx_set_option(self._h, int(option), int(value)))
 
-    def chain_pixel_kernel(self, after):
-        """this context's NEXT pixel kernel is held on its stream until the pixel kernel `after` (another Context) enqueued last is
-        in its tail -- rmcv_ctx_chain_pixel_kernel: a scheduling hint for pipelined loops, no data dependency"""
-        lib().rmcv_ctx_chain_pixel_kernel.argtypes = [C.c_void_p, C.c_void_p]
-        self._chk(lib().rmcv_ctx_chain_pixel_kernel(self._h, after._h))
-
     def check_guards(self):
         """(number of damaged guard zones around the context's device buffers, description of the first) -- 0 in a correct build"""
         n = C.c_int32(-1)

@@ -105,8 +105,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
                                                  int* __restrict__ strip_ctr, int taper_head, int taper_tail,
-                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq, unsigned* started,
-                                                 unsigned long long* tail_word, unsigned long long tail_id, int tail_at)
+                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq, unsigned* started)
 {
     extern __shared__ uint64_t smem[];
     // "this launch is RUNNING": the stream that carries the sparse kernel of the batch waits for this word (hipStreamWaitValue32,
@@ -175,11 +174,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     // finish up to one strip apart) are a quarter as long.
     const int n_mid = per_xcd - taper_head - taper_tail;
     const int n_queue = 4 * taper_head + n_mid + 4 * taper_tail;
-    if (tid == 0) {
-        const int t = atomicAdd(&strip_ctr[xcd], 1);
-        s_next = t;
-        if (t == tail_at && xcd == 0 && tail_word) __hip_atomic_store(tail_word, tail_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (tid == 0) s_next = atomicAdd(&strip_ctr[xcd], 1);
     __syncthreads();
     const int j = s_next;
     if ((uint32_t)j >= (uint32_t)n_queue) break;
@@ -471,14 +466,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
 #endif
     if (tid < 64) {
         int left = 0;
-        if (tid == 0) {
-            left = atomicAdd(&strip_ctr[8], 1);
-            // "this launch is in its TAIL": the first workgroup to leave found its XCD's queue empty -- what is left of the launch is
-            // the strips in flight, at most one per workgroup (~20 us at 1280x1024).  A pixel kernel of the NEXT batch that was told
-            // to wait for this word (rmcv_ctx_chain_pixel_kernel: hipStreamWaitValue64 on its own stream) is let loose now and fills
-            // the CUs as this launch's workgroups leave them, instead of sharing them with it from the start.  A hint: no data hangs on it.
-            if (left == 0 && tail_word && tail_at < 0) __hip_atomic_store(tail_word, tail_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (tid == 0) left = atomicAdd(&strip_ctr[8], 1);
         left = __builtin_amdgcn_readfirstlane(left);
         if (left == (int)gridDim.x - 1 && tid < 9) atomicExch(&strip_ctr[tid], 0);
 #ifdef RMCV_PROFILE_HANDOVER
@@ -489,7 +477,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
 
 template <int CA, int CB>
 static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, int groups, uint32_t seq, bool publish,
-                                  unsigned long long* tail_word, unsigned long long tail_id, hipStream_t s)
+                                  hipStream_t s)
 {
     const int strips = (g.h + SR - 1) / SR;
     int lb = lower_bound, all_pass = 0;
@@ -510,7 +498,6 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     static const bool nopub = getenv("RMCV_K1_NOPUB") && atoi(getenv("RMCV_K1_NOPUB")); // dev knob: no progress words (no hand-over possible)
     const int bpc = bpc_env > 0 ? bpc_env : groups;
     // tapered queue (see the kernel): 16 strips at the head (one 8-row piece per workgroup of an XCD at 2 per CU) and 32 at the tail
-    static const int tail_lead = getenv("RMCV_K1_TAIL_LEAD") ? atoi(getenv("RMCV_K1_TAIL_LEAD")) : 0; // dev knob: say "tail" that many queue entries of XCD 0 before its end
     static const int taper_on = getenv("RMCV_K1_TAPER") ? atoi(getenv("RMCV_K1_TAPER")) : 0; // dev knob for A/B runs: since the loads
     // became unconditional buffer operations the tapered hand-out no longer pays (0.2672 ms without against 0.2692 ms with, same box)
     for (int f0 = 0; f0 < g.n_frames; f0 += chunk) {
@@ -547,7 +534,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
 #define RMCV_K1_LAUNCH(F, P)                                                                                                          \
     launch(k_binary<CA, CB, F, P>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
            morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail,               \
-           pub ? b.frame_ready + f0 : nullptr, seq, pub ? b.started : nullptr, (f0 + chunk >= g.n_frames) ? tail_word : nullptr, tail_id, tail_lead > 0 ? std::max(0, 4 * taper_head + (per_xcd - taper_head - taper_tail) + 4 * taper_tail - tail_lead) : -1)
+           pub ? b.frame_ready + f0 : nullptr, seq, pub ? b.started : nullptr)
         const hipError_t e = fast ? (pub ? RMCV_K1_LAUNCH(true, true) : RMCV_K1_LAUNCH(true, false))
                                   : (pub ? RMCV_K1_LAUNCH(false, true) : RMCV_K1_LAUNCH(false, false));
 #undef RMCV_K1_LAUNCH
@@ -568,12 +555,12 @@ int binary_launches(const Geom& g, const Bufs& b)
 }
 
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, bool publish,
-                         unsigned long long* tail_word, unsigned long long tail_id, hipStream_t s)
+                         hipStream_t s)
 {
     // imgproc.cpp:56-65: GUIDELIGHT G-R; BLUE B-R; everything else (RED, NEUTRAL) R-B.  BGR byte order.
-    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, groups, seq, publish, tail_word, tail_id, s);
-    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, groups, seq, publish, tail_word, tail_id, s);
-    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, groups, seq, publish, tail_word, tail_id, s);
+    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, groups, seq, publish, s);
+    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, groups, seq, publish, s);
+    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, groups, seq, publish, s);
 }
 
 // binary (0 / non-zero bytes) -> padded bit plane; used when a caller hands in its own binary image

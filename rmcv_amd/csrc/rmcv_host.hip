@@ -69,12 +69,6 @@ struct rmcv_ctx {
     bool binary_enqueued = false;  // a pixel kernel has been enqueued on this geometry
     uint32_t binary_seq = 0;      // k_binary launches since the geometry was bound (frame_ready words: launch L is through with a frame at L * h)
     uint32_t launch_id = 0;       // k_binary launches of this context, never reset: the label the `started` word carries
-    // Chained pixel kernels (rmcv_ctx_chain_pixel_kernel): a launch says when it is in its tail (Bufs::tail carries tail_id, which
-    // never restarts), and the next pixel kernel of a context told to wait for that (chain_*) is held on its stream until then
-    unsigned long long tail_id = 0;
-    unsigned long long* chain_word = nullptr;
-    unsigned long long chain_id = 0;
-    bool chain_armed = false;
     int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
     int pixel_groups = 3;         // RMCV_OPT_PIXEL_GROUPS
     char err[256] = {0};
@@ -172,7 +166,6 @@ void rmcv_ctx_destroy(rmcv_ctx* c)
     if (c->ev_pre_binary) hipEventDestroy(c->ev_pre_binary);
     for (void* p : c->allocs) hipFree(p);
     if (c->bufs.started) hipFree(c->bufs.started);
-    if (c->bufs.tail) hipFree(c->bufs.tail);
     if (c->own_frames) hipFree(c->own_frames);
     for (auto& r : c->registered) hipHostUnregister(const_cast<void*>(r.p));
     for (void* h : {(void*)c->h_frame, (void*)c->h_hdr, (void*)c->h_pts, (void*)c->h_offs, (void*)c->h_blobs,
@@ -274,9 +267,6 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
         if (can && hipExtMallocWithFlags((void**)&b.started, 8, hipMallocSignalMemory) == hipSuccess) {
             if (hipMemset(b.started, 0, 8) != hipSuccess) { hipFree(b.started); b.started = nullptr; }
         } else b.started = nullptr;
-        if (can && hipExtMallocWithFlags((void**)&b.tail, 8, hipMallocSignalMemory) == hipSuccess) {
-            if (hipMemset(b.tail, 0, 8) != hipSuccess) { hipFree(b.tail); b.tail = nullptr; }
-        } else b.tail = nullptr;
         (void)hipGetLastError();
         (void)0; // (without the word RMCV_OPT_HANDOVER = 1 is refused)
     }
@@ -475,14 +465,8 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
         }
         if (forked) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pre_binary, 0), "hand-over: fork");
         const bool publish = c->handover != 0;
-        if (c->chain_armed) { // held until the pixel kernel it was chained to is in its tail (a scheduling hint: no data hangs on it)
-            c->chain_armed = false;
-            HIPCHK(c, hipStreamWaitValue64(s, c->chain_word, c->chain_id, hipStreamWaitValueGte, ~0ull), "chained pixel kernel: wait for the tail of the previous one");
-        }
-        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->launch_id + 1, publish,
-                                b.tail, c->tail_id + 1, s), "k_binary");
+        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->launch_id + 1, publish, s), "k_binary");
         c->launch_id++;  // (counted once the launch is accepted: the device's words and these counters move together)
-        c->tail_id++;
         if (publish) c->binary_seq++;
         HT();
     }
@@ -628,18 +612,6 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         return RMCV_OK;
     }
     return fail(c, RMCV_ERR_BAD_ARG, "unknown option or value");
-}
-
-int rmcv_ctx_chain_pixel_kernel(rmcv_ctx* c, rmcv_ctx* after)
-{
-    if (!c || !after || c == after) return c ? fail(c, RMCV_ERR_BAD_ARG, "chain: needs two different contexts") : RMCV_ERR_BAD_ARG;
-    if (c->device != after->device) return fail(c, RMCV_ERR_BAD_ARG, "chain: the contexts are on different devices");
-    if (!after->bufs.tail) return fail(c, RMCV_ERR_BAD_ARG, "chain: needs hipStreamWaitValue64 on signal memory, which this device / runtime lacks");
-    if (after->tail_id == 0) { c->chain_armed = false; return RMCV_OK; } // nothing to wait for yet
-    c->chain_word = after->bufs.tail;
-    c->chain_id = after->tail_id;
-    c->chain_armed = true;
-    return RMCV_OK;
 }
 
 int rmcv_ctx_check_guards(rmcv_ctx* c, int32_t* n_damaged)
@@ -1105,7 +1077,7 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     const Geom& g = c->geom;
     const Bufs& b = c->bufs;
     hipStream_t s = c->stream;
-    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, c->launch_id + 1, false, nullptr, 0, s), "k_binary");
+    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, c->launch_id + 1, false, s), "k_binary");
     c->launch_id++;
     if (binary_out) HIPCHK(c, hipEventRecord(c->ev_fork, s), "image download: mark");
     // running ahead with both parameter sets known: the frame's whole sparse part is ONE kernel (the fused per-frame kernel of

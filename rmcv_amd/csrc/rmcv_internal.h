@@ -79,7 +79,6 @@ struct Bufs {
     int32_t* status;       // [frame] RMCV_FRAME_* bits
     int32_t* frame_order;  // [frame] the frames in k_binary's completion order, interleaved over the XCDs (SparseSched::order)
     unsigned long long* frame_ready; // [frame] k_binary's per-frame progress: rows finished, summed over the launches since set_geom
-    unsigned long long* tail; // signal memory: the number of the last k_binary launch of this context that has reached its tail (hipStreamWaitValue64 target)
     unsigned* started;     // signal memory: the label of the k_binary launch that has started running (hipStreamWaitValue32 target)
     // icon classifier (BASELINE config 5); allocated by rmcv_svm_load
     float* svm_w;          // [n_df][1200]
@@ -136,9 +135,8 @@ hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const 
 hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 // publish: the launch adds its finished rows to Bufs::frame_ready, writes plane words and row masks through (sc1) and says under
 // label `seq` when it runs (Bufs::started) -- what the frame-level hand-over needs; without it the stores are plain
-// tail_word / tail_id: the launch stores tail_id to tail_word (signal memory, may be null) when its first workgroup finds the queue empty
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, bool publish,
-                         unsigned long long* tail_word, unsigned long long tail_id, hipStream_t s);
+                         hipStream_t s);
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, uint32_t wait_seq, hipStream_t s);
 int binary_launches(const Geom& g, const Bufs& b); // launches launch_binary makes for this geometry (> 1: no frame-level hand-over)
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
