@@ -459,23 +459,35 @@ __device__ inline void eigen_nonsymmetric3(const double M[3][3], double eval[3],
 }
 
 // ---- symmetric k x k cyclic Jacobi + normal-equation least squares (general-fit fallback) --------
-__device__ inline void jacobi_sym(LaneVec& A, int k, LaneVec& lam, LaneVec& V)
+// K is a compile-time constant and the loops over p, q, r are unrolled: every subscript is a constant lane (v_readlane with an
+// immediate, a select against a constant mask), no subscript arithmetic.  Operations and their order are unchanged, and so is the
+// time (14-17 us of a general fit's 33 for K = 5, measured before and after): the sweep is a chain of dependent divisions and
+// square roots -- ~6 sweeps x 10 rotations x 5 of them --, not of subscripts.  Kept for the two VGPRs it gives back.
+template <int K>
+__device__ __forceinline__ void jacobi_sym(LaneVec& A, LaneVec& lam, LaneVec& V)
 {
-    for (int i = 0; i < k; i++)
-        for (int j = 0; j < k; j++) V[i * k + j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < K; i++)
+#pragma unroll
+        for (int j = 0; j < K; j++) V[i * K + j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
     for (int sweep = 0; sweep < 60; sweep++) {
         double off = 0.0;
-        for (int p = 0; p < k; p++)
-            for (int q = p + 1; q < k; q++) off += dabs(A[p * k + q]);
+#pragma unroll
+        for (int p = 0; p < K; p++)
+#pragma unroll
+            for (int q = p + 1; q < K; q++) off += dabs(A[p * K + q]);
         if (off == 0.0) break;
-        for (int p = 0; p < k; p++)
-            for (int q = p + 1; q < k; q++) {
-                double apq = A[p * k + q];
+#pragma unroll
+        for (int p = 0; p < K; p++)
+#pragma unroll
+            for (int q = p + 1; q < K; q++) {
+                double apq = A[p * K + q];
                 if (apq == 0.0) continue;
-                double app = A[p * k + p], aqq = A[q * k + q];
+                double app = A[p * K + p], aqq = A[q * K + q];
                 if (dabs(apq) < 1e-300 || dabs(apq) <= 1.1102230246251565e-16 * 1e-3 * dsqrt(dabs(app * aqq))) {
-                    A[p * k + q] = 0.0;
-                    A[q * k + p] = 0.0;
+                    A[p * K + q] = 0.0;
+                    A[q * K + p] = 0.0;
                     continue;
                 }
                 double theta = (aqq - app) / (2.0 * apq);
@@ -483,27 +495,29 @@ __device__ inline void jacobi_sym(LaneVec& A, int k, LaneVec& lam, LaneVec& V)
                 if (theta < 0) t = -t;
                 double c = 1.0 / dsqrt(t * t + 1.0);
                 double s = t * c;
-                A[p * k + p] = app - t * apq;
-                A[q * k + q] = aqq + t * apq;
-                A[p * k + q] = 0.0;
-                A[q * k + p] = 0.0;
-                for (int r = 0; r < k; r++) {
+                A[p * K + p] = app - t * apq;
+                A[q * K + q] = aqq + t * apq;
+                A[p * K + q] = 0.0;
+                A[q * K + p] = 0.0;
+#pragma unroll
+                for (int r = 0; r < K; r++) {
                     if (r != p && r != q) {
-                        double arp = A[r * k + p], arq = A[r * k + q];
+                        double arp = A[r * K + p], arq = A[r * K + q];
                         double nrp = c * arp - s * arq;
                         double nrq = s * arp + c * arq;
-                        A[r * k + p] = nrp;
-                        A[p * k + r] = nrp;
-                        A[r * k + q] = nrq;
-                        A[q * k + r] = nrq;
+                        A[r * K + p] = nrp;
+                        A[p * K + r] = nrp;
+                        A[r * K + q] = nrq;
+                        A[q * K + r] = nrq;
                     }
-                    double vrp = V[r * k + p], vrq = V[r * k + q];
-                    V[r * k + p] = c * vrp - s * vrq;
-                    V[r * k + q] = s * vrp + c * vrq;
+                    double vrp = V[r * K + p], vrq = V[r * K + q];
+                    V[r * K + p] = c * vrp - s * vrq;
+                    V[r * K + q] = s * vrp + c * vrq;
                 }
             }
     }
-    for (int i = 0; i < k; i++) lam[i] = (double)A[i * k + i];
+#pragma unroll
+    for (int i = 0; i < K; i++) lam[i] = (double)A[i * K + i];
 }
 
 // Least squares through the normal equations, device twin of oracle/rmcv_oracle.c normal_factor / normal_apply: the Jacobi
@@ -515,13 +529,15 @@ struct NormalFac {
     __device__ __forceinline__ explicit NormalFac(int lane) : lam(lane), V(lane), k(0), use(0) {}
 };
 
-// A: k x k in lanes 0..k*k-1 (destroyed); wmax / wmin: the extreme singular values of the design matrix
-__device__ inline void normal_factor(LaneVec& A, int k, NormalFac& F, double* wmax, double* wmin)
+// A: K x K in lanes 0..K*K-1 (destroyed); wmax / wmin: the extreme singular values of the design matrix
+template <int K>
+__device__ __forceinline__ void normal_factor(LaneVec& A, NormalFac& F, double* wmax, double* wmin)
 {
-    F.k = k;
-    jacobi_sym(A, k, F.lam, F.V);
+    F.k = K;
+    jacobi_sym<K>(A, F.lam, F.V);
     double wsum = 0, mx = 0, mn = 0;
-    for (int i = 0; i < k; i++) {
+#pragma unroll
+    for (int i = 0; i < K; i++) {
         const double li = F.lam[i];
         const double wi = li > 0 ? dsqrt(li) : 0.0;
         wsum += wi;
@@ -530,7 +546,8 @@ __device__ inline void normal_factor(LaneVec& A, int k, NormalFac& F, double* wm
     }
     const double thr = 2.0 * DBL_EPSILON * wsum;
     F.use = 0;
-    for (int i = 0; i < k; i++) {
+#pragma unroll
+    for (int i = 0; i < K; i++) {
         const double li = F.lam[i];
         const double wi = li > 0 ? dsqrt(li) : 0.0;
         F.use |= (wi > thr ? 1 : 0) << i;
@@ -539,21 +556,25 @@ __device__ inline void normal_factor(LaneVec& A, int k, NormalFac& F, double* wm
     *wmin = mn;
 }
 
-// x (k <= 5 entries, the rest 0) = pinv(G) g;  g in lanes 0..k-1 of g.reg
-__device__ inline void normal_apply(NormalFac& F, LaneVec& g, double* x, int lane)
+// x (K <= 5 entries, the rest 0) = pinv(G) g;  g in lanes 0..K-1 of g.reg
+template <int K>
+__device__ __forceinline__ void normal_apply(NormalFac& F, LaneVec& g, double* x, int lane)
 {
-    const int k = F.k;
     LaneVec xs(lane);
-    for (int i = 0; i < k; i++) xs[i] = 0.0;
-    for (int c = 0; c < k; c++) {
+#pragma unroll
+    for (int i = 0; i < K; i++) xs[i] = 0.0;
+#pragma unroll
+    for (int c = 0; c < K; c++) {
         if (!((F.use >> c) & 1)) continue;
         double dot = 0.0;
-        for (int r = 0; r < k; r++) dot += (double)F.V[r * k + c] * (double)g[r];
+#pragma unroll
+        for (int r = 0; r < K; r++) dot += (double)F.V[r * K + c] * (double)g[r];
         dot = dot / (double)F.lam[c];
-        for (int r = 0; r < k; r++) xs[r] += dot * (double)F.V[r * k + c];
+#pragma unroll
+        for (int r = 0; r < K; r++) xs[r] += dot * (double)F.V[r * K + c];
     }
 #pragma unroll
-    for (int i = 0; i < 5; i++) x[i] = i < k ? xs.get(i) : 0.0;
+    for (int i = 0; i < 5; i++) x[i] = i < K ? xs.get(i) : 0.0;
 }
 
 __device__ __forceinline__ void get_ofs(int i, float eps, float* ox, float* oy)

@@ -167,7 +167,7 @@ __device__ __forceinline__ void normal_refine(NormalFac& Fac, int n, int lane, d
 #pragma unroll
         for (int a = 0; a < K; a++) h.reg = lane == a ? acc[a] : h.reg;
         double dx[5];
-        normal_apply(Fac, h, dx, lane);
+        normal_apply<K>(Fac, h, dx, lane);
 #pragma unroll
         for (int a = 0; a < K; a++) xv.reg = lane == a ? xs[a] + dx[a] : xv.reg;
     }
@@ -281,13 +281,13 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
             FSTAMP(9);
             NormalFac Fac(lane);
             double wmax, wmin;
-            normal_factor(G, 5, Fac, &wmax, &wmin);
+            normal_factor<5>(G, Fac, &wmax, &wmin);
             FSTAMP(10);
             if (iter == 0 && wmax * FLT_EPSILON > wmin) {
                 eps = (float)(s / (n * 2) * 1e-3);
                 continue;
             }
-            normal_apply(Fac, g, gfp, lane);
+            normal_apply<5>(Fac, g, gfp, lane);
             FSTAMP(11);
             normal_refine<5>(Fac, n, lane, 10000.0, gfp, row5);
             break;
@@ -324,8 +324,8 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
         FSTAMP(5);
         NormalFac Fac(lane);
         double wmax3, wmin3;
-        normal_factor(G, 3, Fac, &wmax3, &wmin3);
-        normal_apply(Fac, g, gfp, lane);
+        normal_factor<3>(G, Fac, &wmax3, &wmin3);
+        normal_apply<3>(Fac, g, gfp, lane);
         FSTAMP(12);
         normal_refine<3>(Fac, n, lane, 1.0, gfp, row3);
         FSTAMP(13);
