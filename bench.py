@@ -29,7 +29,19 @@ sys.path.insert(0, ROOT)
 # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A step's kernels must not share a
 # queue with another batch's or with RCCL's stream: the null stream + three batch streams + RCCL's own need five, and with four
 # the gather of every step cost 15 % (736 k against 843 k frames/s, tools/ab_dist.sh).  Read by the HIP runtime at start-up.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+# C5 (1920x1200 + the classifier in the per-frame kernel) has the longer sparse chain and runs 8 batches in flight with a sparse stream
+# each (below): 2 pixel + 8 sparse streams + the null stream + RCCL's.
+def _argv_value(flag, default):
+    for i, a in enumerate(sys.argv):
+        if a == flag and i + 1 < len(sys.argv):
+            return sys.argv[i + 1]
+        if a.startswith(flag + "="):
+            return a.split("=", 1)[1]
+    return default
+
+
+DEEP = _argv_value("--workload", "c3") == "c5"
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12" if DEEP else "6")
 
 FRAMES = 256
 WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200),   # BASELINE.json configs[2] (the metric's config) and configs[4]
@@ -61,20 +73,27 @@ def parse_args(argv=None):
                          "legacy: c3 with rm::FindLightBlobs(fitEllipse=false) as the blob stage")
     ap.add_argument("--pose", action="store_true",
                     help="add the pose stage (rm::solve_PnP + world position per armour, SURVEY 8f-3) to every step")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="contexts (buffer sets) the steps are pipelined over (1 = strictly serial steps)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="contexts (buffer sets) the steps are pipelined over (1 = strictly serial steps); default 4, C5: 8 "
+                         "(tools/ab_r3_c5_deep.sh: 521-555 k frames/s with 4 contexts over 2 sparse streams, 571-573 k with 8 over 8)")
     ap.add_argument("--mode", choices=("pipeline", "alternate"), default="pipeline",
                     help="pipeline (default): the pixel kernels of consecutive steps alternate over --pixel-streams streams, the sparse "
                          "stages run on --sparse-streams higher-priority streams, a step's two halves chained by events; alternate: "
                          "whole steps on one stream per context (round 1's schedule: the same steady state, a longer ramp)")
     ap.add_argument("--pixel-streams", type=int, default=2)
-    ap.add_argument("--sparse-streams", type=int, default=2)
+    ap.add_argument("--sparse-streams", type=int, default=None, help="default 2; C5: one per context")
     ap.add_argument("--gather", choices=("auto", "torch", "abi"), default="auto",
                     help="the armour-list gather of a launched run: torch.distributed.gather (asynchronous; the default for more than "
                          "one rank: rmcv_gather's multi-rank path has not run on hardware yet -- no multi-GPU box was available to this "
                          "build) or rmcv_gather, the C-ABI entry point that calls RCCL itself (what a C++ host uses; the default for a "
                          "launched single rank, where it moves nothing)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    deep = args.workload == "c5"
+    if args.streams is None:
+        args.streams = 8 if deep else 4
+    if args.sparse_streams is None:
+        args.sparse_streams = args.streams if (deep and args.streams > 1) else 2
+    return args
 
 
 VARIANTS = {"plain": 0, "stress": 1, "dense1": 11, "dense2": 12, "dense3": 13, "dense4": 14, "dense": 14}
