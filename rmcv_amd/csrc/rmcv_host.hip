@@ -41,6 +41,11 @@ struct rmcv_ctx {
     uint8_t* h_frame = nullptr;    // pinned staging (lazy): the BGR frame on its way up (RMCV_OPT_FRAME_UPLOAD = 1); small results on their way down:
     size_t h_frame_bytes = 0;
     int32_t* h_hdr = nullptr;      // [16]: contours at 0, blobs at 4, armours at 8
+    // the same pinned buffers as the device addresses them (k_export stores into them); null: not mappable, copies are used
+    int32_t *hd_hdr = nullptr, *hd_offs = nullptr, *hd_blob_src = nullptr, *hd_neg = nullptr;
+    rmcv_point* hd_pts = nullptr;
+    rmcv_lightblob* hd_blobs = nullptr;
+    rmcv_armour* hd_armours = nullptr;
     rmcv_point* h_pts = nullptr;   // [max_points]      the CSR the last rmcv_extract_color returned
     int32_t* h_offs = nullptr;     // [max_contours + 1]
     rmcv_lightblob* h_blobs = nullptr; // [max_blobs]   the positive list the last rmcv_filter_lightblobs returned
@@ -325,6 +330,14 @@ static int ensure_staging(rmcv_ctx* c)
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_armours, (size_t)L.max_armours * sizeof(rmcv_armour), hipHostMallocDefault);
     if (e == hipSuccess) e = dalloc(c, &c->d_hdr, 16);
     if (e != hipSuccess) return fail(c, RMCV_ERR_NOMEM, "pinned staging", e);
+    memset(c->h_hdr, 0, 16 * sizeof(int32_t));
+    if (hipHostGetDevicePointer((void**)&c->hd_hdr, c->h_hdr, 0) != hipSuccess || hipHostGetDevicePointer((void**)&c->hd_pts, c->h_pts, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->hd_offs, c->h_offs, 0) != hipSuccess || hipHostGetDevicePointer((void**)&c->hd_blobs, c->h_blobs, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->hd_blob_src, c->h_blob_src, 0) != hipSuccess || hipHostGetDevicePointer((void**)&c->hd_neg, c->h_neg, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->hd_armours, c->h_armours, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        c->hd_hdr = nullptr; // k_export is not used
+    }
     return RMCV_OK;
 }
 
@@ -952,7 +965,7 @@ static int upload_one(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride,
 }
 
 // the blob stage on frame slot 0 + its results on their way to pinned memory (header at h_hdr[4..6]); no synchronisation
-static int enqueue_blobs(rmcv_ctx* c, const rmcv_ctx::LbParams& q, bool compute = true)
+static int enqueue_blobs(rmcv_ctx* c, const rmcv_ctx::LbParams& q, bool compute = true, bool download = true)
 {
     rmcv_params p;
     rmcv_default_params(&p);
@@ -970,6 +983,7 @@ static int enqueue_blobs(rmcv_ctx* c, const rmcv_ctx::LbParams& q, bool compute 
         HIPCHK(c, launch_status_clear(g1, b, RMCV_FRAME_OVF_BLOBS | RMCV_FRAME_OVF_ARMOURS | RMCV_FRAME_HULL, s), "k_status_clear");
         HIPCHK(c, launch_blobs(g1, b, c->lim, p, s), "k_blobs");
     }
+    if (!download) return RMCV_OK; // (the caller sends everything home with one k_export)
     HIPCHK(c, launch_gather3(b.n_blobs, b.n_neg, b.status, c->d_hdr + 4, s), "k_gather3");
     HIPCHK(c, hipMemcpyAsync(c->h_hdr + 4, c->d_hdr + 4, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
     const int bw = std::min(SF_BLOB_WIN, c->lim.max_blobs), nw = std::min(SF_NEG_WIN, c->lim.max_contours);
@@ -1002,7 +1016,7 @@ static int finish_blobs(rmcv_ctx* c, rmcv_lightblob* blobs_out, int blobs_cap, i
     return RMCV_OK;
 }
 
-static int enqueue_armours(rmcv_ctx* c, const rmcv_ctx::ArParams& q, bool compute = true)
+static int enqueue_armours(rmcv_ctx* c, const rmcv_ctx::ArParams& q, bool compute = true, bool download = true)
 {
     rmcv_params p;
     rmcv_default_params(&p);
@@ -1018,6 +1032,7 @@ static int enqueue_armours(rmcv_ctx* c, const rmcv_ctx::ArParams& q, bool comput
         HIPCHK(c, launch_status_clear(g1, b, RMCV_FRAME_OVF_ARMOURS, s), "k_status_clear");
         HIPCHK(c, launch_armours(g1, b, c->lim, p, s), "k_armours");
     }
+    if (!download) return RMCV_OK;
     HIPCHK(c, launch_gather3(b.n_armours, b.status, b.status, c->d_hdr + 8, s), "k_gather3");
     HIPCHK(c, hipMemcpyAsync(c->h_hdr + 8, c->d_hdr + 8, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
     const int aw = std::min(SF_ARM_WIN, c->lim.max_armours);
@@ -1099,21 +1114,51 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     } else {
         HIPCHK(c, launch_contours(g, b, c->lim, 0, s), "k_contours");
     }
-    HIPCHK(c, launch_pack_contours(g, b, c->lim, c->pack_pts, c->pack_offs, c->d_hdr, s), "k_pack_contours");
-    HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
-    HIPCHK(c, hipMemcpyAsync(c->h_offs, c->pack_offs, (size_t)(std::min(SF_OFFS_WIN, c->lim.max_contours) + 1) * 4, hipMemcpyDeviceToHost, s), "D2H offs");
-    HIPCHK(c, hipMemcpyAsync(c->h_pts, c->pack_pts, (size_t)std::min(SF_PTS_WIN, c->lim.max_points) * sizeof(rmcv_point), hipMemcpyDeviceToHost, s), "D2H pts");
+    // Results go home by kernel stores into the pinned buffers (ExportArgs) instead of a row of small copies -- each of those is a
+    // hand-over from the compute queue to the copy engine and back, 5-8 us apiece, nine of them when the chain runs ahead
+    // (0.256 -> 0.202 ms per chain, tools/frame_chain.py).  When the frame's whole sparse part has run already (fused_ahead) the
+    // kernel that packs the contours does it on its way out; otherwise one k_export behind the last stage.
+    static const bool use_export = !(getenv("RMCV_EXPORT") && atoi(getenv("RMCV_EXPORT")) == 0); // dev knob for A/B runs
+    const bool exporting = use_export && c->hd_hdr != nullptr;
+    const bool will_lb = c->last_lb_valid && c->run_ahead, will_ar = will_lb && c->last_ar_valid;
+    ExportArgs ex;
+    memset(&ex, 0, sizeof(ex));
+    if (exporting) {
+        ex.hdr_dst = c->hd_hdr;
+        ex.hdr_src[0] = c->d_hdr; ex.hdr_src[1] = c->d_hdr + 1; ex.hdr_src[2] = c->d_hdr + 2;
+        ex.sec[ex.n_sec++] = {c->pack_offs, c->hd_offs, c->d_hdr, 1, 4, std::min(SF_OFFS_WIN, c->lim.max_contours) + 1};
+        ex.sec[ex.n_sec++] = {c->pack_pts, c->hd_pts, c->d_hdr + 1, 0, (int)sizeof(rmcv_point), std::min(SF_PTS_WIN, c->lim.max_points)};
+        if (will_lb) {
+            const int bw = std::min(SF_BLOB_WIN, c->lim.max_blobs), nw = std::min(SF_NEG_WIN, c->lim.max_contours);
+            ex.hdr_src[4] = b.n_blobs; ex.hdr_src[5] = b.n_neg; ex.hdr_src[6] = b.status;
+            ex.sec[ex.n_sec++] = {b.blobs, c->hd_blobs, b.n_blobs, 0, (int)sizeof(rmcv_lightblob), bw};
+            ex.sec[ex.n_sec++] = {b.blob_src, c->hd_blob_src, b.n_blobs, 0, 4, bw};
+            ex.sec[ex.n_sec++] = {b.neg_idx, c->hd_neg, b.n_neg, 0, 4, nw};
+        }
+        if (will_ar) {
+            ex.hdr_src[8] = b.n_armours; ex.hdr_src[9] = b.status; ex.hdr_src[10] = b.status;
+            ex.sec[ex.n_sec++] = {b.armours, c->hd_armours, b.n_armours, 0, (int)sizeof(rmcv_armour), std::min(SF_ARM_WIN, c->lim.max_armours)};
+        }
+    }
+    const bool export_in_pack = exporting && fused_ahead; // (fused_ahead: the blobs and armours exist before the contours are packed)
+    HIPCHK(c, launch_pack_contours(g, b, c->lim, c->pack_pts, c->pack_offs, c->d_hdr, s, export_in_pack ? &ex : nullptr), "k_pack_contours");
+    if (!exporting) {
+        HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, 3 * 4, hipMemcpyDeviceToHost, s), "D2H");
+        HIPCHK(c, hipMemcpyAsync(c->h_offs, c->pack_offs, (size_t)(std::min(SF_OFFS_WIN, c->lim.max_contours) + 1) * 4, hipMemcpyDeviceToHost, s), "D2H offs");
+        HIPCHK(c, hipMemcpyAsync(c->h_pts, c->pack_pts, (size_t)std::min(SF_PTS_WIN, c->lim.max_points) * sizeof(rmcv_point), hipMemcpyDeviceToHost, s), "D2H pts");
+    }
     // the byte image goes straight to the caller's buffer (the runtime's pageable path: 37 us for 1.3 MB); through the pinned
     // staging buffer it cost a 65 us CPU copy on top of the DMA
     bool ahead_lb = false, ahead_ar = false;
-    if (c->last_lb_valid && c->run_ahead) { // the filters of this frame, with the previous frame's parameters (see rmcv_ctx::last_lb)
-        if ((rc = enqueue_blobs(c, c->last_lb, !fused_ahead))) return rc;
+    if (will_lb) { // the filters of this frame, with the previous frame's parameters (see rmcv_ctx::last_lb)
+        if ((rc = enqueue_blobs(c, c->last_lb, !fused_ahead, !exporting))) return rc;
         ahead_lb = true;
-        if (c->last_ar_valid) {
-            if ((rc = enqueue_armours(c, c->last_ar, !fused_ahead))) return rc;
+        if (will_ar) {
+            if ((rc = enqueue_armours(c, c->last_ar, !fused_ahead, !exporting))) return rc;
             ahead_ar = true;
         }
     }
+    if (exporting && !export_in_pack) HIPCHK(c, launch_export(ex, s), "k_export");
     // The byte image is complete when k_binary is: its download (1.3 MB, 37 us) runs on the side stream BESIDE the sparse kernels
     // instead of behind them.  Enqueued last: the runtime's pageable copy may keep this thread busy, and by now everything else of
     // the frame is on the GPU's queues.

@@ -149,8 +149,25 @@ hipError_t launch_classify(const Geom& g, const Bufs& b, const Limits& lim, hipS
 // stage-wise helpers: binary (host-supplied 0/255 image) -> bit plane
 hipError_t launch_pack_bits(const Geom& g, const Bufs& b, hipStream_t s);
 // contours in findContours order as CSR (for download); d_offs has max_contours+1 entries per frame
+// The per-frame chain's results on their way to the host in ONE kernel: up to 8 lists (src on the device, dst in pinned host
+// memory mapped into the device's address space) of `count[0] + count_add` elements, clamped to `max_elems`, and up to 12 header
+// words.  Nine small device-to-host copies in a row, each a hand-over to the copy engine, cost the chain 40-60 us; the kernel's
+// own stores cross PCIe as posted writes.
+struct ExportSec {
+    const void* src;
+    void* dst;
+    const int32_t* count; // null: max_elems elements
+    int count_add, elem_bytes, max_elems;
+};
+struct ExportArgs {
+    ExportSec sec[8];
+    int n_sec;
+    const int32_t* hdr_src[12]; // header word i = *hdr_src[i] (null: left alone)
+    int32_t* hdr_dst;
+};
+hipError_t launch_export(const ExportArgs& a, hipStream_t s);
 hipError_t launch_pack_contours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_point* d_pts_out, int32_t* d_offs_out,
-                                int32_t* d_hdr /* nullable: frame 0's {n_contours, n_points, status} */, hipStream_t s);
+                                int32_t* d_hdr /* nullable: frame 0's {n_contours, n_points, status} */, hipStream_t s, const ExportArgs* ex = nullptr); // ex: frame 0's workgroup also exports (one-frame chains)
 hipError_t launch_gather3(const int32_t* a, const int32_t* b, const int32_t* c, int32_t* d_out, hipStream_t s); // d_out[0..2] = *a, *b, *c
 
 } // namespace rmcv
