@@ -650,6 +650,28 @@ def main():
         sf["note"] = ("one %dx%d host frame per call chain, results copied back to host after every call (what rm::extract_color / "
                       "filter_lightblobs / filter_armours return); 60 chains per mode; PCIe-inclusive, never `value`" % (W, H))
         c1.close()
+        # the same chain from a C host (tools/frame_chain.c, compiled here if a C compiler is at hand): what an unchanged C++ caller
+        # sees -- the figures above carry three ctypes calls per frame
+        try:
+            import shutil
+            import subprocess
+            import tempfile
+            cc = shutil.which("gcc") or shutil.which("cc")
+            if cc:
+                exe = os.path.join(tempfile.mkdtemp(prefix="rmcv_fc_"), "frame_chain")
+                libdir = os.path.join(ROOT, "rmcv_amd", "lib")
+                subprocess.run([cc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "frame_chain.c"), "-o", exe,
+                                "-L", libdir, "-lrmcv_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, timeout=120)
+                cp = subprocess.run([exe, str(W), str(H)], capture_output=True, text=True, timeout=120)
+                ch = {}
+                for ln in cp.stdout.splitlines():
+                    w_ = ln.split()
+                    if len(w_) > 6 and w_[1] == "median":
+                        ch[w_[0]] = {"median_ms": float(w_[2]), "min_ms": float(w_[4]), "p90_ms": float(w_[6])}
+                if ch:
+                    sf["c_host"] = dict(ch, note="tools/frame_chain.c: the three C-ABI calls from C, 300 chains per mode")
+        except Exception as e:  # noqa: BLE001 -- a side measurement: report, never fail the bench line
+            sf["c_host"] = {"error": repr(e)[:200]}
         out["single_frame_ms"] = sf
 
     if rank == 0 and world == 1 and args.cpu_frames > 0:
