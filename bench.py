@@ -314,7 +314,8 @@ def main():
                 sB.wait_event(ev_gath[k])                  # the record is rewritten: its previous gather (ns steps back) must be through
             if works[k] is not None:
                 works[k].wait()                            # likewise on the torch path (a stream-side wait on the collective, ns steps old)
-            ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), sB.cuda_stream)
+            if not os.environ.get("RMCV_BENCH_NO_COMPACT"):       # (dev knob: what the compaction kernel costs the chain; not the metric)
+                ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), sB.cuda_stream)
             # the context's buffers are free once its list is compacted: the gather only reads the record, so the pixel kernel
             # that reuses this context does not wait for the collective (it would lengthen the chain the step rate hangs on)
             ev_done[k].record(sB)
