@@ -186,7 +186,12 @@ def main():
     # every batch in flight has its OWN frames (batch k of rank r starts at stream index r*n + k*1000003): steps that overlap
     # in time must not share input, or the later one would be served from the 256 MB Infinity Cache instead of HBM
     frames_k = [torch.from_numpy(host).to(dev)]                  # resident in HBM before any timing
-    for k in range(1, ns):
+    # At least FOUR frame sets even when fewer batches are in flight: a launch that reads the gigabyte its predecessor has just read
+    # gets part of it from the 256 MB Infinity Cache -- k_binary alone, back to back: 0.215 ms on the same frames, 0.240 rotating over
+    # two sets, 0.2575 over four (tools/k1_pipe.py) -- which a camera feed never does.  Everything this file measures "alone" (the
+    # roofline kernel, the lone batch, the stage split, serial steps) therefore takes the contexts -- one per frame set, each with its own output buffers -- in turn (nxt below).
+    n_sets = max(ns, 4)
+    for k in range(1, n_sets):
         frames_k.append(torch.from_numpy(synth.batch(rank * n + k * 1000003, n, W, H, CAMP_BLUE, args.variant, threads=nthreads)).to(dev))
     frames = frames_k[0]
     # Steps are double-buffered over `--streams` contexts (own work buffers, own HIP stream, same resident
@@ -194,7 +199,7 @@ def main():
     # the HBM-bound pixel kernel of step i+1 streams -- what a continuous camera feed would do.
     # (the dense streams have up to ~2100 contours per frame: beyond the default limit of 2048)
     ctxs = [Context(device=local_rank, max_frames=n, max_width=W, max_height=H, max_contours=(4096 if args.variant >= 10 or args.density_sweep else 2048))
-            for _ in range(ns)]
+            for _ in range(n_sets)]                                # the first ns carry the steps; all of them the "alone" measurements (nxt below)
     stages = STAGE_ALL | (STAGE_IDENTITY if args.workload == "c5" else 0) | (STAGE_POSE if args.pose else 0)
     if os.environ.get("RMCV_BENCH_STAGES"):                      # dev knob (tools/ab_streams.sh): a partial path is NOT the metric
         stages = int(os.environ["RMCV_BENCH_STAGES"])
@@ -209,6 +214,12 @@ def main():
         if args.pose:
             c.pnp_load()                                          # camera constants of executable/main.cpp:7-19
     ctx = ctxs[0]
+    rot = [0]
+
+    def nxt():
+        """the next context in turn: its frames were last read, and its buffers last written, n_sets launches ago"""
+        rot[0] = (rot[0] + 1) % n_sets
+        return ctxs[rot[0]]
     params = default_params()                                     # main.cpp:172-176: BLUE, lb 80, close, ...
     legacy = LegacyParams(1.5, 80, 70, 10, 99999, int(os.environ.get("RMCV_LEGACY_FIT", "0"))) if args.workload == "legacy" else None
 
@@ -288,11 +299,12 @@ def main():
         first_use = step_no[0] < ns
         step_no[0] += 1
         if not pipelined:
+            cx = nxt() if ns < n_sets else ctxs[k]                 # fewer batches in flight than frame sets: the contexts take turns (see n_sets)
             with torch.cuda.stream(streams[k]):
-                run_path(ctxs[k], cur_stages[0], streams[k].cuda_stream)
+                run_path(cx, cur_stages[0], streams[k].cuda_stream)
                 if works[k] is not None:
                     works[k].wait()                        # the record is rewritten: its previous gather must be through (stream-side wait)
-                ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
+                cx.compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
                 return gather_step(k, streams[k].cuda_stream, k)
         sA = sAs[(step_no[0] - 1) % len(sAs)]
         with torch.cuda.stream(sA):
@@ -402,24 +414,27 @@ def main():
     stage = np.zeros(5)
     reps = max(5, min(args.steps, 20))
     for _ in range(reps):
-        stage += np.asarray(ctx.run_timed(params, stages, sh))
+        stage += np.asarray(nxt().run_timed(params, stages, sh))
     stage /= reps
     # one batch at a time, HIP events around the whole batch, median and min over >= 20 passes
     lone = []
-    ctx.set_option(OPT_SPARSE_WAVES, 8)                            # the latency settings: a lone batch has the CUs to itself
-    ctx.set_option(OPT_PIXEL_GROUPS, 3)
+    for c in ctxs:
+        c.set_option(OPT_SPARSE_WAVES, 8)                          # the latency settings: a lone batch has the CUs to itself
+        c.set_option(OPT_PIXEL_GROUPS, 3)
     for _ in range(max(20, reps)):
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cx = nxt()
         with torch.cuda.stream(stream):
             ea.record(stream)
-            run_path(ctx, stages, sh)
-            ctx.compact_armours_into(rec.data_ptr() + head, cap, rec.data_ptr(), sh)
+            run_path(cx, stages, sh)
+            cx.compact_armours_into(rec.data_ptr() + head, cap, rec.data_ptr(), sh)
             eb.record(stream)
         torch.cuda.synchronize()
         lone.append(ea.elapsed_time(eb))
     lone.sort()
-    ctx.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
-    ctx.set_option(OPT_PIXEL_GROUPS, 2 if ns >= 2 else 3)
+    for c in ctxs:
+        c.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
+        c.set_option(OPT_PIXEL_GROUPS, 2 if ns >= 2 else 3)
     fused_ms = None
     if legacy is None:          # what the steps actually launch: findContours + filter_lightblobs + filter_armours as one kernel
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -446,15 +461,17 @@ def main():
     # stream, so the event/launch latency (~20 us, visible in stage_ms.binary) is amortised and the figure is the
     # kernel's duration, the same quantity rocprofv3 --kernel-trace reports
     R = 20
-    def k_binary_alone(groups):
-        ctx.set_option(OPT_PIXEL_GROUPS, groups)
+    def k_binary_alone(groups, rotate=True):
+        for c in ctxs:
+            c.set_option(OPT_PIXEL_GROUPS, groups)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         with torch.cuda.stream(stream):
             ctx.run(params, STAGE_BINARY, sh)
             e0.record(stream)
             for _ in range(R):
-                ctx.run(params, STAGE_BINARY, sh)
+                # rotate: every launch reads frames, and writes buffers, last touched n_sets launches ago -- HBM, not the Infinity Cache
+                (nxt() if rotate else ctx).run(params, STAGE_BINARY, sh)
             e1.record(stream)
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / R
@@ -463,7 +480,20 @@ def main():
     groups_in_steps = 2 if ns >= 2 else 3
     k1_ms = k_binary_alone(3)
     k1_steps_ms = k_binary_alone(groups_in_steps) if groups_in_steps != 3 else k1_ms
-    ctx.set_option(OPT_PIXEL_GROUPS, groups_in_steps)
+    k1_warm_ms = k_binary_alone(3, rotate=False)                    # rounds 1-2 and the first half of round 3 reported THIS as the roofline figure
+    # the pixel kernels ALONE in the schedule the steps launch them in (two streams, the steps' workgroups per CU, every context's
+    # own frames, no events): what the overlap of consecutive launches is worth (ramp and tail of one hidden behind the other)
+    k1_pipe_ms = None
+    if pipelined:
+        torch.cuda.synchronize()
+        for rep in range(2):
+            t0p = time.perf_counter()
+            for i in range(4 * R):
+                ctxs[i % ns].run(params, STAGE_BINARY, sAs[i % len(sAs)].cuda_stream)
+            torch.cuda.synchronize()
+            k1_pipe_ms = (time.perf_counter() - t0p) / (4 * R) * 1e3
+    for c in ctxs:
+        c.set_option(OPT_PIXEL_GROUPS, groups_in_steps)
     achieved = n * BYTES_PER_FRAME / (k1_ms * 1e-3) / 1e9
 
     traffic = None
@@ -512,10 +542,19 @@ def main():
         "roofline": {"kernel": "k_binary", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME, "avg_launch_ms": round(k1_ms, 4),
-                     "launches_timed": R, "workgroups_per_cu": 3,
+                     "launches_timed": R, "workgroups_per_cu": 3, "contexts_rotated": n_sets,
+                     "same_frames_every_launch": {"avg_launch_ms": round(k1_warm_ms, 4),
+                                                  "frac": round(n * BYTES_PER_FRAME / (k1_warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                  "note": "NOT the roofline figure: 20 launches over the SAME gigabyte of frames, part of which the 256 MB Infinity "
+                                                          "Cache still holds from the launch before (what this file reported as `roofline` until the second half "
+                                                          "of round 3)"},
                      "as_launched_by_the_steps": {"workgroups_per_cu": groups_in_steps, "avg_launch_ms": round(k1_steps_ms, 4),
                                                   "frac": round(n * BYTES_PER_FRAME / (k1_steps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                  "note": "alone, back to back; in the steps two such launches overlap (4 workgroups per CU resident)"}},
+                                                  "note": "alone, back to back; in the steps two such launches overlap (4 workgroups per CU resident)"},
+                     "pixel_kernels_only_in_the_steps_schedule": None if k1_pipe_ms is None else {
+                         "ms_per_launch": round(k1_pipe_ms, 4), "frac": round(n * BYTES_PER_FRAME / (k1_pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "%d launches alternating over the steps' %d pixel streams and %d contexts, nothing else on the machine, wall clock "
+                                 "between two synchronisations: consecutive launches overlap, each hides the other's ramp and tail" % (4 * R, len(sAs), ns)}},
     }
 
     if not args.no_extras and rank == 0:
@@ -528,7 +567,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                ctx.run(p2, STAGE_BINARY, sh)
+                nxt().run(p2, STAGE_BINARY, sh)
             torch.cuda.synchronize()
             d2 = time.perf_counter() - t0
             ex[name + "_fps"] = round(n * args.steps / d2, 1)

@@ -42,6 +42,12 @@ namespace rmcv {
                          // sparse kernel -- which may run BESIDE this launch, on another XCD with its own L2 -- sees a frame's words
                          // as soon as the frame's progress word says so, without an L2 write-back (frame-level hand-over, below)
 #endif
+#ifndef RMCV_K1_PLAIN_PLAUX
+#define RMCV_K1_PLAIN_PLAUX 0 // ... of the bit-plane stores when nothing runs beside this launch (no hand-over)
+#endif
+#ifndef RMCV_K1_HALOAUX
+#define RMCV_K1_HALOAUX 0 // cache-policy bits of the loads of the row quads a strip shares with its neighbours (0 = cacheable: the neighbour finds them in L2)
+#endif
 #ifndef RMCV_K1_LDAUX
 #define RMCV_K1_LDAUX 2 // cache-policy bits of the frame loads that no other workgroup shares (2 = nt)
 #endif
@@ -152,6 +158,8 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     // word reaches L * h.  Published after the barrier at the top of the NEXT iteration (every wave's stores are then
     // acknowledged), by one thread.
     int pub_f = -1, pub_rows = 0;
+    int ticket = 0;
+    if (tid == 0) ticket = atomicAdd(&strip_ctr[xcd * CTR_STRIDE], 1);
     for (;;) {
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
@@ -174,7 +182,14 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     // finish up to one strip apart) are a quarter as long.
     const int n_mid = per_xcd - taper_head - taper_tail;
     const int n_queue = 4 * taper_head + n_mid + 4 * taper_tail;
-    if (tid == 0) s_next = atomicAdd(&strip_ctr[xcd], 1);
+    // The ticket for THIS strip was drawn while the previous strip was being processed (`ticket`, thread 0); the next one is
+    // drawn now and not looked at until the next iteration: a draw is a device-scope atomic -- a round trip of microseconds to the
+    // memory side, which used to sit on every strip's critical path between two barriers.  (The queue heads are CTR_STRIDE ints
+    // apart: eight heads in one cache line served every draw of every XCD one after the other.)
+    if (tid == 0) {
+        s_next = ticket;
+        ticket = atomicAdd(&strip_ctr[xcd * CTR_STRIDE], 1);
+    }
     __syncthreads();
     const int j = s_next;
     if ((uint32_t)j >= (uint32_t)n_queue) break;
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                     // cacheable (the neighbour finds them in L2), everything else is read once and says so
                     if (halo && (jq == 0 || jq == nq - 1)) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b96(r_in, vo[k], 0, 0);
+                        for (int k = 0; k < 4; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b96(r_in, vo[k], 0, RMCV_K1_HALOAUX);
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b96(r_in, vo[k], 0, RMCV_K1_LDAUX);
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                 // in L2 (same-box A/B of the whole bench: plain is 0-4 % faster, tools/ab_r3_pl.sh)
                 const uint32_t po = ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB;
                 // (PUB is a template parameter: as a run-time branch the two stores cost the 80-register kernel five spilled dwords)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, PUB ? RMCV_K1_PLAUX : 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, PUB ? RMCV_K1_PLAUX : RMCV_K1_PLAIN_PLAUX);
                 k += k_step;
                 s_ += s_step;
                 if (k >= ww) { k -= ww; s_++; }
@@ -466,9 +481,9 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
 #endif
     if (tid < 64) {
         int left = 0;
-        if (tid == 0) left = atomicAdd(&strip_ctr[8], 1);
+        if (tid == 0) left = atomicAdd(&strip_ctr[8 * CTR_STRIDE], 1);
         left = __builtin_amdgcn_readfirstlane(left);
-        if (left == (int)gridDim.x - 1 && tid < 9) atomicExch(&strip_ctr[tid], 0);
+        if (left == (int)gridDim.x - 1 && tid < 9) atomicExch(&strip_ctr[tid * CTR_STRIDE], 0);
 #ifdef RMCV_PROFILE_HANDOVER
         if (left == (int)gridDim.x - 1 && tid == 0) printf("[kb end] %lld\n", (long long)wall_clock64());
 #endif

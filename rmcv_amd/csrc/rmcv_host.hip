@@ -234,7 +234,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.binary, F * d.max_width * d.max_height);
     if (e == hipSuccess) e = dalloc(c, &b.bits, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.rowmask, F * d.max_height);
-    if (e == hipSuccess) e = dalloc(c, &b.strip_ctr, 16);
+    if (e == hipSuccess) e = dalloc(c, &b.strip_ctr, 9 * CTR_STRIDE);
     if (e == hipSuccess) e = dalloc(c, &b.lab, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.neg, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.points, F * d.max_points);
@@ -277,7 +277,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     }
     if (e == hipSuccess) {
         hipMemset(b.frame_ready, 0, F * sizeof(unsigned long long));
-        hipMemset(b.strip_ctr, 0, 16 * sizeof(int));
+        hipMemset(b.strip_ctr, 0, 9 * CTR_STRIDE * sizeof(int));
         hipMemset(b.n_contours, 0, F * 4);
         hipMemset(b.n_points, 0, F * 4);
         hipMemset(b.n_blobs, 0, F * 4);
