@@ -398,6 +398,34 @@ def main():
         steady = {"steps": long_steps, "ms_per_step": round(dts / long_steps * 1e3, 4), "frames_per_s": round(world * n * long_steps / dts, 1),
                   "note": "one region of 25 x --steps steps between barrier+synchronize pairs: the pipeline's fill and drain amortised; not the metric"}
 
+    # ---- dev tool: RMCV_BENCH_AB="<option id>:<value A>:<value B>[:<pairs>]" -- the same loop, regions of 5 x --steps steps alternating between
+    # two values of a context option (rmcv_ctx_set_option on every context), IN ONE PROCESS: the boxes drift by 2 % within a minute, which
+    # A/B runs of separate processes cannot tell from an effect of 1 %.  Printed as `ab`; not the metric.
+    ab = None
+    if os.environ.get("RMCV_BENCH_AB"):
+        f_ = os.environ["RMCV_BENCH_AB"].split(":")
+        opt_, va_, vb_, pairs_ = int(f_[0]), int(f_[1]), int(f_[2]), int(f_[3]) if len(f_) > 3 else 12
+        reg_ = 5 * args.steps
+        res_ = {va_: [], vb_: []}
+        for pr in range(pairs_):
+            for v_ in ((va_, vb_) if pr % 2 == 0 else (vb_, va_)):
+                for c in ctxs:
+                    c.set_option(opt_, v_)
+                for _ in range(2 * ns):
+                    step()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(reg_):
+                    step()
+                barrier()
+                res_[v_].append((time.perf_counter() - t0) / reg_ * 1e3)
+        for c in ctxs:
+            c.set_option(opt_, va_)
+        ab = {"option": opt_, "steps_per_region": reg_, "pairs": pairs_,
+              "a": {"value": va_, "median_ms": round(float(np.median(res_[va_])), 4), "mean_ms": round(float(np.mean(res_[va_])), 4), "each": [round(x, 4) for x in res_[va_]]},
+              "b": {"value": vb_, "median_ms": round(float(np.median(res_[vb_])), 4), "mean_ms": round(float(np.mean(res_[vb_])), 4), "each": [round(x, 4) for x in res_[vb_]]}}
+        ab["b_over_a"] = round(ab["b"]["mean_ms"] / ab["a"]["mean_ms"], 4)
+
     # ---- what was computed (outside the timed region): status + gathered list sanity
     cnt = ctx.counts()
     bad = int(np.count_nonzero(cnt["status"] & 15))
@@ -532,6 +560,8 @@ def main():
                    "frame_level_handover": handover},
         "lone_batch_ms": {"median": round(lone[len(lone) // 2], 4), "min": round(lone[0], 4), "passes": len(lone),
                           "note": "one batch at a time on one stream, events around detect + compaction (latency, not the metric)"},
+        **({"ab": ab} if ab else {}),
+        **({"ptrs": ["%x" % t.data_ptr() for t in frames_k]} if os.environ.get("RMCV_BENCH_PTRS") else {}),
         "path_hbm_frac": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
         "stage_ms": {"binary": round(float(stage[0]), 4), "contours": round(float(stage[1]), 4),
                      "blobs": round(float(stage[2]), 4), "armours": round(float(stage[3]), 4),

@@ -171,6 +171,12 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * finished by the first launch.  Results are identical.  Measured: worth 14 % where EVERY frame is that dense, costs
  * 20-30 % where a few frames per batch are (they then run after the others instead of beside them). */
 #define RMCV_OPT_DENSE_DEFER 7
+/* RMCV_OPT_PIXEL_STAGGER: the pixel kernel's second and third workgroup of every CU wait `value` and 2 x `value` ticks of 10 ns
+ * before their first load (0, the default: all start together).  A measurement knob; results are identical. */
+#define RMCV_OPT_PIXEL_STAGGER 8
+/* RMCV_OPT_SPARSE_PRIO: instruction-issue priority (s_setprio) of the per-frame kernel's waves, 0..3; 3 (default).  A measurement
+ * knob; results are identical. */
+#define RMCV_OPT_SPARSE_PRIO 9
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
                                                  int* __restrict__ strip_ctr, int taper_head, int taper_tail,
-                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq, unsigned* started)
+                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq, unsigned* started, int stagger)
 {
     extern __shared__ uint64_t smem[];
     // "this launch is RUNNING": the stream that carries the sparse kernel of the batch waits for this word (hipStreamWaitValue32,
@@ -160,6 +160,14 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
     int pub_f = -1, pub_rows = 0;
     int ticket = 0;
     if (tid == 0) ticket = atomicAdd(&strip_ctr[xcd * CTR_STRIDE], 1);
+    // Out of phase from the start: the workgroups of a launch begin together, and with equal strips they stay in step for the first
+    // few -- everybody loads, then everybody computes and stores -- which a launch on its own pays in idle memory cycles (two
+    // overlapping launches fill each other's gaps).  The dispatcher deals workgroups b, b + 256, b + 512 to the same CU: the second
+    // and third wait `stagger` and 2 x `stagger` ticks of the 100 MHz clock before their first load.
+    if (stagger > 0) {
+        const long long wait = (long long)(blockIdx.x >> 8) * stagger, t0 = wall_clock64();
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     for (;;) {
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
@@ -513,6 +521,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     static const bool nopub = getenv("RMCV_K1_NOPUB") && atoi(getenv("RMCV_K1_NOPUB")); // dev knob: no progress words (no hand-over possible)
     const int bpc = bpc_env > 0 ? bpc_env : groups;
     // tapered queue (see the kernel): 16 strips at the head (one 8-row piece per workgroup of an XCD at 2 per CU) and 32 at the tail
+    const int stagger = g.pixel_stagger; // RMCV_OPT_PIXEL_STAGGER
     static const int taper_on = getenv("RMCV_K1_TAPER") ? atoi(getenv("RMCV_K1_TAPER")) : 0; // dev knob for A/B runs: since the loads
     // became unconditional buffer operations the tapered hand-out no longer pays (0.2672 ms without against 0.2692 ms with, same box)
     for (int f0 = 0; f0 < g.n_frames; f0 += chunk) {
@@ -549,7 +558,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
 #define RMCV_K1_LAUNCH(F, P)                                                                                                          \
     launch(k_binary<CA, CB, F, P>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
            morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail,               \
-           pub ? b.frame_ready + f0 : nullptr, seq, pub ? b.started : nullptr)
+           pub ? b.frame_ready + f0 : nullptr, seq, pub ? b.started : nullptr, stagger)
         const hipError_t e = fast ? (pub ? RMCV_K1_LAUNCH(true, true) : RMCV_K1_LAUNCH(true, false))
                                   : (pub ? RMCV_K1_LAUNCH(false, true) : RMCV_K1_LAUNCH(false, false));
 #undef RMCV_K1_LAUNCH

@@ -224,6 +224,8 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         c->geom.device = device;
+        c->geom.sparse_prio = 3;
+        c->geom.pixel_stagger = getenv("RMCV_K1_STAGGER") ? atoi(getenv("RMCV_K1_STAGGER")) : 0; // RMCV_OPT_PIXEL_STAGGER (env: dev A/B knob)
         c->geom.dense_defer = getenv("RMCV_DENSE_DEFER") ? atoi(getenv("RMCV_DENSE_DEFER")) : 0; // RMCV_OPT_DENSE_DEFER (env: dev A/B knob)
         c->geom.n_cu = (device < MAX_DEVICES && hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
         if (device >= MAX_DEVICES) e = hipErrorInvalidDevice;
@@ -610,6 +612,14 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
     if (option == RMCV_OPT_HANDOVER && (value == 0 || value == 1)) {
         if (value && !c->bufs.started) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_OPT_HANDOVER needs hipStreamWaitValue32 on signal memory, which this device / runtime lacks");
         c->handover = value;
+        return RMCV_OK;
+    }
+    if (option == RMCV_OPT_SPARSE_PRIO && value >= 0 && value <= 3) {
+        c->geom.sparse_prio = value;
+        return RMCV_OK;
+    }
+    if (option == RMCV_OPT_PIXEL_STAGGER && value >= 0 && value <= 100000) {
+        c->geom.pixel_stagger = value;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_DENSE_DEFER && (value == 0 || value == 1)) {
