@@ -289,6 +289,7 @@ def main():
     # frame-level hand-over (the sparse kernel beside its own pixel kernel): built, tested, measured equal on this schedule
     # (tools/ab_vs_round2.sh: 0.2493 against 0.2502 ms per step, three alternating runs each) -- off unless asked for
     handover = args.handover or os.environ.get("RMCV_BENCH_HANDOVER", "0") == "1"
+    ho = [handover]                                              # (a list: RMCV_BENCH_AB toggles it between regions)
     for c in ctxs:
         c.set_option(OPT_HANDOVER, 1 if handover else 0)
 
@@ -314,7 +315,7 @@ def main():
             ev_bin[k].record(sA)
         sB = sBs[k % len(sBs)]
         with torch.cuda.stream(sB):
-            if handover:
+            if ho[0]:
                 # frame-level hand-over: the sparse kernel is enqueued beside its own pixel kernel and takes each frame when its last
                 # strip is written (RMCV_STAGE_HANDOVER: the library orders it after what preceded that pixel kernel, not after it)
                 run_path(ctxs[k], (cur_stages[0] & ~(STAGE_BINARY | STAGE_NO_IMAGE)) | STAGE_HANDOVER, sB.cuda_stream)
@@ -411,6 +412,9 @@ def main():
             for v_ in ((va_, vb_) if pr % 2 == 0 else (vb_, va_)):
                 for c in ctxs:
                     c.set_option(opt_, v_)
+                if opt_ == OPT_HANDOVER:                           # the option AND the schedule that uses it (RMCV_STAGE_HANDOVER in step())
+                    barrier()
+                    ho[0] = bool(v_)
                 for _ in range(2 * ns):
                     step()
                 barrier()
@@ -421,6 +425,9 @@ def main():
                 res_[v_].append((time.perf_counter() - t0) / reg_ * 1e3)
         for c in ctxs:
             c.set_option(opt_, va_)
+        if opt_ == OPT_HANDOVER:
+            barrier()
+            ho[0] = bool(va_)
         ab = {"option": opt_, "steps_per_region": reg_, "pairs": pairs_,
               "a": {"value": va_, "median_ms": round(float(np.median(res_[va_])), 4), "mean_ms": round(float(np.mean(res_[va_])), 4), "each": [round(x, 4) for x in res_[va_]]},
               "b": {"value": vb_, "median_ms": round(float(np.median(res_[vb_])), 4), "mean_ms": round(float(np.mean(res_[vb_])), 4), "each": [round(x, 4) for x in res_[vb_]]}}

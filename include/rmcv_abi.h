@@ -177,6 +177,9 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
 /* RMCV_OPT_SPARSE_PRIO: instruction-issue priority (s_setprio) of the per-frame kernel's waves, 0..3; 3 (default).  A measurement
  * knob; results are identical. */
 #define RMCV_OPT_SPARSE_PRIO 9
+/* RMCV_OPT_PIXEL_TAPER: 1: the first 16 and the last 32 strips of every XCD's queue of the pixel kernel are handed out as four
+ * 8-row pieces each (shorter ramp and tail, more halo rows read); 0 (default).  A measurement knob; results are identical. */
+#define RMCV_OPT_PIXEL_TAPER 10
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */

@@ -522,7 +522,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     const int bpc = bpc_env > 0 ? bpc_env : groups;
     // tapered queue (see the kernel): 16 strips at the head (one 8-row piece per workgroup of an XCD at 2 per CU) and 32 at the tail
     const int stagger = g.pixel_stagger; // RMCV_OPT_PIXEL_STAGGER
-    static const int taper_on = getenv("RMCV_K1_TAPER") ? atoi(getenv("RMCV_K1_TAPER")) : 0; // dev knob for A/B runs: since the loads
+    const int taper_on = g.pixel_taper; // RMCV_OPT_PIXEL_TAPER (env RMCV_K1_TAPER sets its default), for A/B runs: since the loads
     // became unconditional buffer operations the tapered hand-out no longer pays (0.2672 ms without against 0.2692 ms with, same box)
     for (int f0 = 0; f0 < g.n_frames; f0 += chunk) {
         const int nf = std::min(chunk, g.n_frames - f0);

@@ -116,6 +116,8 @@ static hipError_t dalloc_named(rmcv_ctx* c, T** p, size_t count, const char* nam
         c->allocs.push_back(q);
         c->guarded.push_back({(uint8_t*)q, bytes, name});
         *p = (T*)((uint8_t*)q + GUARD);
+        static const bool trace_alloc = getenv("RMCV_TRACE_ALLOC") && atoi(getenv("RMCV_TRACE_ALLOC")); // dev knob (tools/placement_probe.py)
+        if (trace_alloc && bytes >= (1u << 20)) fprintf(stderr, "[alloc] ctx %p %-14s %p %zu\n", (void*)c, name, (void*)*p, bytes);
         e = hipMemset(q, GUARD_BYTE, GUARD);
         // the rounding slack behind the payload belongs to the rear zone
         if (e == hipSuccess) e = hipMemset((uint8_t*)q + GUARD + count * sizeof(T), GUARD_BYTE, bytes - count * sizeof(T) + GUARD);
@@ -225,6 +227,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
         hipDeviceProp_t prop;
         c->geom.device = device;
         c->geom.sparse_prio = 3;
+        c->geom.pixel_taper = getenv("RMCV_K1_TAPER") ? atoi(getenv("RMCV_K1_TAPER")) : 0;
         c->geom.pixel_stagger = getenv("RMCV_K1_STAGGER") ? atoi(getenv("RMCV_K1_STAGGER")) : 0; // RMCV_OPT_PIXEL_STAGGER (env: dev A/B knob)
         c->geom.dense_defer = getenv("RMCV_DENSE_DEFER") ? atoi(getenv("RMCV_DENSE_DEFER")) : 0; // RMCV_OPT_DENSE_DEFER (env: dev A/B knob)
         c->geom.n_cu = (device < MAX_DEVICES && hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
@@ -612,6 +615,10 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
     if (option == RMCV_OPT_HANDOVER && (value == 0 || value == 1)) {
         if (value && !c->bufs.started) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_OPT_HANDOVER needs hipStreamWaitValue32 on signal memory, which this device / runtime lacks");
         c->handover = value;
+        return RMCV_OK;
+    }
+    if (option == RMCV_OPT_PIXEL_TAPER && (value == 0 || value == 1)) {
+        c->geom.pixel_taper = value;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_SPARSE_PRIO && value >= 0 && value <= 3) {
