@@ -53,17 +53,17 @@ for stages, name in ((STAGE_BINARY, "with the byte image"), (STAGE_BINARY | STAG
     for g in range(G):
         print("%s group %d: median %.4f ms per launch  min %.4f  max %.4f" % (name, g, np.median(res[1:, g]), res[1:, g].min(), res[1:, g].max()))
 
-# can ONE (context, frame set) pair be told fast from slow by itself?  (one stream, the same gigabyte over and over: warm for every pair alike)
+# is a slow group's gigabyte slow for ANY reader?  a plain reduction over every frame set (torch's own kernel), cold (the sets in turn)
+sets = [c._frames_ref for cs in groups for c in cs]
+views = [t.reshape(-1).view(torch.int32) for t in sets]
+acc = np.zeros(len(views))
+for rep in range(6):
+    for i, v in enumerate(views):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        v.sum()
+        torch.cuda.synchronize()
+        if rep:
+            acc[i] += (time.perf_counter() - t0) * 1e3 / 5
 for g in range(G):
-    one = []
-    for k in range(4):
-        ts = []
-        for rep in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(30):
-                groups[g][k].run(p, STAGE_BINARY, streams[0].cuda_stream)
-            torch.cuda.synchronize()
-            ts.append((time.perf_counter() - t0) / 30 * 1e3)
-        one.append(float(np.median(ts)))
-    print("group %d pairs alone, warm: %s" % (g, " ".join("%.4f" % x for x in one)))
+    print("group %d frame sets, torch sum of 1 GB: %s ms" % (g, " ".join("%.4f" % x for x in acc[4 * g:4 * g + 4])))
