@@ -180,6 +180,12 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
 /* RMCV_OPT_PIXEL_TAPER: 1: the first 16 and the last 32 strips of every XCD's queue of the pixel kernel are handed out as four
  * 8-row pieces each (shorter ramp and tail, more halo rows read); 0 (default).  A measurement knob; results are identical. */
 #define RMCV_OPT_PIXEL_TAPER 10
+/* RMCV_OPT_PIXEL_HALO_NT: cache policy of the pixel kernel's loads of the rows a strip shares with its neighbours -- 0 (default):
+ * cacheable (the neighbouring strip finds them in L2); 1: non-temporal like every other load.  Which is faster depends on the
+ * device the process finds itself on and on the workload (the pixel kernels alone gain 3.6 % with 1 on some boxes and
+ * lose 1-5 % on others; the whole path moved by -0.4 % at 1280 px and +6 % at 1920 px on a box of the first kind).  A measurement
+ * knob; results are identical. */
+#define RMCV_OPT_PIXEL_HALO_NT 11
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */

@@ -40,6 +40,7 @@ OPT_DENSE_DEFER = 7
 OPT_PIXEL_STAGGER = 8
 OPT_SPARSE_PRIO = 9
 OPT_PIXEL_TAPER = 10
+OPT_PIXEL_HALO_NT = 11
 STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE, STAGE_NO_IMAGE = 1, 2, 4, 8, 15, 16, 32, 64
 STAGE_HANDOVER = 128
 SVM_FEATURES = 1200

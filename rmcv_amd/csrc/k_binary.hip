@@ -111,8 +111,10 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
                                                  int* __restrict__ strip_ctr, int taper_head, int taper_tail,
-                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq, unsigned* started, int stagger)
+                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq, unsigned* started, int knobs)
 {
+    const int stagger = knobs & 0xFFFFF;        // RMCV_OPT_PIXEL_STAGGER
+    const bool halo_nt = (knobs >> 20) & 1;     // RMCV_OPT_PIXEL_HALO_NT
     extern __shared__ uint64_t smem[];
     // "this launch is RUNNING": the stream that carries the sparse kernel of the batch waits for this word (hipStreamWaitValue32,
     // rmcv_host.hip) before it lets workgroups loose that spin for this launch's frames -- a spinning consumer must never be on
@@ -284,7 +286,10 @@ __global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ f
                     for (int k = 0; k < 4; k++) vo[k] = (!CHK || t0 + (uint32_t)k < span ? rowk[k] : OOB_S) + lane_off;
                     // the first and the last row quad hold the rows this strip shares with its neighbours: those stay
                     // cacheable (the neighbour finds them in L2), everything else is read once and says so
-                    if (halo && (jq == 0 || jq == nq - 1)) {
+                    // (RMCV_OPT_PIXEL_HALO_NT, a measurement knob: on some boxes the pixel kernels alone run at 0.2537 ms per launch
+                    // with cacheable shared rows and at 0.2446 with the hint for them too, on the others the hint costs 1-5 %; the
+                    // whole path hardly notices at 1280 px and loses 6 % at 1920 px: DESIGN.md 6g)
+                    if (halo && !halo_nt && (jq == 0 || jq == nq - 1)) {
 #pragma unroll
                         for (int k = 0; k < 4; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b96(r_in, vo[k], 0, RMCV_K1_HALOAUX);
                     } else {
@@ -521,7 +526,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     static const bool nopub = getenv("RMCV_K1_NOPUB") && atoi(getenv("RMCV_K1_NOPUB")); // dev knob: no progress words (no hand-over possible)
     const int bpc = bpc_env > 0 ? bpc_env : groups;
     // tapered queue (see the kernel): 16 strips at the head (one 8-row piece per workgroup of an XCD at 2 per CU) and 32 at the tail
-    const int stagger = g.pixel_stagger; // RMCV_OPT_PIXEL_STAGGER
+    const int stagger = (g.pixel_stagger & 0xFFFFF) | (g.pixel_halo_nt ? 1 << 20 : 0); // RMCV_OPT_PIXEL_STAGGER, RMCV_OPT_PIXEL_HALO_NT
     const int taper_on = g.pixel_taper; // RMCV_OPT_PIXEL_TAPER (env RMCV_K1_TAPER sets its default), for A/B runs: since the loads
     // became unconditional buffer operations the tapered hand-out no longer pays (0.2672 ms without against 0.2692 ms with, same box)
     for (int f0 = 0; f0 < g.n_frames; f0 += chunk) {

@@ -227,6 +227,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
         hipDeviceProp_t prop;
         c->geom.device = device;
         c->geom.sparse_prio = 3;
+        c->geom.pixel_halo_nt = getenv("RMCV_K1_HALO_NT") ? atoi(getenv("RMCV_K1_HALO_NT")) : 0;
         c->geom.pixel_taper = getenv("RMCV_K1_TAPER") ? atoi(getenv("RMCV_K1_TAPER")) : 0;
         c->geom.pixel_stagger = getenv("RMCV_K1_STAGGER") ? atoi(getenv("RMCV_K1_STAGGER")) : 0; // RMCV_OPT_PIXEL_STAGGER (env: dev A/B knob)
         c->geom.dense_defer = getenv("RMCV_DENSE_DEFER") ? atoi(getenv("RMCV_DENSE_DEFER")) : 0; // RMCV_OPT_DENSE_DEFER (env: dev A/B knob)
@@ -617,6 +618,10 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         c->handover = value;
         return RMCV_OK;
     }
+    if (option == RMCV_OPT_PIXEL_HALO_NT && (value == 0 || value == 1)) {
+        c->geom.pixel_halo_nt = value;
+        return RMCV_OK;
+    }
     if (option == RMCV_OPT_PIXEL_TAPER && (value == 0 || value == 1)) {
         c->geom.pixel_taper = value;
         return RMCV_OK;
@@ -625,7 +630,7 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         c->geom.sparse_prio = value;
         return RMCV_OK;
     }
-    if (option == RMCV_OPT_PIXEL_STAGGER && value >= 0 && value <= 100000) {
+    if (option == RMCV_OPT_PIXEL_STAGGER && value >= 0 && value <= 100000) { // (20 bits of the kernel's knob word)
         c->geom.pixel_stagger = value;
         return RMCV_OK;
     }

@@ -19,6 +19,7 @@ struct Geom {
     int device;          // HIP device of the owning context: per-device launch state (function attributes) is indexed by it
     int n_cu;            // compute units of that device (sizes the persistent grid of k_binary)
     int sparse_prio;     // RMCV_OPT_SPARSE_PRIO: s_setprio of the per-frame kernel's waves (0..3)
+    int pixel_halo_nt;   // RMCV_OPT_PIXEL_HALO_NT: the row quads a strip shares with its neighbours are loaded non-temporal too
     int pixel_taper;     // RMCV_OPT_PIXEL_TAPER: the first 16 and last 32 strips of every XCD queue handed out as 8-row pieces
     int pixel_stagger;   // RMCV_OPT_PIXEL_STAGGER: k_binary's workgroups of one CU start this many 10-ns ticks apart (0: together)
     int dense_defer;     // RMCV_OPT_DENSE_DEFER: frames beyond the LDS tables are left to a second launch with 8 wavefronts per frame
