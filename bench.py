@@ -29,19 +29,9 @@ sys.path.insert(0, ROOT)
 # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A step's kernels must not share a
 # queue with another batch's or with RCCL's stream: the null stream + three batch streams + RCCL's own need five, and with four
 # the gather of every step cost 15 % (736 k against 843 k frames/s, tools/ab_dist.sh).  Read by the HIP runtime at start-up.
-# C5 (1920x1200 + the classifier in the per-frame kernel) has the longer sparse chain and runs 8 batches in flight with a sparse stream
-# each (below): 2 pixel + 8 sparse streams + the null stream + RCCL's.
-def _argv_value(flag, default):
-    for i, a in enumerate(sys.argv):
-        if a == flag and i + 1 < len(sys.argv):
-            return sys.argv[i + 1]
-        if a.startswith(flag + "="):
-            return a.split("=", 1)[1]
-    return default
-
-
-DEEP = _argv_value("--workload", "c3") == "c5"
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12" if DEEP else "6")
+# The steps run 8 batches in flight over 2 pixel + 4 sparse streams (below): with the null stream and RCCL's that is more than the
+# default of 4 hardware queues and than round 2's 6 -- 12 (8 and 16 measure the same).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 FRAMES = 256
 WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200),   # BASELINE.json configs[2] (the metric's config) and configs[4]
@@ -73,27 +63,22 @@ def parse_args(argv=None):
                          "legacy: c3 with rm::FindLightBlobs(fitEllipse=false) as the blob stage")
     ap.add_argument("--pose", action="store_true",
                     help="add the pose stage (rm::solve_PnP + world position per armour, SURVEY 8f-3) to every step")
-    ap.add_argument("--streams", type=int, default=None,
-                    help="contexts (buffer sets) the steps are pipelined over (1 = strictly serial steps); default 4, C5: 8 "
-                         "(tools/ab_r3_c5_deep.sh: 521-555 k frames/s with 4 contexts over 2 sparse streams, 571-573 k with 8 over 8)")
+    ap.add_argument("--streams", type=int, default=8,
+                    help="contexts (buffer sets = batches in flight) the steps are pipelined over (1 = strictly serial steps).  8 over 4 sparse "
+                         "streams since the end of round 3: alternating regions of ONE process (RMCV_BENCH_AB=sched:...) put it 4.3-4.5 %% ahead "
+                         "of round 2's 4 over 2 on C3 and 1 %% on C5; whole processes, five alternations: 0.2587 against 0.2689 ms per step")
     ap.add_argument("--mode", choices=("pipeline", "alternate"), default="pipeline",
                     help="pipeline (default): the pixel kernels of consecutive steps alternate over --pixel-streams streams, the sparse "
                          "stages run on --sparse-streams higher-priority streams, a step's two halves chained by events; alternate: "
                          "whole steps on one stream per context (round 1's schedule: the same steady state, a longer ramp)")
     ap.add_argument("--pixel-streams", type=int, default=2)
-    ap.add_argument("--sparse-streams", type=int, default=None, help="default 2; C5: one per context")
+    ap.add_argument("--sparse-streams", type=int, default=4)
     ap.add_argument("--gather", choices=("auto", "torch", "abi"), default="auto",
                     help="the armour-list gather of a launched run: torch.distributed.gather (asynchronous; the default for more than "
                          "one rank: rmcv_gather's multi-rank path has not run on hardware yet -- no multi-GPU box was available to this "
                          "build) or rmcv_gather, the C-ABI entry point that calls RCCL itself (what a C++ host uses; the default for a "
                          "launched single rank, where it moves nothing)")
-    args = ap.parse_args(argv)
-    deep = args.workload == "c5"
-    if args.streams is None:
-        args.streams = 8 if deep else 4
-    if args.sparse_streams is None:
-        args.sparse_streams = args.streams if (deep and args.streams > 1) else 2
-    return args
+    return ap.parse_args(argv)
 
 
 VARIANTS = {"plain": 0, "stress": 1, "dense1": 11, "dense2": 12, "dense3": 13, "dense4": 14, "dense": 14}
@@ -295,9 +280,13 @@ def main():
 
     cur_stages = [stages]
 
+    shape = [ns, len(sAs), len(sBs)]                             # batches in flight, pixel streams, sparse streams IN USE (RMCV_BENCH_AB "sched" narrows them)
+    used = [False] * ns
+
     def step():
-        k = step_no[0] % ns
-        first_use = step_no[0] < ns
+        k = step_no[0] % shape[0]
+        first_use = not used[k]
+        used[k] = True
         step_no[0] += 1
         if not pipelined:
             cx = nxt() if ns < n_sets else ctxs[k]                 # fewer batches in flight than frame sets: the contexts take turns (see n_sets)
@@ -307,13 +296,13 @@ def main():
                     works[k].wait()                        # the record is rewritten: its previous gather must be through (stream-side wait)
                 cx.compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
                 return gather_step(k, streams[k].cuda_stream, k)
-        sA = sAs[(step_no[0] - 1) % len(sAs)]
+        sA = sAs[(step_no[0] - 1) % shape[1]]
         with torch.cuda.stream(sA):
             if not first_use:
                 sA.wait_event(ev_done[k])
             ctxs[k].run(params, cur_stages[0] & (STAGE_BINARY | STAGE_NO_IMAGE), sA.cuda_stream)
             ev_bin[k].record(sA)
-        sB = sBs[k % len(sBs)]
+        sB = sBs[k % shape[2]]
         with torch.cuda.stream(sB):
             if ho[0]:
                 # frame-level hand-over: the sparse kernel is enqueued beside its own pixel kernel and takes each frame when its last
@@ -405,13 +394,25 @@ def main():
     ab = None
     if os.environ.get("RMCV_BENCH_AB"):
         f_ = os.environ["RMCV_BENCH_AB"].split(":")
+        # "sched:<contexts>,<pixel streams>,<sparse streams>:<...>": the SHAPE of the schedule instead of a context option (start the
+        # process with the larger of each: --streams / --pixel-streams / --sparse-streams, and GPU_MAX_HW_QUEUES to match)
+        sched_ = f_[0] == "sched"
+        if sched_:
+            shapes_ = {0: [int(x) for x in f_[1].split(",")], 1: [int(x) for x in f_[2].split(",")]}
+            assert all(a <= b for sh in shapes_.values() for a, b in zip(sh, (ns, len(sAs), len(sBs))))
+            f_ = ["-1", "0", "1"] + f_[3:]
         opt_, va_, vb_, pairs_ = int(f_[0]), int(f_[1]), int(f_[2]), int(f_[3]) if len(f_) > 3 else 12
         reg_ = 5 * args.steps
         res_ = {va_: [], vb_: []}
         for pr in range(pairs_):
             for v_ in ((va_, vb_) if pr % 2 == 0 else (vb_, va_)):
-                for c in ctxs:
-                    c.set_option(opt_, v_)
+                if sched_:
+                    barrier()
+                    shape[:] = shapes_[v_]
+                    step_no[0] = 0
+                else:
+                    for c in ctxs:
+                        c.set_option(opt_, v_)
                 if opt_ == OPT_HANDOVER:                           # the option AND the schedule that uses it (RMCV_STAGE_HANDOVER in step())
                     barrier()
                     ho[0] = bool(v_)
@@ -423,12 +424,17 @@ def main():
                     step()
                 barrier()
                 res_[v_].append((time.perf_counter() - t0) / reg_ * 1e3)
-        for c in ctxs:
-            c.set_option(opt_, va_)
+        if sched_:
+            barrier()
+            shape[:] = [ns, len(sAs), len(sBs)]
+            step_no[0] = 0
+        else:
+            for c in ctxs:
+                c.set_option(opt_, va_)
         if opt_ == OPT_HANDOVER:
             barrier()
             ho[0] = bool(va_)
-        ab = {"option": opt_, "steps_per_region": reg_, "pairs": pairs_,
+        ab = {"option": ("sched %s vs %s" % (shapes_[0], shapes_[1])) if sched_ else opt_, "steps_per_region": reg_, "pairs": pairs_,
               "a": {"value": va_, "median_ms": round(float(np.median(res_[va_])), 4), "mean_ms": round(float(np.mean(res_[va_])), 4), "each": [round(x, 4) for x in res_[va_]]},
               "b": {"value": vb_, "median_ms": round(float(np.median(res_[vb_])), 4), "mean_ms": round(float(np.mean(res_[vb_])), 4), "each": [round(x, 4) for x in res_[vb_]]}}
         ab["b_over_a"] = round(ab["b"]["mean_ms"] / ab["a"]["mean_ms"], 4)
@@ -658,12 +664,11 @@ def main():
                           "frames_mid_tier": int(np.count_nonzero(st_ & 64)), "frames_slow_path": int(np.count_nonzero(st_ & 16)),
                           "frames_over_capacity": int(np.count_nonzero(st_ & 15))})
         out["density_sweep"] = {"steps_per_region": region, "levels": sweep,
-                                "note": "steady-state regions of the bench's own loop (4 batches in flight), rank-0 shard; not the metric"}
+                                "note": "steady-state regions of the bench's own loop (%d batches in flight over %d sparse streams), rank-0 shard; not the metric" % (ns, len(sBs))}
         if not os.environ.get("RMCV_BENCH_SWEEP_LEVELS"):
-            # The dense frame of a batch keeps ONE workgroup busy for 0.5-1 ms after the batch's other frames are through; with 4
-            # batches in flight over 2 sparse streams the launches behind it wait for it.  A deeper schedule -- 8 batches in flight,
-            # a sparse stream each -- hides it (at 2-3 % on the plain stream, which is why it is not the default): the same two levels
-            # under that schedule, in a child process (the schedule is fixed when the streams are created).
+            # The dense frame of a batch keeps ONE workgroup busy for 0.5-1 ms after the batch's other frames are through, and the
+            # launches behind it on its sparse stream wait for it.  With a sparse stream PER batch in flight nothing is behind it:
+            # the same two levels under that schedule, in a child process (the schedule is fixed when the streams are created).
             import subprocess
             env = dict(os.environ, RMCV_BENCH_SWEEP_LEVELS="plain,one", GPU_MAX_HW_QUEUES="12")
             cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-frames", "0",
