@@ -396,6 +396,23 @@ def main():
         f_ = os.environ["RMCV_BENCH_AB"].split(":")
         # "sched:<contexts>,<pixel streams>,<sparse streams>:<...>": the SHAPE of the schedule instead of a context option (start the
         # process with the larger of each: --streams / --pixel-streams / --sparse-streams, and GPU_MAX_HW_QUEUES to match)
+        # "lib:<path of another build of librmcv_hip.so>": regions alternate between THIS build and that one (a second set of contexts on
+        # the same frames; tools/build_variant*.sh make such builds) -- the only way to compare compile-time variants at better than +-3 %
+        libab_ = f_[0] == "lib"
+        if libab_:
+            from rmcv_amd import abi as abi_
+            lib_a, lib_b = abi_.lib(), abi_.load(os.path.abspath(f_[1]))
+            abi_.use(lib_b)
+            ctxs_b = [Context(device=local_rank, max_frames=n, max_width=W, max_height=H, max_contours=ctxs[0].limits.max_contours) for _ in range(n_sets)]
+            for k, c in enumerate(ctxs_b):
+                c.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
+                c.set_option(OPT_PIXEL_GROUPS, 2 if ns >= 2 else 3)
+                c.bind_device_frames(frames_k[k].data_ptr(), n, H, W, keepalive=frames_k[k])
+                if svm:
+                    c.svm_load(*svm)
+            abi_.use(lib_a)
+            ctxs_a = list(ctxs)
+            f_ = ["-2", "0", "1"] + f_[2:]
         sched_ = f_[0] == "sched"
         if sched_:
             shapes_ = {0: [int(x) for x in f_[1].split(",")], 1: [int(x) for x in f_[2].split(",")]}
@@ -406,7 +423,14 @@ def main():
         res_ = {va_: [], vb_: []}
         for pr in range(pairs_):
             for v_ in ((va_, vb_) if pr % 2 == 0 else (vb_, va_)):
-                if sched_:
+                if libab_:
+                    barrier()
+                    abi_.use(lib_b if v_ else lib_a)
+                    ctxs[:] = ctxs_b if v_ else ctxs_a
+                    for k_ in range(len(used)):
+                        used[k_] = False                           # (the other set's events say nothing about this set's buffers)
+                    step_no[0] = 0
+                elif sched_:
                     barrier()
                     shape[:] = shapes_[v_]
                     step_no[0] = 0
@@ -424,7 +448,16 @@ def main():
                     step()
                 barrier()
                 res_[v_].append((time.perf_counter() - t0) / reg_ * 1e3)
-        if sched_:
+        if libab_:
+            barrier()
+            abi_.use(lib_a)
+            ctxs[:] = ctxs_a
+            for k_ in range(len(used)):
+                used[k_] = False
+            step_no[0] = 0
+            for c in ctxs_b:
+                c.close()
+        elif sched_:
             barrier()
             shape[:] = [ns, len(sAs), len(sBs)]
             step_no[0] = 0
@@ -434,7 +467,7 @@ def main():
         if opt_ == OPT_HANDOVER:
             barrier()
             ho[0] = bool(va_)
-        ab = {"option": ("sched %s vs %s" % (shapes_[0], shapes_[1])) if sched_ else opt_, "steps_per_region": reg_, "pairs": pairs_,
+        ab = {"option": ("this build vs %s" % os.environ["RMCV_BENCH_AB"].split(":")[1]) if libab_ else ("sched %s vs %s" % (shapes_[0], shapes_[1])) if sched_ else opt_, "steps_per_region": reg_, "pairs": pairs_,
               "a": {"value": va_, "median_ms": round(float(np.median(res_[va_])), 4), "mean_ms": round(float(np.mean(res_[va_])), 4), "each": [round(x, 4) for x in res_[va_]]},
               "b": {"value": vb_, "median_ms": round(float(np.median(res_[vb_])), 4), "mean_ms": round(float(np.mean(res_[vb_])), 4), "each": [round(x, 4) for x in res_[vb_]]}}
         ab["b_over_a"] = round(ab["b"]["mean_ms"] / ab["a"]["mean_ms"], 4)

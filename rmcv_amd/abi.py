@@ -94,20 +94,33 @@ class RmcvError(RuntimeError):
 _lib = None
 
 
+def load(path):
+    """a configured handle of one build of the library (not installed as THE library: see use)"""
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: run `make -C rmcv_amd/csrc` (or __graft_entry__.build())" % path)
+    L = C.CDLL(path)
+    L.rmcv_last_error.restype = C.c_char_p
+    L.rmcv_last_error.argtypes = [C.c_void_p]
+    L.rmcv_synth_checksum.restype = C.c_uint64
+    L.rmcv_ctx_destroy.restype = None
+    L.rmcv_ctx_destroy.argtypes = [C.c_void_p]
+    return L
+
+
 def lib():
     """load librmcv_hip.so; raises (never falls back) when it has not been built"""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError("%s is missing: run `make -C rmcv_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
-        L.rmcv_last_error.restype = C.c_char_p
-        L.rmcv_last_error.argtypes = [C.c_void_p]
-        L.rmcv_synth_checksum.restype = C.c_uint64
-        L.rmcv_ctx_destroy.restype = None
-        L.rmcv_ctx_destroy.argtypes = [C.c_void_p]
-        _lib = L
+        _lib = load(LIB_PATH)
     return _lib
+
+
+def use(L):
+    """dev tool (bench.py RMCV_BENCH_AB=lib:...): make another build THE library for the calls that follow; returns the previous one.
+    Contexts belong to the build that made them: switch back before touching them."""
+    global _lib
+    prev, _lib = lib(), L
+    return prev
 
 
 def ptr(a):

@@ -31,12 +31,13 @@ class Context:
         if rc != 0:
             raise RmcvError(rc, "rmcv_ctx_create failed (no GPU? this library has no CPU path)")
         self._h = h
+        self._made_by = lib()                                     # (a process can hold two builds: bench.py's RMCV_BENCH_AB=lib:...)
         self.device = device
         self._frames_ref = None
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().rmcv_ctx_destroy(self._h)
+            self._made_by.rmcv_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
