@@ -9,11 +9,18 @@ already resident in HBM: rm::extract_color -> rm::filter_lightblobs -> rm::filte
 lists and -- for N > 1 -- the RCCL gather of those lists to rank 0 (BASELINE config 4).  Weak
 scaling: every rank owns its own 256 frames, no collective on the data path.
 
+Eight batches are in flight (own context, own frames each), pixel kernels alternating over 2 streams, the sparse stages over 4.
+
 Prints ONE JSON line on rank 0: the contract fields plus
   roofline      k_binary (the kernel that moves the algorithmic 4 B/px), timed with HIP events on
-                its own launch stream inside this process
+                its own launch stream inside this process, COLD: every launch on another context's
+                frames and buffers (the same gigabyte again would come partly out of the 256 MB
+                Infinity Cache -- printed beside it as same_frames_every_launch)
   cpu_baseline  the CPU oracle (a port/restatement of the reference path, oracle/) timed on this
                 box's host cores on a bounded sample of the same frames (rank 0, N=1 only)
+
+Dev tool: RMCV_BENCH_AB="<option>:<a>:<b>" | "sched:<ctx,pix,sparse>:<...>" | "lib:<another build>" alternates two settings between
+regions of ONE process (two processes of the same command differ by +-3 % on one box; regions inside a process by 0.1 %).
 """
 import argparse
 import json
