@@ -420,6 +420,12 @@ def main():
             abi_.use(lib_a)
             ctxs_a = list(ctxs)
             f_ = ["-2", "0", "1"] + f_[2:]
+        # "stages:<mask>:<mask>": what the steps run (1 = pixel kernel only, 3 = + findContours, 7 = + fits, 15 = the whole path): what does each stage COST the step?
+        stg_ = f_[0] == "stages"
+        if stg_:
+            masks_ = {0: int(f_[1]), 1: int(f_[2])}
+            keep_stages_ = cur_stages[0]
+            f_ = ["-4", "0", "1"] + f_[3:]
         sched_ = f_[0] == "sched"
         if sched_:
             shapes_ = {0: [int(x) for x in f_[1].split(",")], 1: [int(x) for x in f_[2].split(",")]}
@@ -430,7 +436,10 @@ def main():
         res_ = {va_: [], vb_: []}
         for pr in range(pairs_):
             for v_ in ((va_, vb_) if pr % 2 == 0 else (vb_, va_)):
-                if libab_:
+                if stg_:
+                    barrier()
+                    cur_stages[0] = masks_[v_] | (keep_stages_ & ~15)
+                elif libab_:
                     barrier()
                     abi_.use(lib_b if v_ else lib_a)
                     ctxs[:] = ctxs_b if v_ else ctxs_a
@@ -455,7 +464,10 @@ def main():
                     step()
                 barrier()
                 res_[v_].append((time.perf_counter() - t0) / reg_ * 1e3)
-        if libab_:
+        if stg_:
+            barrier()
+            cur_stages[0] = keep_stages_
+        elif libab_:
             barrier()
             abi_.use(lib_a)
             ctxs[:] = ctxs_a
@@ -474,7 +486,7 @@ def main():
         if opt_ == OPT_HANDOVER:
             barrier()
             ho[0] = bool(va_)
-        ab = {"option": ("this build vs %s" % os.environ["RMCV_BENCH_AB"].split(":")[1]) if libab_ else ("sched %s vs %s" % (shapes_[0], shapes_[1])) if sched_ else opt_, "steps_per_region": reg_, "pairs": pairs_,
+        ab = {"option": ("stage masks %d vs %d" % (masks_[0], masks_[1])) if stg_ else ("this build vs %s" % os.environ["RMCV_BENCH_AB"].split(":")[1]) if libab_ else ("sched %s vs %s" % (shapes_[0], shapes_[1])) if sched_ else opt_, "steps_per_region": reg_, "pairs": pairs_,
               "a": {"value": va_, "median_ms": round(float(np.median(res_[va_])), 4), "mean_ms": round(float(np.mean(res_[va_])), 4), "each": [round(x, 4) for x in res_[va_]]},
               "b": {"value": vb_, "median_ms": round(float(np.median(res_[vb_])), 4), "mean_ms": round(float(np.mean(res_[vb_])), 4), "each": [round(x, 4) for x in res_[vb_]]}}
         ab["b_over_a"] = round(ab["b"]["mean_ms"] / ab["a"]["mean_ms"], 4)

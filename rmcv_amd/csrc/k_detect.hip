@@ -167,7 +167,10 @@ __global__ __launch_bounds__(64) void k_pairs(const int32_t* __restrict__ slot_k
     const int np = blob_compact_frame(f, lane, slot_kind, slot_ell, n_contours[f], max_contours, T.enemy, T.blobs, T.blob_src,
                                       T.ellipses, T.neg_idx, T.n_blobs, T.n_neg, T.status, T.max_blobs);
     if (T.do_pairs) {
-        __threadfence(); // the pair loop re-reads, across lanes, the blobs this wave just wrote
+        // the pair loop re-reads, across lanes, the blobs this wave has just written: workgroup scope is enough (one CU, one L1) -- at
+            // device scope the fence is an L2 write-back + invalidate (buffer_wbl2 sc1, buffer_inv sc1) per frame, on the XCD whose
+            // L2 the pixel kernels of the other batches are streaming through: it cost the step 3 %
+            __threadfence_block();
         armours_frame(f, lane, T.blobs, np, T.max_blobs, T.angle_diff_max, T.shear_max, T.length_ratio_max, T.enemy, T.armours,
                       T.n_armours, T.status, T.max_armours);
     }
