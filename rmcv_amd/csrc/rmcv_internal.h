@@ -34,7 +34,10 @@ struct Geom {
 };
 
 static constexpr int CTR_STRIDE = 32;   // ints between the heads of k_binary's strip queues (Bufs::strip_ctr): a 128-byte line each, 9 of them
-static constexpr int STRIP_ROWS = 32;   // rows of a k_binary strip (k_binary.hip: SR); the sparse kernel's frame queues follow its strip order
+#ifndef RMCV_SR
+#define RMCV_SR 32
+#endif
+static constexpr int STRIP_ROWS = RMCV_SR;   // rows of a k_binary strip (k_binary.hip: SR); the sparse kernel's frame queues follow its strip order
 static constexpr int VISIT_CAP = 4096; // border visits of one frame the contour stage holds in LDS (contours_device.h); more -> mid tier
 static constexpr int NN_MID = 1 << 17;   // border visits of one frame the mid tier holds (tables in global memory); more -> literal scanner
 static constexpr int CAND_MID = 1 << 15; // outer borders (before RETR_EXTERNAL drops the nested ones) the mid tier holds
