@@ -210,7 +210,7 @@ __global__ void k_pack_contours(const rmcv_point* __restrict__ points, const int
     }
     // the per-frame chain running ahead (one frame, everything of it computed already): this workgroup also sends the results home
     if (ex.hdr_dst && f == 0) {
-        __threadfence();
+        __threadfence_block(); // (what it exports it has written itself or an earlier kernel has: workgroup scope -- no L2 write-back)
         __syncthreads(); // the CSR this workgroup has just written is what it exports
         export_lists(ex, threadIdx.x, blockDim.x);
     }
