@@ -106,7 +106,10 @@ static constexpr int RSRC3 = 0x00020000;     // raw buffer descriptor word 3, gf
 // waves per SIMD) next to one wave of the 4-wavefront sparse kernel (168 VGPRs): 4 x 80 + 168 <= 512.  At 88 the sparse kernel
 // would no longer fit beside them and the batches in flight would take turns instead of sharing the CUs.
 template <int CA, int CB, bool FAST, bool PUB>
-__global__ __launch_bounds__(256, 6) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride, int n_frames,
+#ifndef RMCV_K1_MINBLOCKS
+#define RMCV_K1_MINBLOCKS 6
+#endif
+__global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t* __restrict__ frames, int64_t frame_pitch, int stride, int n_frames,
                                                  int w, int h, int ww, int lb, int all_pass, int morph,
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
