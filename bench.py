@@ -693,7 +693,7 @@ def main():
                                 ("dense4", 14, False), ("plain + one dense4 frame per batch", 0, True)]:
             if os.environ.get("RMCV_BENCH_SWEEP_LEVELS") and label.split()[0] not in os.environ["RMCV_BENCH_SWEEP_LEVELS"].split(",") \
                     and not (one and "one" in os.environ["RMCV_BENCH_SWEEP_LEVELS"].split(",")):
-                continue                                           # dev knob (tools/ab_r3_one_dense.sh): a subset of the levels
+                continue                                           # dev knob (tools/ab_process_r3.sh one_dense): a subset of the levels
             for k in range(ns):
                 hb = synth.batch(rank * n + k * 1000003, n, W, H, CAMP_BLUE, var, threads=nthreads)
                 if one:

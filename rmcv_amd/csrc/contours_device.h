@@ -237,7 +237,7 @@ static constexpr int CT_MAXH = RMCV_CT_MAXH;   // rows covered by the LDS row ta
 // The workgroup's LDS: this struct, followed by the ROW TABLES (RowTabs below), which are sized by the frame's height at launch:
 // a row costs 8 bytes (mask of its non-empty words, its place in the list of non-empty rows, its slot base), 2048 rows 16 KB but the
 // 1200 rows of a 1920x1200 frame 9.6 KB -- and with 16 KB the workgroup did not fit a CU's 160 KB beside the four pixel-kernel
-// workgroups (4 x 19.8 KB) of two batches at that width (round 3: C5 +4-6 % once it does, tools/ab_r3_c5_lds.sh).
+// workgroups (4 x 19.8 KB) of two batches at that width (round 3: C5 +4-6 % once it does, tools/ab_process_r3.sh c5_lds).
 // Layout: what the fused tail may overlay with its wave-private rows comes first (exactly 8 x sizeof(WaveLds) = 30 720 bytes: tables
 // that are dead once the contours are out), then what it needs (the work-list copies in bmask / e2mask, the node tables), then the
 // scalars.

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
                 if (ok) word = R[__umul24(s_ + halo, ww) + k];
                 // written through (sc1) only when this launch publishes per-frame progress (the consumer may then read the words
                 // from another XCD while the launch still runs); otherwise plain: the sparse kernel of the same batch finds them
-                // in L2 (same-box A/B of the whole bench: plain is 0-4 % faster, tools/ab_r3_pl.sh)
+                // in L2 (same-box A/B of the whole bench: plain is 0-4 % faster, tools/ab_process_r3.sh pl)
                 const uint32_t po = ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB;
                 // (PUB is a template parameter: as a run-time branch the two stores cost the 80-register kernel five spilled dwords)
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, PUB ? RMCV_K1_PLAUX : RMCV_K1_PLAIN_PLAUX);
