@@ -86,3 +86,36 @@ def test_pipelined_async_gathers_world2_keep_every_step_apart():
         total += len(a)
     assert out["armours_all_steps"] == total > 0
     assert out["sha256_all_steps"] == h.hexdigest()
+
+
+def test_default_schedule_is_the_measured_one():
+    """8 batches in flight, 2 pixel + 4 sparse streams, 12 hardware queues (found by alternating schedule shapes
+    inside one process); the environment's GPU_MAX_HW_QUEUES wins when it is set"""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    saved = os.environ.pop("GPU_MAX_HW_QUEUES", None)
+    try:
+        bench = importlib.reload(importlib.import_module("bench"))
+        a = bench.parse_args([])
+        assert (a.streams, a.pixel_streams, a.sparse_streams, a.gpus) == (8, 2, 4, 1)
+        assert os.environ["GPU_MAX_HW_QUEUES"] == "12"
+        assert bench.parse_args(["--workload", "c5"]).streams == 8
+    finally:
+        if saved is not None:
+            os.environ["GPU_MAX_HW_QUEUES"] = saved
+
+
+def test_two_builds_of_the_library_can_be_loaded_side_by_side():
+    """abi.load / abi.use (bench.py RMCV_BENCH_AB=lib:...): a second handle does not replace THE library until asked to"""
+    from rmcv_amd import abi
+    first = abi.lib()
+    other = abi.load(abi.LIB_PATH)
+    assert abi.lib() is first and other.rmcv_abi_version() == first.rmcv_abi_version()
+    prev = abi.use(other)
+    try:
+        assert prev is first and abi.lib() is other
+    finally:
+        abi.use(first)
+    assert abi.lib() is first
