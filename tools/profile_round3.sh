@@ -1,5 +1,5 @@
 # usage: bash tools/profile_round3.sh <tag> [c3|c5]   (on the GPU box through gpurun; writes gpurun_out/prof_<tag>/)
-# Round-3 evidence for one workload: kernel stats of the serial and of the default (pipelined, frame-level hand-over) command, HBM
+# Round-3 evidence for one workload: kernel stats of the serial command (cold: the contexts take turns) and of the default (pipelined) one, HBM
 # traffic of k_binary (FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE calibrated on the morph = none kernel at the same frame
 # size), SQ counters per kernel.  Every rocprofv3 call has the program directly after `--`; PMC passes carry --kernel-trace only.
 tag=${1:-r03}; wl=${2:-c3}
