@@ -3,24 +3,26 @@
 
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-A "step" = one pass of the hot path over one batch of 256 synthetic 1280x1024 BGR frames that are
-already resident in HBM: rm::extract_color -> rm::filter_lightblobs -> rm::filter_armours
-(reference executable/main.cpp:172-176), followed by the device-side compaction of the armour
-lists and -- for N > 1 -- the RCCL gather of those lists to rank 0 (BASELINE config 4).  Weak
-scaling: every rank owns its own 256 frames, no collective on the data path.
+A "step" = one pass of the hot path over one batch of 256 synthetic 1280x1024 BGR frames that are already resident in HBM:
+rm::extract_color -> rm::filter_lightblobs -> rm::filter_armours (reference executable/main.cpp:172-176), the device-side
+compaction of the armour lists, their copy to pinned host memory and -- for N > 1 -- the RCCL gather of the lists to rank 0
+(BASELINE config 4).  Weak scaling: every rank owns its own 256 frames, no collective on the data path.
 
-Eight batches are in flight (own context, own frames each), pixel kernels alternating over 2 streams, the sparse stages over 4.
+The schedule is the LIBRARY's: a step is ONE call, rmcv_pipeline_submit (include/rmcv_abi.h) -- eight batches in flight, pixel
+kernels alternating over two HIP streams, the per-frame kernels on four higher-priority streams, chained by events inside
+librmcv_hip.so.  tools/pipeline_bench.c drives the same calls from C; this file adds what the driver's contract asks for around it.
 
 Prints ONE JSON line on rank 0: the contract fields plus
-  roofline      k_binary (the kernel that moves the algorithmic 4 B/px), timed with HIP events on
-                its own launch stream inside this process, COLD: every launch on another context's
-                frames and buffers (the same gigabyte again would come partly out of the 256 MB
-                Infinity Cache -- printed beside it as same_frames_every_launch)
-  cpu_baseline  the CPU oracle (a port/restatement of the reference path, oracle/) timed on this
-                box's host cores on a bounded sample of the same frames (rank 0, N=1 only)
+  roofline      k_binary (the kernel that moves the algorithmic 4 B/px), timed with HIP events on its own launch stream inside this
+                process, COLD (every launch on another context's frames and buffers); `in_schedule_frac` = the same kernel in the
+                steps' own schedule (two launches overlapping, nothing else on the machine)
+  cpu_baseline  the CPU oracle (a port/restatement of the reference path, oracle/) timed on this box's host cores on a bounded
+                sample of the same frames (rank 0, N=1 only)
+  c5, density_sweep   short sub-records for BASELINE config 5 and for denser scenes (skipped by --no-extras)
 
-Dev tool: RMCV_BENCH_AB="<option>:<a>:<b>" | "sched:<ctx,pix,sparse>:<...>" | "lib:<another build>" alternates two settings between
-regions of ONE process (two processes of the same command differ by +-3 % on one box; regions inside a process by 0.1 %).
+Dev tool (--dev): RMCV_BENCH_AB="<option>:<a>:<b>" | "sched:<depth,pix,sparse>:<...>" | "stages:<mask>:<mask>" | "lib:<another build>"
+alternates two settings between regions of ONE process (two processes of one command differ by +-3 % on one box; regions inside a
+process by 0.1 %).
 """
 import argparse
 import json
@@ -33,17 +35,24 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A step's kernels must not share a
-# queue with another batch's or with RCCL's stream: the null stream + three batch streams + RCCL's own need five, and with four
-# the gather of every step cost 15 % (736 k against 843 k frames/s, tools/ab_dist.sh).  Read by the HIP runtime at start-up.
-# The steps run 8 batches in flight over 2 pixel + 4 sparse streams (below): with the null stream and RCCL's that is more than the
-# default of 4 hardware queues and than round 2's 6 -- 12 (8 and 16 measure the same).
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read when the runtime starts.  The steps
+# run 8 batches in flight over 2 pixel + 4 sparse streams; with the null stream and RCCL's that is more than 4 (a step's kernels
+# that share a queue with another batch's cannot overlap: the gather of every step cost 15 % at 4).  12 (8 and 16 measure the same).
+# librmcv_hip.so sets the same default when it is loaded; torch may start HIP before that, so it is set here as well.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 FRAMES = 256
 WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200),   # BASELINE.json configs[2] (the metric's config) and configs[4]
              "legacy": (1280, 1024)}                     # FindLightBlobs (minAreaRect boxes, camp vote) in place of filter_lightblobs
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+# environment knobs that change what the timed region runs: refused unless --dev, echoed in config.dev_knobs either way
+DEV_KNOBS = ("RMCV_BENCH_STAGES", "RMCV_BENCH_AB", "RMCV_SPARSE_WAVES", "RMCV_PIXEL_GROUPS", "RMCV_K1_BPC", "RMCV_FUSE_SPARSE", "RMCV_CONTOURS_LITERAL",
+             "RMCV_K1_HALO_NT", "RMCV_DENSE_DEFER", "RMCV_LIB_PATH", "RMCV_NO_MID")
+VARIANTS = {"plain": 0, "stress": 1, "dense1": 11, "dense2": 12, "dense3": 13, "dense4": 14, "dense": 14}
+
+
+def variant_id(v):
+    return VARIANTS[v] if v in VARIANTS else int(v)
 
 
 def parse_args(argv=None):
@@ -60,39 +69,29 @@ def parse_args(argv=None):
                     help="synthetic stream: plain (0, the metric's), stress (1), dense1..dense4 (11..14; dense = dense4: +2000 specks and 13 "
                          "bright windows per frame, 5 %% foreground -- frames beyond findContours' LDS tables; a workload beside the metric)")
     ap.add_argument("--handover", action="store_true",
-                    help="frame-level hand-over: enqueue every step's sparse kernel beside its own pixel kernel (RMCV_STAGE_HANDOVER)")
-    ap.add_argument("--density-sweep", action="store_true",
-                    help="after the run: steady-state step time on every density level (plain, dense1..dense4), printed as `density_sweep`")
+                    help="frame-level hand-over: every step's sparse kernel runs beside its own pixel kernel (rmcv_pipeline_config::handover)")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames per pass of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the C2 (binary only) side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (C2, C5, density sweep, per-frame chain)")
+    ap.add_argument("--density-sweep", action="store_true", help="the density sweep with all five levels instead of the default three")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
                     help="c3: 1280x1024 full path (the metric's config); c5: 1920x1200 full path + SVM digit classify on the icons; "
                          "legacy: c3 with rm::FindLightBlobs(fitEllipse=false) as the blob stage")
     ap.add_argument("--pose", action="store_true",
                     help="add the pose stage (rm::solve_PnP + world position per armour, SURVEY 8f-3) to every step")
     ap.add_argument("--streams", type=int, default=8,
-                    help="contexts (buffer sets = batches in flight) the steps are pipelined over (1 = strictly serial steps).  8 over 4 sparse "
-                         "streams since the end of round 3: alternating regions of ONE process (RMCV_BENCH_AB=sched:...) put it 4.3-4.5 %% ahead "
-                         "of round 2's 4 over 2 on C3 and 1 %% on C5; whole processes, five alternations: 0.2587 against 0.2689 ms per step")
-    ap.add_argument("--mode", choices=("pipeline", "alternate"), default="pipeline",
-                    help="pipeline (default): the pixel kernels of consecutive steps alternate over --pixel-streams streams, the sparse "
-                         "stages run on --sparse-streams higher-priority streams, a step's two halves chained by events; alternate: "
-                         "whole steps on one stream per context (round 1's schedule: the same steady state, a longer ramp)")
+                    help="batches in flight = depth of the pipeline (1 = strictly serial steps).  8 over 4 sparse streams since the end of "
+                         "round 3: alternating regions of ONE process put it 4.3-4.5 %% ahead of round 2's 4 over 2 on C3 and 1 %% on C5")
     ap.add_argument("--pixel-streams", type=int, default=2)
     ap.add_argument("--sparse-streams", type=int, default=4)
+    ap.add_argument("--device-results", action="store_true",
+                    help="leave the armour lists in HBM (rmcv_pipeline_config::host_results = 2) instead of copying every step's to pinned host memory")
     ap.add_argument("--gather", choices=("auto", "torch", "abi"), default="auto",
-                    help="the armour-list gather of a launched run: torch.distributed.gather (asynchronous; the default for more than "
-                         "one rank: rmcv_gather's multi-rank path has not run on hardware yet -- no multi-GPU box was available to this "
-                         "build) or rmcv_gather, the C-ABI entry point that calls RCCL itself (what a C++ host uses; the default for a "
-                         "launched single rank, where it moves nothing)")
+                    help="the armour-list gather of a launched run, through the pipeline's hook: torch.distributed.gather (asynchronous; the "
+                         "default for more than one rank: rmcv_gather's multi-rank path has not run on hardware yet -- no multi-GPU box "
+                         "was available to this build) or rmcv_gather, the C-ABI entry point that calls RCCL itself (what a C++ host "
+                         "uses: rmcv_pipeline_set_gather; the default for a launched single rank, where it moves nothing)")
+    ap.add_argument("--dev", action="store_true", help="accept the environment knobs that change the timed region (%s)" % ", ".join(DEV_KNOBS))
     return ap.parse_args(argv)
-
-
-VARIANTS = {"plain": 0, "stress": 1, "dense1": 11, "dense2": 12, "dense3": 13, "dense4": 14, "dense": 14}
-
-
-def variant_id(v):
-    return VARIANTS[v] if v in VARIANTS else int(v)
 
 
 def free_port():
@@ -138,9 +137,20 @@ def resolve_world(args, environ):
     return world, int(environ.get("RANK", "0")) if launched else 0, int(environ.get("LOCAL_RANK", "0")) if launched else 0, launched
 
 
+def dev_knobs(environ, dev):
+    """the environment knobs that are set; SystemExit when there are any and --dev was not given: a figure measured with one of
+    them is not the metric, and the line must not look as if it were"""
+    found = {k: environ[k] for k in DEV_KNOBS if environ.get(k)}
+    if found and not dev:
+        raise SystemExit("bench.py: %s set in the environment changes what the timed region runs; pass --dev to accept (the line then says so)"
+                         % ", ".join(sorted(found)))
+    return found
+
+
 def main():
     args = parse_args()
     world, rank, local_rank, launched = resolve_world(args, os.environ)
+    knobs = dev_knobs(os.environ, args.dev)
     if args.gpus > 1 and not launched:
         import torch                                             # (may call hipGetDeviceCount; harmless: the ranks are fresh children)
         have = torch.cuda.device_count()
@@ -158,8 +168,8 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, STAGE_ALL, STAGE_ARMOURS, STAGE_BINARY, STAGE_BLOBS,
-                          STAGE_HANDOVER, STAGE_IDENTITY, STAGE_NO_IMAGE, STAGE_POSE, OPT_HANDOVER, OPT_PIXEL_GROUPS, OPT_SPARSE_WAVES, Context, LegacyParams, default_params, synth)
+    from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, OPT_PIXEL_GROUPS, OPT_SPARSE_WAVES, STAGE_ALL, STAGE_BINARY,
+                          STAGE_IDENTITY, STAGE_NO_IMAGE, STAGE_POSE, Context, LegacyParams, Pipeline, default_params, synth)
     from rmcv_amd import dist as rdist
 
     if not torch.cuda.is_available():
@@ -174,74 +184,61 @@ def main():
     n = args.frames
     ns = max(1, args.streams)
     nthreads = min(16, os.cpu_count() or 1)
-    host = synth.batch(rank * n, n, W, H, CAMP_BLUE, args.variant, threads=nthreads)
-    # every batch in flight has its OWN frames (batch k of rank r starts at stream index r*n + k*1000003): steps that overlap
-    # in time must not share input, or the later one would be served from the 256 MB Infinity Cache instead of HBM
-    frames_k = [torch.from_numpy(host).to(dev)]                  # resident in HBM before any timing
-    # At least FOUR frame sets even when fewer batches are in flight: a launch that reads the gigabyte its predecessor has just read
-    # gets part of it from the 256 MB Infinity Cache -- k_binary alone, back to back: 0.215 ms on the same frames, 0.240 rotating over
-    # two sets, 0.2575 over four (tools/k1_pipe.py) -- which a camera feed never does.  Everything this file measures "alone" (the
-    # roofline kernel, the lone batch, the stage split, serial steps) therefore takes the contexts -- one per frame set, each with its own output buffers -- in turn (nxt below).
-    n_sets = max(ns, 4)
-    for k in range(1, n_sets):
-        frames_k.append(torch.from_numpy(synth.batch(rank * n + k * 1000003, n, W, H, CAMP_BLUE, args.variant, threads=nthreads)).to(dev))
-    frames = frames_k[0]
-    # Steps are double-buffered over `--streams` contexts (own work buffers, own HIP stream, same resident
-    # frames): while the sparse stages of step i (contours, fits, pairing: latency-bound, a few waves per CU) run,
-    # the HBM-bound pixel kernel of step i+1 streams -- what a continuous camera feed would do.
-    # (the dense streams have up to ~2100 contours per frame: beyond the default limit of 2048)
-    ctxs = [Context(device=local_rank, max_frames=n, max_width=W, max_height=H, max_contours=(4096 if args.variant >= 10 or args.density_sweep else 2048))
-            for _ in range(n_sets)]                                # the first ns carry the steps; all of them the "alone" measurements (nxt below)
-    stages = STAGE_ALL | (STAGE_IDENTITY if args.workload == "c5" else 0) | (STAGE_POSE if args.pose else 0)
-    if os.environ.get("RMCV_BENCH_STAGES"):                      # dev knob (tools/ab_streams.sh): a partial path is NOT the metric
-        stages = int(os.environ["RMCV_BENCH_STAGES"])
-    svm = synth.svm_weights() if args.workload == "c5" else None   # svm.xml is not in the reference: seeded stand-in weights
-    for k, c in enumerate(ctxs):
-        # several batches in flight: 4 wavefronts per frame in the sparse kernel (throughput); a lone batch: 8 (latency)
-        c.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
-        c.set_option(OPT_PIXEL_GROUPS, int(os.environ.get("RMCV_PIXEL_GROUPS", "2" if ns >= 2 else "3")))   # likewise: 2 pixel workgroups per CU when batches overlap, 3 alone
-        c.bind_device_frames(frames_k[k].data_ptr(), n, H, W, keepalive=frames_k[k])
-        if svm:
-            c.svm_load(*svm)
-        if args.pose:
-            c.pnp_load()                                          # camera constants of executable/main.cpp:7-19
-    ctx = ctxs[0]
-    rot = [0]
 
-    def nxt():
-        """the next context in turn: its frames were last read, and its buffers last written, n_sets launches ago"""
-        rot[0] = (rot[0] + 1) % n_sets
-        return ctxs[rot[0]]
+    def frame_sets(count, w, h, variant, one_dense=False):
+        """`count` batches of n frames in HBM.  Set k of rank r starts at stream index r*n + k*1000003: steps that follow each other
+        must not share input, or the later one would be served from the 256 MB Infinity Cache instead of HBM (k_binary alone, back
+        to back: 0.215 ms on the same frames, 0.240 rotating over two sets, 0.2575 over four) -- which a camera feed never does."""
+        out, first = [], None
+        for k in range(count):
+            hb = synth.batch(rank * n + k * 1000003, n, w, h, CAMP_BLUE, variant, threads=nthreads)
+            if one_dense:
+                hb[n // 2] = synth.frame(rank * n + k * 1000003 + n // 2, w, h, CAMP_BLUE, 14)
+            if first is None:
+                first = hb
+            out.append(torch.from_numpy(hb).to(dev))              # resident in HBM before any timing
+        return out, first
+
+    # At least FOUR frame sets even when fewer batches are in flight; with 8 in flight, 8 (as round 3 measured it).
+    n_sets = max(ns, 4)
+    frames_k, host = frame_sets(n_sets, W, H, args.variant)
+    stages = STAGE_ALL | (STAGE_IDENTITY if args.workload == "c5" else 0) | (STAGE_POSE if args.pose else 0)
+    if knobs.get("RMCV_BENCH_STAGES"):                            # dev knob: a partial path is NOT the metric
+        stages = int(knobs["RMCV_BENCH_STAGES"])
+    svm = synth.svm_weights() if args.workload == "c5" else None   # svm.xml is not in the reference: seeded stand-in weights
     params = default_params()                                     # main.cpp:172-176: BLUE, lb 80, close, ...
     legacy = LegacyParams(1.5, 80, 70, 10, 99999, int(os.environ.get("RMCV_LEGACY_FIT", "0"))) if args.workload == "legacy" else None
+    max_contours = 4096 if args.variant >= 10 else 2048           # (the dense streams have up to ~2100 contours per frame)
 
-    def run_path(c, st, hs):
-        if legacy is not None:
-            c.run_legacy(legacy, params, st, hs)
-        else:
-            c.run(params, st, hs)
-    cap = n * 8                                                   # armours per rank in the gather record (the synthetic stream has ~3 per frame)
-    head, _ = rdist.record_layout(n, cap)
-    recs_buf = [rdist.new_record(n, cap, dev) for _ in range(ns)]
-    gather_out = [rdist.new_gather_list(r) if use_dist else None for r in recs_buf]   # rank 0's receive buffers, one set per stream
-    # The gather of a step is enqueued on the stream its record was produced on (a gather stream of its own added stream-to-queue
-    # sharing and event hops that cost 0.07 ms per step).  A communicator's operations must execute in ONE order on every rank;
-    # the steps' gathers are issued in step order but on alternating streams, so each gather first waits (an event, on the GPU)
-    # for the previous step's gather -- ONE communicator: a second RCCL communicator in the process cost 0.07 ms per step
-    # by itself (0.335-0.343 against 0.268-0.284 ms, same box).  torch.distributed.gather synchronises the calling stream with the
-    # process group's own stream, which in the pipelined schedule holds up the next step's sparse kernels (711-721 k frames/s).
+    def make_pipeline(depth, pix, sp, w=W, h=H, mc=max_contours, with_svm=svm):
+        # a lone batch has the CUs to itself: 8 wavefronts per frame and 3 pixel workgroups per CU; batches in flight share every CU:
+        # 4 and 2 (the library's own rule, rmcv_pipeline_create; the dev knobs override it)
+        pl = Pipeline(device=local_rank, depth=depth, pixel_streams=pix, sparse_streams=sp, armour_cap=n * 8,
+                      sparse_waves=int(knobs.get("RMCV_SPARSE_WAVES", 0)), pixel_groups=int(knobs.get("RMCV_PIXEL_GROUPS", 0)),
+                      host_results=2 if args.device_results else 1, handover=1 if args.handover else 2,
+                      max_frames=n, max_width=w, max_height=h, max_contours=mc)
+        for c in pl.contexts:
+            if with_svm:
+                c.svm_load(*with_svm)
+            if args.pose:
+                c.pnp_load()                                      # camera constants of executable/main.cpp:7-19
+        return pl
+
+    pl = make_pipeline(ns, args.pixel_streams, args.sparse_streams)
+    info = pl.info
+    cap = info.armour_cap
+    head = info.armours_offset
+
+    # ---- the gather of a launched run rides on the pipeline's hook
     if args.gather == "auto":
         args.gather = "abi" if world == 1 else "torch"
-    abi_gathers = [rdist.AbiGather(local_rank)] if (use_dist and args.gather == "abi") else None
-    works = [None] * ns                                          # torch path: the asynchronous gather of the step that last used record k
-    ev_gath = [torch.cuda.Event() for _ in range(ns)]
-    abi_recv = [abi_gathers[0].new_recv(r) for r in recs_buf] if abi_gathers else None
-    gather_note = args.gather if use_dist else None
-    if abi_gathers:
+    gather_note, hook, abi_gather = (args.gather if use_dist else None), None, None
+    if use_dist and args.gather == "abi":
+        abi_gather = rdist.AbiGather(local_rank)
         # self-check before anything is timed: the communicator moves a stamped record from every rank to its slot on the root
         probe = torch.full((4096,), rank + 1, dtype=torch.uint8, device=dev)
-        rb = abi_gathers[0].new_recv(probe)
-        parts = abi_gathers[0].gather(probe, rb, torch.cuda.current_stream().cuda_stream)
+        rb = abi_gather.new_recv(probe)
+        parts = abi_gather.gather(probe, rb, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         ok = 1
         if rank == 0 and any(int(pt.min()) != r_ + 1 or int(pt.max()) != r_ + 1 for r_, pt in enumerate(parts)):
@@ -249,103 +246,34 @@ def main():
         t_ok = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.broadcast(t_ok, src=0)
         if int(t_ok.item()) != 1:          # never time a path that moved wrong bytes: fall back to torch.distributed.gather, and say so
-            abi_gathers[0].close()
-            abi_gathers, abi_recv, gather_note = None, None, "torch (rmcv_gather failed its self-check)"
+            abi_gather.close()
+            abi_gather, gather_note = None, "torch (rmcv_gather failed its self-check)"
+        else:
+            pl.set_gather(abi_gather._h, 0)
+    if use_dist and abi_gather is None:
+        hook = rdist.TorchGatherHook(info.record_bytes, ns, dev)
+        pl.set_hook(hook)
 
-    def gather_step(k, hs, stream_index):
-        if not use_dist:
-            return [recs_buf[k]]
-        if abi_gathers:
-            cur = torch.cuda.current_stream()
-            if step_no[0] > 1:
-                cur.wait_event(ev_gath[(k - 1) % ns])     # the previous step's gather (step_no was advanced already)
-            out = abi_gathers[0].gather(recs_buf[k], abi_recv[k], hs)
-            ev_gath[k].record(cur)
-            return out
-        # asynchronous: the process group's stream waits for the record, the calling stream does not wait for the collective
-        out, works[k] = rdist.gather_records(recs_buf[k], out=gather_out[k], async_op=True)
-        return out
-    # one stream per batch in flight (priorities alternate; with GPU_MAX_HW_QUEUES = 6 every stream has its own hardware queue, which is
-    # what lets kernels of two steps actually run concurrently
-    prios = [int(x) for x in os.environ.get("RMCV_BENCH_PRIOS", "").split(",") if x] or [0, -1]
-    streams = [torch.cuda.Stream(device=dev, priority=prios[k % len(prios)]) for k in range(ns)]
-    stream, sh, rec = streams[0], streams[0].cuda_stream, recs_buf[0]
+    cur = {"pl": pl, "stages": stages, "sets": frames_k, "w": W, "h": H}
     step_no = [0]
-    # software pipeline: stream A carries only k_binary (HBM-bound), stream B (higher priority) the sparse stages;
-    # step i's sparse chain waits for its own pixel kernel, the pixel kernel of step i+ns waits for the buffers
-    sAs = [torch.cuda.Stream(device=dev, priority=0) for _ in range(max(1, args.pixel_streams))]
-    sBs = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(max(1, args.sparse_streams))]
-    ev_bin = [torch.cuda.Event() for _ in range(ns)]
-    ev_done = [torch.cuda.Event() for _ in range(ns)]
-    pipelined = args.mode == "pipeline" and ns > 1
-    # frame-level hand-over (the sparse kernel beside its own pixel kernel): built, tested, measured equal on this schedule
-    # (tools/ab_vs_round2.sh: 0.2493 against 0.2502 ms per step, three alternating runs each) -- off unless asked for
-    handover = args.handover or os.environ.get("RMCV_BENCH_HANDOVER", "0") == "1"
-    ho = [handover]                                              # (a list: RMCV_BENCH_AB toggles it between regions)
-    for c in ctxs:
-        c.set_option(OPT_HANDOVER, 1 if handover else 0)
-
-    cur_stages = [stages]
-
-    shape = [ns, len(sAs), len(sBs)]                             # batches in flight, pixel streams, sparse streams IN USE (RMCV_BENCH_AB "sched" narrows them)
-    used = [False] * ns
 
     def step():
-        k = step_no[0] % shape[0]
-        first_use = not used[k]
-        used[k] = True
+        """ONE call into the library: the next batch, on the next frame set"""
+        fr = cur["sets"][step_no[0] % len(cur["sets"])]
         step_no[0] += 1
-        if not pipelined:
-            cx = nxt() if ns < n_sets else ctxs[k]                 # fewer batches in flight than frame sets: the contexts take turns (see n_sets)
-            with torch.cuda.stream(streams[k]):
-                run_path(cx, cur_stages[0], streams[k].cuda_stream)
-                if works[k] is not None:
-                    works[k].wait()                        # the record is rewritten: its previous gather must be through (stream-side wait)
-                cx.compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), streams[k].cuda_stream)
-                return gather_step(k, streams[k].cuda_stream, k)
-        sA = sAs[(step_no[0] - 1) % shape[1]]
-        with torch.cuda.stream(sA):
-            if not first_use:
-                sA.wait_event(ev_done[k])
-            ctxs[k].run(params, cur_stages[0] & (STAGE_BINARY | STAGE_NO_IMAGE), sA.cuda_stream)
-            ev_bin[k].record(sA)
-        sB = sBs[k % shape[2]]
-        with torch.cuda.stream(sB):
-            if ho[0]:
-                # frame-level hand-over: the sparse kernel is enqueued beside its own pixel kernel and takes each frame when its last
-                # strip is written (RMCV_STAGE_HANDOVER: the library orders it after what preceded that pixel kernel, not after it)
-                run_path(ctxs[k], (cur_stages[0] & ~(STAGE_BINARY | STAGE_NO_IMAGE)) | STAGE_HANDOVER, sB.cuda_stream)
-            else:
-                sB.wait_event(ev_bin[k])
-                if cur_stages[0] & ~(STAGE_BINARY | STAGE_NO_IMAGE):      # (RMCV_BENCH_STAGES=1, a dev knob: pixel kernels only)
-                    run_path(ctxs[k], cur_stages[0] & ~(STAGE_BINARY | STAGE_NO_IMAGE), sB.cuda_stream)
-            if abi_gathers and not first_use:
-                sB.wait_event(ev_gath[k])                  # the record is rewritten: its previous gather (ns steps back) must be through
-            if works[k] is not None:
-                works[k].wait()                            # likewise on the torch path (a stream-side wait on the collective, ns steps old)
-            if not os.environ.get("RMCV_BENCH_NO_COMPACT"):       # (dev knob: what the compaction kernel costs the chain; not the metric)
-                ctxs[k].compact_armours_into(recs_buf[k].data_ptr() + head, cap, recs_buf[k].data_ptr(), sB.cuda_stream)
-            # the context's buffers are free once its list is compacted: the gather only reads the record, so the pixel kernel
-            # that reuses this context does not wait for the collective (it would lengthen the chain the step rate hangs on)
-            ev_done[k].record(sB)
-            return gather_step(k, sB.cuda_stream, k % len(sBs))
+        return cur["pl"].submit(fr.data_ptr(), n, cur["h"], cur["w"], params, cur["stages"], legacy=legacy)
 
     def barrier():
-        # every stream that carried a gather is drained BEFORE the process group's own collectives (barrier, all_reduce) are
-        # enqueued: rmcv_gather's communicator and torch's never have kernels resident together -- with streams sharing
-        # hardware queues, a recv queued ahead of an all-reduce on one rank and the reverse on another could otherwise wait on each other
-        for wk in works:
-            if wk is not None:
-                wk.wait()
+        # the pipeline and every gather are drained BEFORE the process group's own collectives (barrier, all_reduce) are enqueued:
+        # rmcv_gather's communicator and torch's never have kernels resident together
+        cur["pl"].drain()
+        if hook is not None:
+            hook.wait_all()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    if os.environ.get("RMCV_BENCH_STAGES"):                      # dev knob: later stages need the planes of a full pass
-        for k in range(ns):
-            ctxs[k].run(params, STAGE_ALL, streams[k].cuda_stream)
-        torch.cuda.synchronize()
     def agree_max(x):
         """the same number on every rank (MAX): ranks must take the same decisions, a step contains a collective"""
         if not use_dist:
@@ -354,166 +282,168 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def regions(steps, repeats):
+        """`repeats` regions of exactly `steps` steps between barrier + synchronize pairs -> (wall seconds each, host enqueue seconds each)"""
+        rep, enq = [], []
+        for _ in range(repeats):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            enq.append(time.perf_counter() - t0)       # host time to enqueue the region's steps (the GPU may still be running them)
+            barrier()
+            rep.append(agree_max(time.perf_counter() - t0))
+        return rep, enq
+
+    def median(x):
+        s = sorted(x)
+        return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+    if knobs.get("RMCV_BENCH_STAGES"):                           # dev knob: later stages need the planes of a full pass
+        cur["stages"] = STAGE_ALL
+        for _ in range(ns):
+            step()
+        barrier()
+        cur["stages"] = stages
     for _ in range(args.warmup):
-        recs = step()
+        step()
     barrier()
     # warm-up by time as well: a GPU that idled while the frames were generated has to ramp its clocks; 5 steps are 1.5 ms
-    # (round 1: the driver's 20-step run read 822 k frames/s where 100-step runs read 905-950 k)
     tw, warm_steps = time.perf_counter(), 0
     while agree_max(time.perf_counter() - tw) < args.warmup_seconds:
         for _ in range(max(1, args.steps)):
-            recs = step()
+            step()
         warm_steps += max(1, args.steps)
         barrier()
     # the timed region: EXACTLY --steps steps between two (barrier + synchronize), MAX over ranks; repeated --repeats times,
     # value = the median repeat (SURVEY 8d: median and min over the passes)
-    rep_dt, enq_dt = [], []
-    for _ in range(max(1, args.repeats)):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            recs = step()
-        enq_dt.append(time.perf_counter() - t0)       # host time to enqueue the region's steps (the GPU may still be running them)
-        barrier()
-        rep_dt.append(agree_max(time.perf_counter() - t0))
-    srt = sorted(rep_dt)
-    dt = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    rep_dt, enq_dt = regions(args.steps, max(1, args.repeats))
+    dt = median(rep_dt)
     ms_per_step = dt / args.steps * 1e3
     value = world * n * args.steps / dt
-    # beside the metric: ONE long region (the same loop, 25 x --steps steps).  A timed region starts with an empty pipeline and ends by
-    # draining it -- the last steps' sparse chains run after the last pixel kernel -- which a 20-step region pays in full and a
-    # camera feed never does; the long region shows the steady state the schedule reaches.  Reported, never `value`.
+    # beside the metric: ONE long region (25 x --steps steps): a timed region starts with an empty pipeline and ends by draining it,
+    # which a 20-step region pays in full and a camera feed never does.  Reported, never `value`.
     steady = None
-    if not args.no_extras or os.environ.get("RMCV_BENCH_STEADY"):
+    if not args.no_extras:
         long_steps = 25 * args.steps
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(long_steps):
-            recs = step()
-        barrier()
-        dts = agree_max(time.perf_counter() - t0)
+        (dts,), _ = regions(long_steps, 1)
         steady = {"steps": long_steps, "ms_per_step": round(dts / long_steps * 1e3, 4), "frames_per_s": round(world * n * long_steps / dts, 1),
                   "note": "one region of 25 x --steps steps between barrier+synchronize pairs: the pipeline's fill and drain amortised; not the metric"}
 
-    # ---- dev tool: RMCV_BENCH_AB="<option id>:<value A>:<value B>[:<pairs>]" -- the same loop, regions of 5 x --steps steps alternating between
-    # two values of a context option (rmcv_ctx_set_option on every context), IN ONE PROCESS: the boxes drift by 2 % within a minute, which
-    # A/B runs of separate processes cannot tell from an effect of 1 %.  Printed as `ab`; not the metric.
-    ab = None
-    if os.environ.get("RMCV_BENCH_AB"):
-        f_ = os.environ["RMCV_BENCH_AB"].split(":")
-        # "sched:<contexts>,<pixel streams>,<sparse streams>:<...>": the SHAPE of the schedule instead of a context option (start the
-        # process with the larger of each: --streams / --pixel-streams / --sparse-streams, and GPU_MAX_HW_QUEUES to match)
-        # "lib:<path of another build of librmcv_hip.so>": regions alternate between THIS build and that one (a second set of contexts on
-        # the same frames; tools/build_variant*.sh make such builds) -- the only way to compare compile-time variants at better than +-3 %
-        libab_ = f_[0] == "lib"
-        if libab_:
-            from rmcv_amd import abi as abi_
-            lib_a, lib_b = abi_.lib(), abi_.load(os.path.abspath(f_[1]))
-            abi_.use(lib_b)
-            ctxs_b = [Context(device=local_rank, max_frames=n, max_width=W, max_height=H, max_contours=ctxs[0].limits.max_contours) for _ in range(n_sets)]
-            for k, c in enumerate(ctxs_b):
-                c.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
-                c.set_option(OPT_PIXEL_GROUPS, 2 if ns >= 2 else 3)
-                c.bind_device_frames(frames_k[k].data_ptr(), n, H, W, keepalive=frames_k[k])
-                if svm:
-                    c.svm_load(*svm)
-            abi_.use(lib_a)
-            ctxs_a = list(ctxs)
-            f_ = ["-2", "0", "1"] + f_[2:]
-        # "stages:<mask>:<mask>": what the steps run (1 = pixel kernel only, 3 = + findContours, 7 = + fits, 15 = the whole path): what does each stage COST the step?
-        stg_ = f_[0] == "stages"
-        if stg_:
-            masks_ = {0: int(f_[1]), 1: int(f_[2])}
-            keep_stages_ = cur_stages[0]
-            f_ = ["-4", "0", "1"] + f_[3:]
-        sched_ = f_[0] == "sched"
-        if sched_:
-            shapes_ = {0: [int(x) for x in f_[1].split(",")], 1: [int(x) for x in f_[2].split(",")]}
-            assert all(a <= b for sh in shapes_.values() for a, b in zip(sh, (ns, len(sAs), len(sBs))))
-            f_ = ["-1", "0", "1"] + f_[3:]
-        opt_, va_, vb_, pairs_ = int(f_[0]), int(f_[1]), int(f_[2]), int(f_[3]) if len(f_) > 3 else 12
-        reg_ = 5 * args.steps
-        res_ = {va_: [], vb_: []}
-        for pr in range(pairs_):
-            for v_ in ((va_, vb_) if pr % 2 == 0 else (vb_, va_)):
-                if stg_:
-                    barrier()
-                    cur_stages[0] = masks_[v_] | (keep_stages_ & ~15)
-                elif libab_:
-                    barrier()
-                    abi_.use(lib_b if v_ else lib_a)
-                    ctxs[:] = ctxs_b if v_ else ctxs_a
-                    for k_ in range(len(used)):
-                        used[k_] = False                           # (the other set's events say nothing about this set's buffers)
-                    step_no[0] = 0
-                elif sched_:
-                    barrier()
-                    shape[:] = shapes_[v_]
-                    step_no[0] = 0
-                else:
-                    for c in ctxs:
-                        c.set_option(opt_, v_)
-                if opt_ == OPT_HANDOVER:                           # the option AND the schedule that uses it (RMCV_STAGE_HANDOVER in step())
-                    barrier()
-                    ho[0] = bool(v_)
-                for _ in range(2 * ns):
-                    step()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(reg_):
-                    step()
-                barrier()
-                res_[v_].append((time.perf_counter() - t0) / reg_ * 1e3)
-        if stg_:
-            barrier()
-            cur_stages[0] = keep_stages_
-        elif libab_:
-            barrier()
-            abi_.use(lib_a)
-            ctxs[:] = ctxs_a
-            for k_ in range(len(used)):
-                used[k_] = False
-            step_no[0] = 0
-            for c in ctxs_b:
-                c.close()
-        elif sched_:
-            barrier()
-            shape[:] = [ns, len(sAs), len(sBs)]
-            step_no[0] = 0
-        else:
-            for c in ctxs:
-                c.set_option(opt_, va_)
-        if opt_ == OPT_HANDOVER:
-            barrier()
-            ho[0] = bool(va_)
-        ab = {"option": ("stage masks %d vs %d" % (masks_[0], masks_[1])) if stg_ else ("this build vs %s" % os.environ["RMCV_BENCH_AB"].split(":")[1]) if libab_ else ("sched %s vs %s" % (shapes_[0], shapes_[1])) if sched_ else opt_, "steps_per_region": reg_, "pairs": pairs_,
-              "a": {"value": va_, "median_ms": round(float(np.median(res_[va_])), 4), "mean_ms": round(float(np.mean(res_[va_])), 4), "each": [round(x, 4) for x in res_[va_]]},
-              "b": {"value": vb_, "median_ms": round(float(np.median(res_[vb_])), 4), "mean_ms": round(float(np.mean(res_[vb_])), 4), "each": [round(x, 4) for x in res_[vb_]]}}
-        ab["b_over_a"] = round(ab["b"]["mean_ms"] / ab["a"]["mean_ms"], 4)
-
-    # ---- what was computed (outside the timed region): status + gathered list sanity
-    cnt = ctx.counts()
+    # ---- what was computed (outside the timed region): the last `depth` batches through rmcv_pipeline_collect + the gathered list
+    barrier()
+    arm_by_set = {}
+    submitted = pl.get_info().submitted                          # tickets count the submits on this pipeline = the steps so far
+    for t_ in range(max(0, submitted - ns), submitted):
+        a_, o_ = pl.collect(t_)
+        arm_by_set[t_ % n_sets] = int(len(a_))                    # (step t ran on frame set t % n_sets)
+        assert o_[-1] == len(a_)
+    last_ticket = submitted - 1
+    ctx_last = pl.context_of(last_ticket)
+    cnt = ctx_last.counts()
     bad = int(np.count_nonzero(cnt["status"] & 15))
     slow = int(np.count_nonzero(cnt["status"] & 16))              # frames findContours handed to the sequential scanner
     mid = int(np.count_nonzero(cnt["status"] & 64))               # frames beyond the LDS tables: mid tier (tables in global memory)
-    n_arm_local = int(cnt["n_armours"].sum())
+    n_arm_local = arm_by_set.get(0, int(cnt["n_armours"].sum()))   # the armours of frame set 0 (= the frames the CPU baseline runs on)
     gathered = None
     if rank == 0:
+        if use_dist and hook is not None:
+            recs = hook.records(last_ticket)
+        elif use_dist:
+            d_, b_ = pl.gathered(last_ticket)
+            whole = rdist.tensor_at(d_, b_, dev)
+            recs = [whole[r_ * info.record_bytes:(r_ + 1) * info.record_bytes] for r_ in range(world)]
+        else:
+            d_, _s = pl.record(last_ticket)
+            recs = [rdist.tensor_at(d_, info.record_bytes, dev)]
         arm, offs = rdist.unpack_records(recs, n, cap)
         gathered = int(arm.shape[0])
         assert offs[-1] == gathered and len(offs) == world * n + 1
 
-    # ---- per-kernel durations with HIP events on the launch stream (same command, extra passes)
+    # ---- dev tool: RMCV_BENCH_AB -- regions of 5 x --steps steps alternating between two settings IN ONE PROCESS
+    ab = None
+    if knobs.get("RMCV_BENCH_AB"):
+        f_ = knobs["RMCV_BENCH_AB"].split(":")
+        kind = f_[0]
+        pairs_ = 12
+        pls, stg, opt_ = {0: pl, 1: pl}, {0: stages, 1: stages}, None
+        if kind == "lib":        # "lib:<path>": THIS build against another build of librmcv_hip.so (tools/build_variant*.sh)
+            from rmcv_amd import abi as abi_
+            lib_a, lib_b = abi_.lib(), abi_.load(os.path.abspath(f_[1]))
+            abi_.use(lib_b)
+            pls[1] = make_pipeline(ns, args.pixel_streams, args.sparse_streams)
+            abi_.use(lib_a)
+            label, pairs_ = "this build vs %s" % f_[1], int(f_[2]) if len(f_) > 2 else 12
+        elif kind == "sched":    # "sched:<depth,pix,sparse>:<depth,pix,sparse>": two shapes of the schedule
+            sh = [[int(x) for x in f_[1].split(",")], [int(x) for x in f_[2].split(",")]]
+            pls = {v: make_pipeline(*sh[v]) for v in (0, 1)}
+            label, pairs_ = "sched %s vs %s" % (sh[0], sh[1]), int(f_[3]) if len(f_) > 3 else 12
+        elif kind == "stages":   # "stages:<mask>:<mask>": what each stage COSTS the step (1 = pixel kernel only, 3 = + findContours, ...)
+            stg = {0: int(f_[1]) | (stages & ~15), 1: int(f_[2]) | (stages & ~15)}
+            label, pairs_ = "stage masks %s vs %s" % (f_[1], f_[2]), int(f_[3]) if len(f_) > 3 else 12
+        else:                    # "<option id>:<a>:<b>": rmcv_ctx_set_option on every context of the ring
+            opt_, vals = int(f_[0]), {0: int(f_[1]), 1: int(f_[2])}
+            label, pairs_ = "option %d: %d vs %d" % (opt_, vals[0], vals[1]), int(f_[3]) if len(f_) > 3 else 12
+        reg_, res_ = 5 * args.steps, {0: [], 1: []}
+        for pr in range(pairs_):
+            for v_ in ((0, 1) if pr % 2 == 0 else (1, 0)):
+                barrier()
+                cur["pl"], cur["stages"] = pls[v_], stg[v_]
+                if opt_ is not None:
+                    for c in pl.contexts:
+                        c.set_option(opt_, vals[v_])
+                for _ in range(2 * ns):
+                    step()
+                (d_,), _ = regions(reg_, 1)
+                res_[v_].append(d_ / reg_ * 1e3)
+        barrier()
+        cur["pl"], cur["stages"] = pl, stages
+        if opt_ is not None:
+            for c in pl.contexts:
+                c.set_option(opt_, vals[0])
+        for v_ in (0, 1):
+            if pls[v_] is not pl:
+                pls[v_].close()
+        ab = {"what": label, "steps_per_region": reg_, "pairs": pairs_,
+              "a": {"median_ms": round(float(np.median(res_[0])), 4), "mean_ms": round(float(np.mean(res_[0])), 4), "each": [round(x, 4) for x in res_[0]]},
+              "b": {"median_ms": round(float(np.median(res_[1])), 4), "mean_ms": round(float(np.mean(res_[1])), 4), "each": [round(x, 4) for x in res_[1]]}}
+        ab["b_over_a"] = round(ab["b"]["mean_ms"] / ab["a"]["mean_ms"], 4)
+
+    # ---- "alone" measurements on the ring's own contexts (the pipeline is drained), each on its own frames: HBM, not the Infinity Cache
+    barrier()
+    ctxs = pl.contexts
+    for k, c in enumerate(ctxs):
+        c.bind_device_frames(frames_k[k % n_sets].data_ptr(), n, H, W)
+    rot = [0]
+
+    def nxt():
+        """the next context in turn: its frames were last read, and its buffers last written, a ring ago"""
+        rot[0] = (rot[0] + 1) % len(ctxs)
+        return ctxs[rot[0]]
+
+    def run_path(c, st, hs):
+        if legacy is not None:
+            c.run_legacy(legacy, params, st, hs)
+        else:
+            c.run(params, st, hs)
+    stream = torch.cuda.Stream(device=dev)
+    sh = stream.cuda_stream
+    rec = rdist.new_record(n, cap, dev)
+    groups_in_steps, waves_in_steps = info.pixel_groups, info.sparse_waves
+
+    def settings(waves, groups):
+        for c in ctxs:
+            c.set_option(OPT_SPARSE_WAVES, waves)
+            c.set_option(OPT_PIXEL_GROUPS, groups)
+    # per-kernel durations with HIP events on the launch stream
     stage = np.zeros(5)
     reps = max(5, min(args.steps, 20))
     for _ in range(reps):
         stage += np.asarray(nxt().run_timed(params, stages, sh))
     stage /= reps
-    # one batch at a time, HIP events around the whole batch, median and min over >= 20 passes
+    # SURVEY 8(d): one batch at a time, HIP events around the whole batch, median and min over >= 20 passes -- at the latency settings
+    settings(8, 3)
     lone = []
-    for c in ctxs:
-        c.set_option(OPT_SPARSE_WAVES, 8)                          # the latency settings: a lone batch has the CUs to itself
-        c.set_option(OPT_PIXEL_GROUPS, 3)
     for _ in range(max(20, reps)):
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         cx = nxt()
@@ -525,68 +455,52 @@ def main():
         torch.cuda.synchronize()
         lone.append(ea.elapsed_time(eb))
     lone.sort()
-    for c in ctxs:
-        c.set_option(OPT_SPARSE_WAVES, int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")))
-        c.set_option(OPT_PIXEL_GROUPS, 2 if ns >= 2 else 3)
     fused_ms = None
     if legacy is None:          # what the steps actually launch: findContours + filter_lightblobs + filter_armours as one kernel
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(stream):
-            ctx.run(params, STAGE_ALL, sh)
+            ctxs[0].run(params, STAGE_ALL, sh)
             ea.record(stream)
             for _ in range(reps):
-                ctx.run(params, STAGE_ALL & ~STAGE_BINARY, sh)
+                ctxs[0].run(params, STAGE_ALL & ~STAGE_BINARY, sh)
             eb.record(stream)
         torch.cuda.synchronize()
         fused_ms = ea.elapsed_time(eb) / reps
-    if legacy is not None:      # run_timed drives the current API; time the legacy blob stage (k_match + k_pairs) on its own
-        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(stream):
-            ctx.run_legacy(legacy, params, STAGE_ALL, sh)
-            ea.record(stream)
-            for _ in range(reps):
-                ctx.run_legacy(legacy, params, STAGE_BLOBS | STAGE_ARMOURS, sh)
-            eb.record(stream)
-        torch.cuda.synchronize()
-        stage[4] += ea.elapsed_time(eb) / reps - stage[2] - stage[3]
-        stage[2], stage[3] = ea.elapsed_time(eb) / reps, 0.0
-    # the dominant kernel on its own: R back-to-back launches of k_binary between two HIP events recorded on the launch
-    # stream, so the event/launch latency (~20 us, visible in stage_ms.binary) is amortised and the figure is the
-    # kernel's duration, the same quantity rocprofv3 --kernel-trace reports
+    # the dominant kernel on its own: R back-to-back launches of k_binary between two HIP events recorded on the launch stream (the
+    # event/launch latency amortised: the figure is the kernel's duration, the quantity rocprofv3 --kernel-trace reports)
     R = 20
+
     def k_binary_alone(groups, rotate=True):
         for c in ctxs:
             c.set_option(OPT_PIXEL_GROUPS, groups)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         with torch.cuda.stream(stream):
-            ctx.run(params, STAGE_BINARY, sh)
+            ctxs[0].run(params, STAGE_BINARY, sh)
             e0.record(stream)
             for _ in range(R):
-                # rotate: every launch reads frames, and writes buffers, last touched n_sets launches ago -- HBM, not the Infinity Cache
-                (nxt() if rotate else ctx).run(params, STAGE_BINARY, sh)
+                (nxt() if rotate else ctxs[0]).run(params, STAGE_BINARY, sh)
             e1.record(stream)
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / R
-    # alone the kernel runs at the library's default of 3 workgroups per CU (what `--streams 1` and a lone batch launch, and what the
-    # serial rocprofv3 summary under profiles/ shows); the pipelined steps launch it with 2 per CU, two launches overlapping
-    groups_in_steps = 2 if ns >= 2 else 3
-    k1_ms = k_binary_alone(3)
+    k1_ms = k_binary_alone(3)                                       # the library's default of 3 workgroups per CU (a lone batch)
     k1_steps_ms = k_binary_alone(groups_in_steps) if groups_in_steps != 3 else k1_ms
-    k1_warm_ms = k_binary_alone(3, rotate=False)                    # rounds 1-2 and the first half of round 3 reported THIS as the roofline figure
-    # the pixel kernels ALONE in the schedule the steps launch them in (two streams, the steps' workgroups per CU, every context's
-    # own frames, no events): what the overlap of consecutive launches is worth (ramp and tail of one hidden behind the other)
+    k1_warm_ms = k_binary_alone(3, rotate=False)
+    # the pixel kernels ALONE in the schedule the steps launch them in (the steps' streams, workgroups per CU and frame sets, no sparse
+    # stage): what the overlap of consecutive launches is worth -- each hides the other's ramp and tail
+    settings(waves_in_steps, groups_in_steps)
     k1_pipe_ms = None
-    if pipelined:
-        torch.cuda.synchronize()
-        for rep in range(2):
-            t0p = time.perf_counter()
-            for i in range(4 * R):
-                ctxs[i % ns].run(params, STAGE_BINARY, sAs[i % len(sAs)].cuda_stream)
-            torch.cuda.synchronize()
-            k1_pipe_ms = (time.perf_counter() - t0p) / (4 * R) * 1e3
-    for c in ctxs:
-        c.set_option(OPT_PIXEL_GROUPS, groups_in_steps)
+    if ns > 1:
+        cur["stages"] = stages & (STAGE_BINARY | STAGE_NO_IMAGE)
+        for _ in range(ns):
+            step()
+        (d_,), _ = regions(4 * R, 1)
+        k1_pipe_ms = d_ / (4 * R) * 1e3
+        cur["stages"] = STAGE_ALL | (stages & ~15)              # (leave full lists behind in every slot)
+        for _ in range(ns):
+            step()
+        barrier()
+        cur["stages"] = stages
     achieved = n * BYTES_PER_FRAME / (k1_ms * 1e-3) / 1e9
 
     traffic = None
@@ -601,14 +515,17 @@ def main():
         except Exception:
             traffic = None
 
+    def frac(ms):
+        return round(n * BYTES_PER_FRAME / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    srt = sorted(rep_dt)
     out = {
         "metric": "frames/sec (%dx%d BGR) armour detect" % (W, H), "value": round(value, 1), "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup + warm_steps, "ms_per_step": round(ms_per_step, 4),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "timed_region": {"repeats": len(rep_dt), "ms_per_step_each": [round(d / args.steps * 1e3, 4) for d in rep_dt],
                          "ms_per_step_median": round(ms_per_step, 4), "ms_per_step_min": round(srt[0] / args.steps * 1e3, 4),
                          "value_at_min": round(world * n * args.steps / srt[0], 1), "warmup_steps_requested": args.warmup, "warmup_steps_by_time": warm_steps,
-                         "host_enqueue_ms_per_step": round(sorted(enq_dt)[len(enq_dt) // 2] / args.steps * 1e3, 4),
-                         "note": "each repeat = exactly `steps` steps between barrier+synchronize pairs; value/ms_per_step = the median repeat"},
+                         "host_enqueue_ms_per_step": round(median(enq_dt) / args.steps * 1e3, 4),
+                         "note": "each repeat = exactly `steps` calls of rmcv_pipeline_submit between barrier+synchronize pairs; value/ms_per_step = the median repeat"},
         "steady_state": steady,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%s: batch=%d/GPU %dx%d BGR, blue lb=80, close3x3 + findContours + lightblob fit + armour "
@@ -618,15 +535,18 @@ def main():
                                                 (" + solve_PnP (IPPE square) and world position per armour" if args.pose else ""),
                                                 " + RCCL gather of armour lists (C4)" if world > 1 else ""),
                    "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
-                   "double_buffered_steps": ns, "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "pixel_groups_per_cu": 2 if ns >= 2 else 3, "sparse_waves_per_frame": int(os.environ.get("RMCV_SPARSE_WAVES", "4" if ns >= 3 else "8")), "schedule": ("software pipeline: pixel kernels alternate over %d streams, sparse stages on %d higher-priority streams, chained by events" % (len(sAs), len(sBs)) if pipelined else "alternating streams"),
-                   "armours_rank0_shard": n_arm_local, "armours_gathered": gathered, "frames_over_capacity": bad,
-                   "frames_slow_path": slow, "frames_mid_tier": mid,
+                   "host_api": "rmcv_pipeline_submit (librmcv_hip.so): one call per step",
+                   "batches_in_flight": info.depth, "pixel_streams": info.pixel_streams, "sparse_streams": info.sparse_streams,
+                   "frame_sets": n_sets, "gpu_max_hw_queues": info.hw_queues_env, "pixel_groups_per_cu": groups_in_steps,
+                   "sparse_waves_per_frame": waves_in_steps, "results_to_host_every_step": info.host_results == 1,
+                   "stages": stages, "dev_knobs": knobs or None,
+                   "armours_rank0_shard": n_arm_local, "armours_by_frame_set": [arm_by_set.get(k) for k in range(n_sets)], "armours_gathered": gathered,
+                   "frames_over_capacity": bad, "frames_slow_path": slow, "frames_mid_tier": mid,
                    "rccl_ranks": (dist.get_world_size() if use_dist else None), "gather": gather_note,
-                   "frame_level_handover": handover},
+                   "frame_level_handover": info.handover == 1},
         "lone_batch_ms": {"median": round(lone[len(lone) // 2], 4), "min": round(lone[0], 4), "passes": len(lone),
                           "note": "one batch at a time on one stream, events around detect + compaction (latency, not the metric)"},
         **({"ab": ab} if ab else {}),
-        **({"ptrs": ["%x" % t.data_ptr() for t in frames_k]} if os.environ.get("RMCV_BENCH_PTRS") else {}),
         "path_hbm_frac": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
         "stage_ms": {"binary": round(float(stage[0]), 4), "contours": round(float(stage[1]), 4),
                      "blobs": round(float(stage[2]), 4), "armours": round(float(stage[3]), 4),
@@ -636,29 +556,29 @@ def main():
                      "fused_sparse": None if fused_ms is None else round(fused_ms, 4)},
         "roofline": {"kernel": "k_binary", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "in_schedule_frac": None if k1_pipe_ms is None else frac(k1_pipe_ms),
                      "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME, "avg_launch_ms": round(k1_ms, 4),
-                     "launches_timed": R, "workgroups_per_cu": 3, "contexts_rotated": n_sets,
-                     "same_frames_every_launch": {"avg_launch_ms": round(k1_warm_ms, 4),
-                                                  "frac": round(n * BYTES_PER_FRAME / (k1_warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                  "note": "NOT the roofline figure: 20 launches over the SAME gigabyte of frames, part of which the 256 MB Infinity "
-                                                          "Cache still holds from the launch before (what this file reported as `roofline` until the second half "
-                                                          "of round 3)"},
-                     "as_launched_by_the_steps": {"workgroups_per_cu": groups_in_steps, "avg_launch_ms": round(k1_steps_ms, 4),
-                                                  "frac": round(n * BYTES_PER_FRAME / (k1_steps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "launches_timed": R, "workgroups_per_cu": 3, "contexts_rotated": len(ctxs),
+                     "note": "frac: one launch at a time, cold (every launch on another context's frames and buffers); in_schedule_frac: the same "
+                             "kernel as the steps launch it -- two launches overlapping on two streams, each hiding the other's ramp and tail",
+                     "same_frames_every_launch": {"avg_launch_ms": round(k1_warm_ms, 4), "frac": frac(k1_warm_ms),
+                                                  "note": "NOT the roofline figure: 20 launches over the SAME gigabyte of frames, part of which the 256 MB "
+                                                          "Infinity Cache still holds from the launch before"},
+                     "as_launched_by_the_steps": {"workgroups_per_cu": groups_in_steps, "avg_launch_ms": round(k1_steps_ms, 4), "frac": frac(k1_steps_ms),
                                                   "note": "alone, back to back; in the steps two such launches overlap (4 workgroups per CU resident)"},
                      "pixel_kernels_only_in_the_steps_schedule": None if k1_pipe_ms is None else {
-                         "ms_per_launch": round(k1_pipe_ms, 4), "frac": round(n * BYTES_PER_FRAME / (k1_pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": "%d launches alternating over the steps' %d pixel streams and %d contexts, nothing else on the machine, wall clock "
-                                 "between two synchronisations: consecutive launches overlap, each hides the other's ramp and tail" % (4 * R, len(sAs), ns)}},
+                         "ms_per_launch": round(k1_pipe_ms, 4), "frac": frac(k1_pipe_ms),
+                         "note": "%d steps of the pipeline with the stage mask cut down to RMCV_STAGE_BINARY, wall clock between two drains" % (4 * R)}},
     }
 
+    extras = not args.no_extras and rank == 0 and world == 1
     if not args.no_extras and rank == 0:
         # BASELINE config 2: red team, subtract + threshold + morphology only
         ex = {}
         for name, morph in (("dilate", MORPH_DILATE), ("close", MORPH_CLOSE)):
             p2 = default_params(camp=CAMP_RED, morph=morph)
             for _ in range(2):
-                ctx.run(p2, STAGE_BINARY, sh)
+                ctxs[0].run(p2, STAGE_BINARY, sh)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
@@ -667,78 +587,82 @@ def main():
             d2 = time.perf_counter() - t0
             ex[name + "_fps"] = round(n * args.steps / d2, 1)
         out["c2_binary_only"] = ex
+    if extras and legacy is None:
         # detection only: the byte image `binary` is not written (RMCV_STAGE_NO_IMAGE; only the reference's debug view reads it,
         # executable/main.cpp:200-201).  NOT the metric: 3 B/px of algorithmic traffic instead of 4.
-        if legacy is None and world == 1:       # (the loop below calls step(), which gathers: a collective only rank 0 entered would hang)
-            cur_stages[0] = stages | STAGE_NO_IMAGE
-            for _ in range(args.warmup):
-                step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            d3 = (time.perf_counter() - t0) / args.steps
-            cur_stages[0] = stages
-            out["detect_only_no_image"] = {"fps": round(n / d3, 1), "ms_per_step": round(d3 * 1e3, 4), "bytes_per_frame": 3 * W * H,
-                                           "hbm_frac": round(n * 3 * W * H / d3 / 1e9 / HBM_PEAK_GBS, 4),
-                                           "note": "same armour lists; the 0/255 image is not materialised"}
+        cur["stages"] = stages | STAGE_NO_IMAGE
+        for _ in range(ns):
+            step()
+        (d3,), _ = regions(args.steps, 1)
+        d3 /= args.steps
+        cur["stages"] = stages
+        out["detect_only_no_image"] = {"fps": round(n / d3, 1), "ms_per_step": round(d3 * 1e3, 4), "bytes_per_frame": 3 * W * H,
+                                       "hbm_frac": round(n * 3 * W * H / d3 / 1e9 / HBM_PEAK_GBS, 4),
+                                       "note": "same armour lists; the 0/255 image is not materialised"}
 
-    if args.density_sweep and world == 1:
-        # ---- throughput against scene density (beside the metric): the same pipelined loop on the plain stream, the four dense
-        # levels, and a plain batch with ONE dense4 frame in it (a camera frame with a lit window must not stall its launch)
-        sweep = []
-        region = max(100, 5 * args.steps)
-        for label, var, one in [("plain", 0, False), ("dense1", 11, False), ("dense2", 12, False), ("dense3", 13, False),
-                                ("dense4", 14, False), ("plain + one dense4 frame per batch", 0, True)]:
-            if os.environ.get("RMCV_BENCH_SWEEP_LEVELS") and label.split()[0] not in os.environ["RMCV_BENCH_SWEEP_LEVELS"].split(",") \
-                    and not (one and "one" in os.environ["RMCV_BENCH_SWEEP_LEVELS"].split(",")):
-                continue                                           # dev knob (tools/ab_process_r3.sh one_dense): a subset of the levels
-            for k in range(ns):
-                hb = synth.batch(rank * n + k * 1000003, n, W, H, CAMP_BLUE, var, threads=nthreads)
-                if one:
-                    hb[n // 2] = synth.frame(rank * n + k * 1000003 + n // 2, W, H, CAMP_BLUE, 14)
-                frames_k[k].copy_(torch.from_numpy(hb))
-            torch.cuda.synchronize()
-            for _ in range(20):
+    if extras and args.workload == "c3" and args.variant == 0:
+        # ---- throughput against scene density (beside the metric), the steps' own loop and schedule: the plain stream, dense levels
+        # (up to +2000 specks and 13 lit windows per frame), and a plain batch with ONE dense4 frame in it (a camera frame with a lit
+        # window must not stall its launch).  Four frame sets per level (consecutive steps never share input).
+        t_sw = time.perf_counter()
+        levels = [("plain", 0, False), ("dense2", 12, False), ("dense4", 14, False), ("plain + one dense4 frame per batch", 0, True)]
+        if args.density_sweep:
+            levels = [("plain", 0, False), ("dense1", 11, False), ("dense2", 12, False), ("dense3", 13, False), ("dense4", 14, False),
+                      ("plain + one dense4 frame per batch", 0, True)]
+        barrier()
+        pl_d = make_pipeline(ns, args.pixel_streams, args.sparse_streams, mc=4096)
+        sweep, region = [], max(60, 3 * args.steps)
+        for label, var, one in levels:
+            sets_, _ = (frames_k[:4], None) if (var == 0 and not one) else frame_sets(4, W, H, var, one)
+            cur["pl"], cur["sets"] = pl_d, sets_
+            for _ in range(2 * ns):
                 step()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(region):
-                step()
-            barrier()
-            dsw = (time.perf_counter() - t0) / region
-            st_ = ctx.counts()["status"]
-            cnt_ = ctx.counts()
+            (dsw,), _ = regions(region, 1)
+            dsw /= region
+            cnt_ = pl_d.context_of(pl_d.get_info().submitted - 1).counts()
+            st_ = cnt_["status"]
             sweep.append({"stream": label, "ms_per_step": round(dsw * 1e3, 4), "frames_per_s": round(n / dsw, 1),
                           "contours_per_frame": round(float(cnt_["n_contours"].mean()), 1),
                           "points_per_frame": round(float(cnt_["n_points"].mean()), 1),
                           "frames_mid_tier": int(np.count_nonzero(st_ & 64)), "frames_slow_path": int(np.count_nonzero(st_ & 16)),
                           "frames_over_capacity": int(np.count_nonzero(st_ & 15))})
-        out["density_sweep"] = {"steps_per_region": region, "levels": sweep,
-                                "note": "steady-state regions of the bench's own loop (%d batches in flight over %d sparse streams), rank-0 shard; not the metric" % (ns, len(sBs))}
-        if not os.environ.get("RMCV_BENCH_SWEEP_LEVELS"):
-            # The dense frame of a batch keeps ONE workgroup busy for 0.5-1 ms after the batch's other frames are through, and the
-            # launches behind it on its sparse stream wait for it.  With a sparse stream PER batch in flight nothing is behind it:
-            # the same two levels under that schedule, in a child process (the schedule is fixed when the streams are created).
-            import subprocess
-            env = dict(os.environ, RMCV_BENCH_SWEEP_LEVELS="plain,one", GPU_MAX_HW_QUEUES="12")
-            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-frames", "0",
-                   "--no-extras", "--density-sweep", "--streams", "8", "--sparse-streams", "8", "--frames", str(n), "--workload", args.workload]
-            try:
-                cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-                dj = json.loads(cp.stdout.strip().splitlines()[-1])
-                out["density_sweep"]["deep_schedule"] = {
-                    "batches_in_flight": 8, "sparse_streams": 8, "gpu_max_hw_queues": 12, "ms_per_step_20_step_regions": dj["ms_per_step"],
-                    "levels": dj["density_sweep"]["levels"],
-                    "note": "the same loop with 8 batches in flight and one sparse stream per batch (child process): one dense frame per batch no longer holds up the launches behind it"}
-            except Exception as e:  # noqa: BLE001 -- a side measurement: report, never fail the bench line
-                out["density_sweep"]["deep_schedule"] = {"error": repr(e)[:200]}
-        for k in range(ns):                                        # back to the run's own stream for what follows
-            frames_k[k].copy_(torch.from_numpy(host if k == 0 else synth.batch(rank * n + k * 1000003, n, W, H, CAMP_BLUE, args.variant, threads=nthreads)))
-        torch.cuda.synchronize()
+            del sets_
+        barrier()
+        cur["pl"], cur["sets"] = pl, frames_k
+        pl_d.close()
+        base_ = sweep[0]["ms_per_step"]
+        for lv in sweep:
+            lv["x_plain"] = round(lv["ms_per_step"] / base_, 3)
+        out["density_sweep"] = {"steps_per_region": region, "levels": sweep, "seconds": round(time.perf_counter() - t_sw, 1),
+                                "note": "steady-state regions of the steps' own loop (%d batches in flight over %d sparse streams, 4 frame sets per level); "
+                                        "x_plain = against this sweep's own plain level; not the metric" % (info.depth, info.sparse_streams)}
 
-    if rank == 0 and world == 1 and not args.no_extras:
+    if extras and args.workload == "c3" and args.variant == 0 and not args.pose:
+        # ---- BASELINE config 5 in short: 256 x 1920x1200 + icon rectification + SVM, 4 batches in flight over 4 frame sets
+        t_c5 = time.perf_counter()
+        W5, H5 = WORKLOADS["c5"]
+        barrier()
+        sets5, _ = frame_sets(4, W5, H5, 0)
+        svm5 = synth.svm_weights()
+        pl5 = make_pipeline(min(ns, 4), min(args.pixel_streams, 2), min(args.sparse_streams, 4), w=W5, h=H5, mc=2048, with_svm=svm5)
+        cur.update(pl=pl5, sets=sets5, w=W5, h=H5, stages=STAGE_ALL | STAGE_IDENTITY)
+        for _ in range(8):
+            step()
+        rep5, _ = regions(20, 3)
+        d5 = median(rep5) / 20
+        last5 = pl5.get_info().submitted - 1
+        a5, _o5 = pl5.collect(last5)
+        ident5 = pl5.context_of(last5).identities()
+        barrier()
+        cur.update(pl=pl, sets=frames_k, w=W, h=H, stages=stages)
+        out["c5"] = {"workload": "C5: batch=%d %dx%d BGR, full path + icon rectification + 7-class linear SVM (synthetic weights)" % (n, W5, H5),
+                     "ms_per_step": round(d5 * 1e3, 4), "frames_per_s": round(n / d5, 1), "hbm_frac": round(n * 4 * W5 * H5 / d5 / 1e9 / HBM_PEAK_GBS, 4),
+                     "batches_in_flight": pl5.info.depth, "regions": "3 x 20 steps (median)", "armours_last_batch": int(len(a5)),
+                     "identities_last_batch": int(len(ident5)), "seconds": round(time.perf_counter() - t_c5, 1)}
+        pl5.close()
+        del sets5
+
+    if extras:
         # ---- the per-frame drop-in path (outside the timed region): the three C-ABI calls exactly as include/rmcv_shim.hpp issues
         # them for an unchanged executable/main.cpp:172-176, on ONE host frame at a time (pageable memory, as a cv::Mat is)
         import ctypes as C
@@ -885,10 +809,11 @@ def main():
                                                    "armours": tot_ev}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    for g_ in (abi_gathers or []):
-        g_.close()
+    barrier()                                       # rank 0 has the extras and the CPU baseline to itself: leave together
+    pl.close()
+    if abi_gather is not None:
+        abi_gather.close()
     if use_dist:
-        barrier()                                   # rank 0 has the extras and the CPU baseline to itself: leave together
         dist.destroy_process_group()
 
 

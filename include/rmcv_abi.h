@@ -171,15 +171,8 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * finished by the first launch.  Results are identical.  Measured: worth 14 % where EVERY frame is that dense, costs
  * 20-30 % where a few frames per batch are (they then run after the others instead of beside them). */
 #define RMCV_OPT_DENSE_DEFER 7
-/* RMCV_OPT_PIXEL_STAGGER: the pixel kernel's second and third workgroup of every CU wait `value` and 2 x `value` ticks of 10 ns
- * before their first load (0, the default: all start together).  A measurement knob; results are identical. */
-#define RMCV_OPT_PIXEL_STAGGER 8
-/* RMCV_OPT_SPARSE_PRIO: instruction-issue priority (s_setprio) of the per-frame kernel's waves, 0..3; 3 (default).  A measurement
- * knob; results are identical. */
-#define RMCV_OPT_SPARSE_PRIO 9
-/* RMCV_OPT_PIXEL_TAPER: 1: the first 16 and the last 32 strips of every XCD's queue of the pixel kernel are handed out as four
- * 8-row pieces each (shorter ramp and tail, more halo rows read); 0 (default).  A measurement knob; results are identical. */
-#define RMCV_OPT_PIXEL_TAPER 10
+/* (option ids 8-10 were round 3's measurement knobs PIXEL_STAGGER, SPARSE_PRIO, PIXEL_TAPER: every setting measured 1.000 or worse;
+ * removed together with their kernel branches -- rmcv_ctx_set_option answers RMCV_ERR_BAD_ARG) */
 /* RMCV_OPT_PIXEL_HALO_NT: cache policy of the pixel kernel's loads of the rows a strip shares with its neighbours -- 0 (default):
  * cacheable (the neighbouring strip finds them in L2); 1: non-temporal like every other load.  Which is faster depends on the
  * device the process finds itself on and on the workload (the pixel kernels alone gain 3.6 % with 1 on some boxes and
@@ -375,9 +368,97 @@ int  rmcv_track_predict(rmcv_track* t, int64_t new_timestamp, double tick_freque
 /* one pass of the tracking thread (executable/main.cpp:60-85) over this frame's observations: targets whose bounding box
  * overlaps an observation by IoU > 0.5 take it (and it leaves the list), the others age (dropped after 26 misses -- with
  * the reference's skip of the target behind an erased one) or coast; what is left of the observations becomes new targets.
- * *n_obs is 0 afterwards.  Any number of observations; RMCV_ERR_CAPACITY when *n_tracking + *n_obs > cap (checked before
- * anything is changed) or when a target would see its 33rd distinct identity (lists handed back consistent). */
+ * *n_obs is 0 afterwards.  Any number of observations; RMCV_ERR_CAPACITY when the list the pass would leave behind (surviving
+ * targets + unmatched observations, counted by a dry run before anything is changed) exceeds cap -- N targets re-observed by N
+ * matching observations need cap >= N, as the reference's vectors do -- or when a target would see its 33rd distinct identity
+ * (lists handed back consistent). */
 int  rmcv_track_step(rmcv_track* tracking, int32_t* n_tracking, int cap, rmcv_track* observations, int32_t* n_obs, double tick_frequency);
+
+/* ---- pipelined batches: the process loop behind the ABI ------------------------------------------------------------------------
+ * The reference's process_function is a `while (1)` that takes the newest camera frame, runs the three detection calls and hands
+ * the armours on (executable/main.cpp:163-209).  Its batch form on one MI355X: `depth` batches in flight, each in a context of its
+ * own; the HBM-bound pixel kernels of consecutive batches alternate over `pixel_streams` HIP streams (two launches overlap: each
+ * hides the other's ramp and tail), the latency-bound per-frame kernels run on `sparse_streams` higher-priority streams; a batch's
+ * two halves and the reuse of its context are chained by events, the armour lists are compacted frame-major on the device and (by
+ * default) copied to pinned host memory behind that.  This is the schedule bench.py's figure is measured on -- owned by the library:
+ * a C or C++ host gets it with three calls.
+ *
+ *     rmcv_pipeline_create(0, &limits, NULL, &pl);
+ *     for (;;) { rmcv_pipeline_submit(pl, d_frames, n, w, h, stride, pitch, &params, RMCV_STAGE_ALL, &ticket);
+ *                if (ticket >= depth) rmcv_pipeline_collect(pl, ticket - depth + 1, armours, cap, frame_offs, &n_total); }
+ *
+ * Single-owner like a context: calls on one pipeline must not overlap.  The frames handed to submit are borrowed until the ticket
+ * is collected (or waited for).  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once
+ * when the HIP runtime starts: the default schedule wants 8 or more (kernels of two batches that share a queue cannot overlap).  The
+ * library sets GPU_MAX_HW_QUEUES=12 in the process environment when it is LOADED and the variable is unset -- effective if no HIP
+ * call preceded the load; rmcv_pipeline_get_info reports what the variable reads. */
+typedef struct rmcv_pipeline rmcv_pipeline;
+typedef struct {            /* 0 in any field = the default; rmcv_default_pipeline_config fills them in */
+    int32_t depth;          /* batches in flight = contexts in the ring                         (8)  */
+    int32_t pixel_streams;  /*                                                                  (2)  */
+    int32_t sparse_streams; /*                                                                  (4)  */
+    int32_t armour_cap;     /* armours a batch's compacted list holds                (8 per frame)   */
+    int32_t sparse_waves;   /* RMCV_OPT_SPARSE_WAVES of the ring's contexts   (4 if depth >= 3 else 8) */
+    int32_t pixel_groups;   /* RMCV_OPT_PIXEL_GROUPS                          (2 if depth >= 2 else 3) */
+    int32_t host_results;   /* 1: every list is copied to pinned host memory behind its compaction (collect then copies from there);
+                             * 2: lists stay on the device until collected                      (1)  */
+    int32_t handover;       /* 1: RMCV_OPT_HANDOVER + RMCV_STAGE_HANDOVER (frame-level hand-over); 2: off           (2)  */
+} rmcv_pipeline_config;
+typedef struct {
+    int32_t depth, pixel_streams, sparse_streams, armour_cap, sparse_waves, pixel_groups, host_results, handover;
+    int32_t max_frames;
+    int32_t hw_queues_env;     /* what GPU_MAX_HW_QUEUES reads in this process (0: unset) */
+    int32_t hw_queues_wanted;  /* 1 + pixel_streams + sparse_streams (+ 1 with a communicator) */
+    int32_t _pad;
+    int64_t record_bytes;      /* a batch's record in HBM: [frame_offs: max_frames + 1 int32 | status: int32 | pad to 16 B | armours: armour_cap x 88 B] */
+    int64_t armours_offset;    /* = the layout of rmcv_amd/dist.py, the payload of rmcv_gather */
+    uint64_t submitted, collected;
+} rmcv_pipeline_info;
+void rmcv_default_pipeline_config(rmcv_pipeline_config* c);
+int  rmcv_pipeline_create(int device, const rmcv_limits* limits /* nullable */, const rmcv_pipeline_config* cfg /* nullable */, rmcv_pipeline** out);
+void rmcv_pipeline_destroy(rmcv_pipeline* pl);   /* drains first */
+const char* rmcv_pipeline_last_error(const rmcv_pipeline* pl);
+int  rmcv_pipeline_get_info(const rmcv_pipeline* pl, rmcv_pipeline_info* out);
+/* the context of ring slot `slot` (0 .. depth-1), for set-up that is per context: rmcv_svm_load (RMCV_STAGE_IDENTITY),
+ * rmcv_pnp_load (RMCV_STAGE_POSE), rmcv_ctx_set_option; and for the per-stage getters on a ticket that has been waited for
+ * (ticket t lives in slot t % depth until ticket t + depth is submitted).  Owned by the pipeline. */
+rmcv_ctx* rmcv_pipeline_context(rmcv_pipeline* pl, int slot);
+/* enqueue one batch of n_frames frames that are resident in HBM (layout as rmcv_batch_set_device_frames); stages must include
+ * RMCV_STAGE_BINARY.  Asynchronous; *ticket (0, 1, 2, ...) names the batch.  The slot's previous batch (ticket - depth) is
+ * overwritten: collect it first. */
+int  rmcv_pipeline_submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch,
+                          const rmcv_params* p, int stages, uint64_t* ticket);
+/* the same with rm::FindLightBlobs as the blob stage (rmcv_batch_run_legacy) */
+int  rmcv_pipeline_submit_legacy(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch,
+                                 const rmcv_params* p, const rmcv_legacy_params* lp, int stages, uint64_t* ticket);
+/* block until the batch is through (its record complete in HBM and, with host_results, on the host) */
+int  rmcv_pipeline_wait(rmcv_pipeline* pl, uint64_t ticket);
+/* wait + hand the batch's armours over, frame-major, in submission order of the frames: frame_offs (nullable) has n_frames + 1
+ * entries.  RMCV_ERR_CAPACITY: a frame exceeded a context limit, or the list exceeds armour_cap / cap (*n_total says what is
+ * needed); RMCV_ERR_BAD_ARG: the ticket was never issued or its slot has been reused. */
+int  rmcv_pipeline_collect(rmcv_pipeline* pl, uint64_t ticket, rmcv_armour* armours_out, int cap, int32_t* frame_offs, int32_t* n_total);
+/* everything submitted so far is through */
+int  rmcv_pipeline_drain(rmcv_pipeline* pl);
+/* device view of a ticket's record and the stream it is produced on (work enqueued there runs behind the compaction) */
+int  rmcv_pipeline_record(rmcv_pipeline* pl, uint64_t ticket, void** d_record, void** hip_stream);
+/* Hook called by rmcv_pipeline_submit, on the submitting thread, right behind the enqueue of a batch's compaction: for a consumer
+ * that lives on the device (a collective, a tracker kernel).  What the hook enqueues on `hip_stream` is ordered behind the record;
+ * the record's next rewrite (ticket + depth) is ordered behind what the hook enqueued there.  A hook that moves the record on
+ * ANOTHER stream returns an event through *done_event (a hipEvent_t it owns, recorded when the record has been read): the rewrite
+ * then waits for it.  A non-zero return fails the submit. */
+typedef int (*rmcv_pipeline_hook)(void* user, uint64_t ticket, void* d_record, int64_t record_bytes, void* hip_stream, void** done_event);
+int  rmcv_pipeline_set_hook(rmcv_pipeline* pl, rmcv_pipeline_hook fn, void* user);
+/* built-in hook for BASELINE config 4: every batch's record is gathered to `root` with rmcv_gather on `comm` (every rank submits the
+ * same number of batches).  On the root, *d_recv of rmcv_pipeline_gathered is n_ranks x record_bytes in rank order, valid once the
+ * ticket has been waited for, until ticket + depth is submitted. */
+int  rmcv_pipeline_set_gather(rmcv_pipeline* pl, rmcv_comm* comm, int root);
+int  rmcv_pipeline_gathered(rmcv_pipeline* pl, uint64_t ticket, void** d_recv, int64_t* bytes);
+
+/* ---- device memory for hosts without HIP headers (tools/pipeline_bench.c): frames resident in HBM ------------------------------- */
+int  rmcv_device_alloc(int device, int64_t bytes, void** d_ptr);
+void rmcv_device_free(int device, void* d_ptr);
+int  rmcv_device_upload(int device, void* d_dst, const void* h_src, int64_t bytes);   /* synchronous */
+int  rmcv_device_download(int device, void* h_dst, const void* d_src, int64_t bytes); /* synchronous */
 
 /* ---- synthetic stream: host generator, integer-only, bit-reproducible --- */
 int      rmcv_synth_frame(uint8_t* bgr, int w, int h, int stride, uint64_t frame_index, int camp, int variant);

@@ -37,9 +37,6 @@ OPT_RUN_AHEAD = 4
 OPT_CONTOUR_TIER = 5
 OPT_HANDOVER = 6
 OPT_DENSE_DEFER = 7
-OPT_PIXEL_STAGGER = 8
-OPT_SPARSE_PRIO = 9
-OPT_PIXEL_TAPER = 10
 OPT_PIXEL_HALO_NT = 11
 STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE, STAGE_NO_IMAGE = 1, 2, 4, 8, 15, 16, 32, 64
 STAGE_HANDOVER = 128
@@ -55,6 +52,9 @@ EXPORTS = [
     "rmcv_svm_load", "rmcv_classify_armours", "rmcv_batch_get_identities", "rmcv_batch_get_icons",
     "rmcv_default_pnp_config", "rmcv_pnp_load", "rmcv_locate_armours", "rmcv_batch_set_base2gripper", "rmcv_batch_get_poses",
     "rmcv_max_iou", "rmcv_identity_max", "rmcv_comm_unique_id", "rmcv_comm_create", "rmcv_comm_destroy", "rmcv_comm_info", "rmcv_comm_last_error", "rmcv_gather",
+    "rmcv_default_pipeline_config", "rmcv_pipeline_create", "rmcv_pipeline_destroy", "rmcv_pipeline_last_error", "rmcv_pipeline_get_info", "rmcv_pipeline_context",
+    "rmcv_pipeline_submit", "rmcv_pipeline_submit_legacy", "rmcv_pipeline_wait", "rmcv_pipeline_collect", "rmcv_pipeline_drain", "rmcv_pipeline_record",
+    "rmcv_pipeline_set_hook", "rmcv_pipeline_set_gather", "rmcv_pipeline_gathered", "rmcv_device_alloc", "rmcv_device_free", "rmcv_device_upload", "rmcv_device_download",
     "rmcv_track_init", "rmcv_track_reset", "rmcv_track_update", "rmcv_track_predict", "rmcv_track_step", "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
 ]
 
@@ -85,6 +85,24 @@ class Limits(C.Structure):
                 ("max_armours", C.c_int32), ("_pad", C.c_int32)]
 
 
+class PipelineConfig(C.Structure):
+    """rmcv_pipeline_config (0 in a field = the default)"""
+    _fields_ = [("depth", C.c_int32), ("pixel_streams", C.c_int32), ("sparse_streams", C.c_int32), ("armour_cap", C.c_int32),
+                ("sparse_waves", C.c_int32), ("pixel_groups", C.c_int32), ("host_results", C.c_int32), ("handover", C.c_int32)]
+
+
+class PipelineInfo(C.Structure):
+    """rmcv_pipeline_info"""
+    _fields_ = [("depth", C.c_int32), ("pixel_streams", C.c_int32), ("sparse_streams", C.c_int32), ("armour_cap", C.c_int32),
+                ("sparse_waves", C.c_int32), ("pixel_groups", C.c_int32), ("host_results", C.c_int32), ("handover", C.c_int32),
+                ("max_frames", C.c_int32), ("hw_queues_env", C.c_int32), ("hw_queues_wanted", C.c_int32), ("_pad", C.c_int32),
+                ("record_bytes", C.c_int64), ("armours_offset", C.c_int64), ("submitted", C.c_uint64), ("collected", C.c_uint64)]
+
+
+# rmcv_pipeline_hook: int (*)(void* user, uint64_t ticket, void* d_record, int64_t record_bytes, void* hip_stream, void** done_event)
+PIPELINE_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p))
+
+
 class RmcvError(RuntimeError):
     def __init__(self, code, msg=""):
         super().__init__("rmcv error %d: %s" % (code, msg))
@@ -104,6 +122,22 @@ def load(path):
     L.rmcv_synth_checksum.restype = C.c_uint64
     L.rmcv_ctx_destroy.restype = None
     L.rmcv_ctx_destroy.argtypes = [C.c_void_p]
+    L.rmcv_pipeline_last_error.restype = C.c_char_p
+    L.rmcv_pipeline_last_error.argtypes = [C.c_void_p]
+    L.rmcv_pipeline_destroy.restype = None
+    L.rmcv_pipeline_destroy.argtypes = [C.c_void_p]
+    L.rmcv_pipeline_context.restype = C.c_void_p
+    L.rmcv_pipeline_context.argtypes = [C.c_void_p, C.c_int]
+    # the call of the timed region: fixed argument types, so that ctypes converts without looking at the Python objects' types
+    L.rmcv_pipeline_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+    L.rmcv_pipeline_submit_legacy.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.rmcv_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64]
+    L.rmcv_pipeline_collect.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.rmcv_pipeline_record.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.rmcv_pipeline_gathered.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.rmcv_pipeline_set_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.rmcv_device_free.restype = None
+    L.rmcv_device_free.argtypes = [C.c_int, C.c_void_p]
     return L
 
 

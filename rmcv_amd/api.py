@@ -35,9 +35,17 @@ class Context:
         self.device = device
         self._frames_ref = None
 
+    @classmethod
+    def borrowed(cls, handle, limits, device=0):
+        """a view of a context somebody else owns (a slot of a Pipeline): the same methods, no destroy"""
+        self = cls.__new__(cls)
+        self.limits, self._h, self._made_by, self.device, self._frames_ref, self._borrowed = limits, C.c_void_p(handle), lib(), device, None, True
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self._made_by.rmcv_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._made_by.rmcv_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):

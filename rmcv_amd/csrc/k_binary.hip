@@ -114,10 +114,8 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
                                                  int* __restrict__ strip_ctr, int taper_head, int taper_tail,
-                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq, unsigned* started, int knobs)
+                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq, unsigned* started, int halo_nt /* RMCV_OPT_PIXEL_HALO_NT */)
 {
-    const int stagger = knobs & 0xFFFFF;        // RMCV_OPT_PIXEL_STAGGER
-    const bool halo_nt = (knobs >> 20) & 1;     // RMCV_OPT_PIXEL_HALO_NT
     extern __shared__ uint64_t smem[];
     // "this launch is RUNNING": the stream that carries the sparse kernel of the batch waits for this word (hipStreamWaitValue32,
     // rmcv_host.hip) before it lets workgroups loose that spin for this launch's frames -- a spinning consumer must never be on
@@ -165,14 +163,6 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
     int pub_f = -1, pub_rows = 0;
     int ticket = 0;
     if (tid == 0) ticket = atomicAdd(&strip_ctr[xcd * CTR_STRIDE], 1);
-    // Out of phase from the start: the workgroups of a launch begin together, and with equal strips they stay in step for the first
-    // few -- everybody loads, then everybody computes and stores -- which a launch on its own pays in idle memory cycles (two
-    // overlapping launches fill each other's gaps).  The dispatcher deals workgroups b, b + 256, b + 512 to the same CU: the second
-    // and third wait `stagger` and 2 x `stagger` ticks of the 100 MHz clock before their first load.
-    if (stagger > 0) {
-        const long long wait = (long long)(blockIdx.x >> 8) * stagger, t0 = wall_clock64();
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
     for (;;) {
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
@@ -190,9 +180,9 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
     pub_f = -1;
     // Every launch finds the heads at 0: the workgroup that leaves last zeroes them (below), so there is no memset per step
     // and no host-side mirror of device state that a failed or foreign launch could put out of step.
-    // Tapered queue: the first taper_head and the last taper_tail strips of an XCD's range are handed out as four 8-row
-    // pieces each, so the kernel's ramp (nothing is stored before a first strip is complete) and its tail (workgroups
-    // finish up to one strip apart) are a quarter as long.
+    // Pieces: the first taper_head and the last taper_tail strips of an XCD's range are handed out as four 8-row pieces each.
+    // Used by launches with fewer strips than half the CUs (one camera frame: the per-frame drop-in chain), which hand out EVERY
+    // strip that way; as a ramp / tail shortener of full batches it measured nothing (round 3) and is not offered any more.
     const int n_mid = per_xcd - taper_head - taper_tail;
     const int n_queue = 4 * taper_head + n_mid + 4 * taper_tail;
     // The ticket for THIS strip was drawn while the previous strip was being processed (`ticket`, thread 0); the next one is
@@ -214,6 +204,7 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
     if (L >= n_blocks) continue; // tail of the last XCD's range: draw on, so that every head advances alike
     const int f = L / strips, strip = L - f * strips;
     const int y0 = strip * SR + piece * (SR / 4);
+    if (y0 >= h) continue; // a piece of the frame's last strip that lies below the image (h % SR <= 24): nothing to load, store or publish
     const int srh = sr + 2 * halo;
     const uint8_t* frame = frames + (int64_t)f * frame_pitch;
 
@@ -487,7 +478,7 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
         }
     }
     pub_f = f;
-    pub_rows = min(sr, h - y0);
+    pub_rows = min(sr, h - y0); // > 0: pieces below the image were skipped above
     } // strip loop
     // Leaving: this workgroup has drawn its last index.  strip_ctr[8] counts the leavers; the last one of the launch knows that
     // nobody will draw again and zeroes the eight heads and the count for the next launch (launches of one context are ordered:
@@ -526,12 +517,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     // persistent grid: `groups` workgroups per CU (RMCV_OPT_PIXEL_GROUPS; RMCV_K1_BPC overrides for A/B runs): alone the kernel is
     // equally fast with 2 and 3 and slower with 4 and more; 2 leaves room on every CU for the kernels of the other batches in flight
     static const int bpc_env = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 0;
-    static const bool nopub = getenv("RMCV_K1_NOPUB") && atoi(getenv("RMCV_K1_NOPUB")); // dev knob: no progress words (no hand-over possible)
     const int bpc = bpc_env > 0 ? bpc_env : groups;
-    // tapered queue (see the kernel): 16 strips at the head (one 8-row piece per workgroup of an XCD at 2 per CU) and 32 at the tail
-    const int stagger = (g.pixel_stagger & 0xFFFFF) | (g.pixel_halo_nt ? 1 << 20 : 0); // RMCV_OPT_PIXEL_STAGGER, RMCV_OPT_PIXEL_HALO_NT
-    const int taper_on = g.pixel_taper; // RMCV_OPT_PIXEL_TAPER (env RMCV_K1_TAPER sets its default), for A/B runs: since the loads
-    // became unconditional buffer operations the tapered hand-out no longer pays (0.2672 ms without against 0.2692 ms with, same box)
     for (int f0 = 0; f0 < g.n_frames; f0 += chunk) {
         const int nf = std::min(chunk, g.n_frames - f0);
         const int n_blocks = nf * strips;
@@ -540,7 +526,6 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
         grid = (grid + 7) & ~7;
         const int per_xcd = (n_blocks + 7) >> 3;
         int taper_head = 0, taper_tail = 0;
-        if (taper_on && per_xcd >= 192) { taper_head = 16; taper_tail = 32; }
         // A launch with fewer strips than half the CUs (one camera frame = 32 strips on 256 CUs: the per-frame drop-in chain) hands
         // EVERY strip out as four 8-row pieces: four times the workgroups, a quarter of the rows each (15 -> 7 us for one frame).
         if (n_blocks * 2 <= (g.n_cu > 0 ? g.n_cu : 256)) {
@@ -553,7 +538,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
         uint64_t* bits = b.bits + (int64_t)f0 * g.plane_pitch;
         uint32_t* rowmask = b.rowmask + (int64_t)f0 * g.h;
         // beyond 64 KiB of dynamic LDS (frames wider than ~6700 pixels) the kernel has to be told; per device and instantiation
-        const bool pub = publish && !nopub && b.frame_ready != nullptr;
+        const bool pub = publish && b.frame_ready != nullptr; // (the caller decides: rmcv_host.hip run_stages)
         static size_t lds_set[MAX_DEVICES][4] = {};
         const int inst = (fast ? 1 : 0) | (pub ? 2 : 0);
         if (planes > 60 * 1024 && planes > lds_set[g.device][inst]) {
@@ -566,7 +551,7 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
 #define RMCV_K1_LAUNCH(F, P)                                                                                                          \
     launch(k_binary<CA, CB, F, P>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
            morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail,               \
-           pub ? b.frame_ready + f0 : nullptr, seq, pub ? b.started : nullptr, stagger)
+           pub ? b.frame_ready + f0 : nullptr, seq, pub ? b.started : nullptr, g.pixel_halo_nt)
         const hipError_t e = fast ? (pub ? RMCV_K1_LAUNCH(true, true) : RMCV_K1_LAUNCH(true, false))
                                   : (pub ? RMCV_K1_LAUNCH(false, true) : RMCV_K1_LAUNCH(false, false));
 #undef RMCV_K1_LAUNCH

@@ -54,7 +54,7 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
         if (e != hipSuccess) return e;
         attr_set[g.device] = true;
     }
-    const int force = (force_literal ? force_literal : g.contour_tier) | ((g.sparse_prio & 3) << 4);
+    const int force = force_literal ? force_literal : g.contour_tier;
     if (waves == 4) {
         // RMCV_OPT_DENSE_DEFER (off by default): the 4-wavefront launch leaves the frames beyond its LDS tables alone and the
         // 8-wavefront kernel takes them in a launch of its own right behind (1.4-1.5x faster per frame; a workgroup of any other
@@ -66,7 +66,7 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
         Q2.frame_ready = nullptr; // the first launch has consumed the planes already
         return launch(k_contours_w8, dim3(grid), dim3(512), lds_bytes(g.h), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
                        g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
-                       lim.max_contours, lim.max_points, 2 | 8 | (force & 0x30), b.elig, b.n_elig, b.slot_kind, X, b.visit_xy, b.mid, b.mid_stride,
+                       lim.max_contours, lim.max_points, 2 | 8, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy, b.mid, b.mid_stride,
                        b.mid_slot_cap, Q2, lds_rows_cap(g.h));
     }
     return launch(k_contours_w8, dim3(grid), dim3(512), lds_bytes(g.h), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,

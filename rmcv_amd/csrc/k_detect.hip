@@ -184,18 +184,21 @@ __global__ __launch_bounds__(64) void k_pairs(const int32_t* __restrict__ slot_k
 static constexpr int COMPACT_FRAMES = 16;
 __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __restrict__ armours,
                                                         const int32_t* __restrict__ n_armours, int n_frames, int max_armours,
-                                                        rmcv_armour* __restrict__ out, int cap, int32_t* __restrict__ frame_offs)
+                                                        rmcv_armour* __restrict__ out, int cap, int32_t* __restrict__ frame_offs,
+                                                        const int32_t* __restrict__ status, int32_t* __restrict__ status_or)
 {
     __shared__ int s_part[256];
-    __shared__ int s_base;
+    __shared__ int s_base, s_st;
     __shared__ int s_off[COMPACT_FRAMES], s_cnt[COMPACT_FRAMES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f_begin = blockIdx.x * COMPACT_FRAMES; // this workgroup's frames
-    if (tid == 0) s_base = 0;
+    if (tid == 0) { s_base = 0; s_st = 0; }
     __syncthreads();
     for (int f0 = 0; f0 < n_frames; f0 += 256) {
         const int f = f0 + tid;
         const int c = f < n_frames ? n_armours[f] : 0;
+        // the batch's status bits OR-ed into one word (rmcv_pipeline_collect reads it with the list instead of n_frames words)
+        if (status_or && blockIdx.x == 0 && f < n_frames) { const int st = status[f]; if (st) atomicOr(&s_st, st); }
         s_part[tid] = c;
         __syncthreads();
         for (int d = 1; d < 256; d <<= 1) { // inclusive Hillis-Steele scan
@@ -214,7 +217,10 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
         if (tid == 255) s_base += s_part[255];
         __syncthreads();
     }
-    if (tid == 0 && blockIdx.x == 0) frame_offs[n_frames] = s_base;
+    if (tid == 0 && blockIdx.x == 0) {
+        frame_offs[n_frames] = s_base;
+        if (status_or) *status_or = s_st;
+    }
     constexpr int DW = (int)(sizeof(rmcv_armour) / 4);
     for (int fi = wave; fi < COMPACT_FRAMES && f_begin + fi < n_frames; fi += 4) {
         const int excl = s_off[fi], c = s_cnt[fi];
@@ -237,10 +243,10 @@ hipError_t launch_status_clear(const Geom& g, const Bufs& b, int mask, hipStream
 }
 
 hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
-                                  int32_t* d_frame_offs, hipStream_t s)
+                                  int32_t* d_frame_offs, hipStream_t s, int32_t* d_status_or)
 {
     return launch(k_compact_armours, dim3(std::max(1, (g.n_frames + COMPACT_FRAMES - 1) / COMPACT_FRAMES)), dim3(256), 0, s, b.armours, b.n_armours, g.n_frames, lim.max_armours, d_out,
-                       cap, d_frame_offs);
+                       cap, d_frame_offs, b.status, d_status_or);
 }
 
 static hipError_t launch_pairs_tail(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s)

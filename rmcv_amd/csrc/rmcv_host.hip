@@ -33,6 +33,8 @@ struct rmcv_ctx {
     int order_n = -1, order_h = -1; // (n_frames, h) the frame order on the device was computed for
     hipEvent_t ev_order = nullptr; // recorded behind the work enqueued last: a call on ANOTHER stream first waits for it
     bool order_pending = false;
+    bool external_order = false;  // a pipeline owns the ordering of this context's launches (rmcv_internal.h: ctx_external_order)
+    hipEvent_t ext_done = nullptr; // ... and records this event behind the last of them
     // ---- per-frame drop-in path (rmcv_extract_color -> rmcv_filter_lightblobs -> rmcv_filter_armours, executable/main.cpp:172-176)
     int frame_upload = 0;          // RMCV_OPT_FRAME_UPLOAD
     int run_ahead = 1;             // RMCV_OPT_RUN_AHEAD
@@ -73,7 +75,11 @@ struct rmcv_ctx {
     bool pre_binary_valid = false; // ev_pre_binary marks the point in front of the last pixel kernel
     bool binary_enqueued = false;  // a pixel kernel has been enqueued on this geometry
     uint32_t binary_seq = 0;      // k_binary launches since the geometry was bound (frame_ready words: launch L is through with a frame at L * h)
-    uint32_t launch_id = 0;       // k_binary launches of this context, never reset: the label the `started` word carries
+    uint32_t pub_id = 0;          // PUBLISHING k_binary launches of this context: the label the `started` word carries.  Only
+                                  // launches that write the word advance it, and the stream waits with >= -- a launch that does
+                                  // not publish (rmcv_extract_color, RMCV_K1_NOPUB) can neither be waited for nor overwrite a label
+    int mid_frames = 0;           // frame slots Bufs::mid holds (ensure_mid)
+    bool mid_failed = false;      // ... could not be allocated: the mid tier is absent for this context
     int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
     int pixel_groups = 3;         // RMCV_OPT_PIXEL_GROUPS
     char err[256] = {0};
@@ -226,10 +232,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         c->geom.device = device;
-        c->geom.sparse_prio = 3;
         c->geom.pixel_halo_nt = getenv("RMCV_K1_HALO_NT") ? atoi(getenv("RMCV_K1_HALO_NT")) : 0;
-        c->geom.pixel_taper = getenv("RMCV_K1_TAPER") ? atoi(getenv("RMCV_K1_TAPER")) : 0;
-        c->geom.pixel_stagger = getenv("RMCV_K1_STAGGER") ? atoi(getenv("RMCV_K1_STAGGER")) : 0; // RMCV_OPT_PIXEL_STAGGER (env: dev A/B knob)
         c->geom.dense_defer = getenv("RMCV_DENSE_DEFER") ? atoi(getenv("RMCV_DENSE_DEFER")) : 0; // RMCV_OPT_DENSE_DEFER (env: dev A/B knob)
         c->geom.n_cu = (device < MAX_DEVICES && hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
         if (device >= MAX_DEVICES) e = hipErrorInvalidDevice;
@@ -251,11 +254,11 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.n_contours, F);
     if (e == hipSuccess) e = dalloc(c, &b.n_points, F);
     if (e == hipSuccess) e = dalloc(c, &b.visit_xy, F * VISIT_CAP);
-    if (e == hipSuccess) { // the mid tier's tables: one block per frame slot, its per-word tables sized for every word of the largest frame
+    { // the mid tier's tables (one 4.5-5.7 MB block per frame slot) are allocated when a geometry is bound, for the frames bound: ensure_mid
         const int64_t words = (int64_t)((d.max_width + 63) / 64) * d.max_height;
         b.mid_slot_cap = (int)std::min<int64_t>(words, 65535);
         b.mid_stride = (int64_t)((mid_bytes(b.mid_slot_cap) + 255) & ~(size_t)255);
-        e = dalloc(c, &b.mid, F * (size_t)b.mid_stride);
+        b.mid = nullptr;
     }
     if (e == hipSuccess) e = dalloc(c, &b.blobs, F * d.max_blobs);
     if (e == hipSuccess) e = dalloc(c, &b.blob_src, F * d.max_blobs);
@@ -302,6 +305,20 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
 
 } // extern "C"
 
+namespace rmcv {
+void ctx_external_order(rmcv_ctx* c, hipEvent_t done)
+{
+    c->external_order = true;
+    c->ext_done = done;
+}
+const Limits& ctx_limits(const rmcv_ctx* c) { return c->lim; }
+int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s)
+{
+    HIPCHK(c, launch_compact_armours(c->geom, c->bufs, c->lim, (rmcv_armour*)d_armours_out, cap, (int32_t*)d_frame_offs, s, (int32_t*)d_status_or), "k_compact_armours");
+    return RMCV_OK;
+}
+} // namespace rmcv
+
 // frame slot 0 of the device buffers no longer holds what the per-frame chain returned last (see rmcv_ctx::res_nc)
 static void resident_none(rmcv_ctx* c)
 {
@@ -347,12 +364,47 @@ static int ensure_staging(rmcv_ctx* c)
     return RMCV_OK;
 }
 
+// The mid tier's scratch (Bufs::mid) for the first `n_frames` frame slots, grow-only.  A context that only ever binds one frame (the
+// per-frame drop-in chain) holds 5.7 MB of it, a 256-frame batch context 1.2-1.5 GB -- allocated for every slot at creation it more
+// than doubled a default context's footprint for users who never see a dense frame.  If the memory is not to be had the tier is
+// simply absent (mid == nullptr): the kernels hand such frames to the sequential scanner instead of failing the call.
+static int ensure_mid(rmcv_ctx* c, int n_frames)
+{
+    if (n_frames <= c->mid_frames || c->mid_failed) return RMCV_OK;
+    static const bool no_mid = getenv("RMCV_NO_MID") && atoi(getenv("RMCV_NO_MID")); // test knob: behave as if the allocation had failed
+    if (c->bufs.mid) { // grow: nothing of this context may still be running on the old block
+        const int rcs = rmcv_batch_sync(c);
+        if (rcs) return rcs;
+        uint8_t* raw = c->bufs.mid - GUARD;
+        for (size_t i = 0; i < c->allocs.size(); i++)
+            if (c->allocs[i] == raw) { c->allocs.erase(c->allocs.begin() + i); break; }
+        for (size_t i = 0; i < c->guarded.size(); i++)
+            if (c->guarded[i].base == raw) { c->guarded.erase(c->guarded.begin() + i); break; }
+        (void)hipFree(raw);
+        c->bufs.mid = nullptr;
+        c->mid_frames = 0;
+    }
+    // (a batch context binds its full batch sooner or later: go there at once rather than in steps)
+    const int want = n_frames > 1 ? c->lim.max_frames : 1;
+    uint8_t* m = nullptr;
+    const hipError_t e = no_mid ? hipErrorOutOfMemory : dalloc_named(c, &m, (size_t)want * (size_t)c->bufs.mid_stride, "b.mid");
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c->mid_failed = true; // degrade, once: frames beyond the LDS tables take the sequential scanner (RMCV_FRAME_SLOW_PATH)
+        return RMCV_OK;
+    }
+    c->bufs.mid = m;
+    c->mid_frames = want;
+    return RMCV_OK;
+}
+
 // bind a geometry; zero the padded planes when it changes (their pads must read 0)
 static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t frame_pitch)
 {
     if (n_frames < 1 || n_frames > c->lim.max_frames) return fail(c, RMCV_ERR_BAD_ARG, "n_frames out of range");
     if (w < 1 || h < 1 || w > c->lim.max_width || h > c->lim.max_height) return fail(c, RMCV_ERR_BAD_ARG, "frame size out of range");
     if (stride < 3 * w || frame_pitch < (int64_t)stride * (h - 1) + 3 * w) return fail(c, RMCV_ERR_BAD_ARG, "bad stride/pitch");
+    { const int rcm = ensure_mid(c, n_frames); if (rcm) return rcm; }
     Geom& g = c->geom;
     g.n_frames = n_frames;
     g.w = w;
@@ -423,12 +475,14 @@ static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t
 // so two streams on one context interleave correctly instead of racing (a context still has ONE owner thread).
 static int order_begin(rmcv_ctx* c, hipStream_t s)
 {
+    if (c->external_order) return RMCV_OK;
     if (c->order_pending && c->last_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->ev_order, 0), "order: wait for the previous stream");
     return RMCV_OK;
 }
 static int order_end(rmcv_ctx* c, hipStream_t s)
 {
     c->last_stream = s;
+    if (c->external_order) return RMCV_OK;
     HIPCHK(c, hipEventRecord(c->ev_order, s), "order: record");
     c->order_pending = true;
     return RMCV_OK;
@@ -449,9 +503,19 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     const bool waits_per_frame = (stages & RMCV_STAGE_HANDOVER) != 0; // the caller enqueued this batch's pixel kernel elsewhere
     stages &= ~RMCV_STAGE_HANDOVER;
     int rc;
+    // every argument check comes BEFORE the first enqueue: an error return leaves the streams as they were
     if (waits_per_frame) {
         if (!c->binary_enqueued) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER without a preceding RMCV_STAGE_BINARY run");
         if (stages & RMCV_STAGE_BINARY) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER goes with a run WITHOUT RMCV_STAGE_BINARY");
+    }
+    if ((stages & RMCV_STAGE_IDENTITY) && !b.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
+    if ((stages & RMCV_STAGE_POSE) && !b.pnp_cfg) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_POSE needs rmcv_pnp_load first");
+    if (c->pub_id >= 0x7FFFFF00u) { // the label is 32 bits wide: start over long before it wraps (months of launches away)
+        if ((rc = rmcv_batch_sync(c))) return rc;
+        if (b.started) HIPCHK(c, hipMemset(b.started, 0, 8), "hand-over: label reset");
+        c->pub_id = 0;
+        c->pre_binary_valid = false;
+        c->binary_enqueued = false;
     }
     if (waits_per_frame && c->handover && c->pre_binary_valid) {
         // everything this context did BEFORE that pixel kernel must be through; the pixel kernel itself need not be
@@ -473,20 +537,23 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     // back -- each frame's contours, fits and pairing start when the frame's last strip is written instead of the batch's.
     // (not when the pixel kernel takes several launches -- batches beyond the 32-bit buffer extents --: the word the sparse stream
     // waits on says that the FIRST of them runs)
-    const bool can_hand_over = c->handover && binary_launches(g, b) == 1;
+    static const bool nopub = getenv("RMCV_K1_NOPUB") && atoi(getenv("RMCV_K1_NOPUB")); // dev knob: no progress words, hence no hand-over
+    const bool can_hand_over = c->handover && !nopub && b.frame_ready && b.started && binary_launches(g, b) == 1;
     const bool forked = one_sparse && can_hand_over && (stages & RMCV_STAGE_BINARY) && g.n_frames >= 4;
     if (stages & RMCV_STAGE_BINARY) {
         c->binary_enqueued = true;
         c->pre_binary_valid = false;
-        if (c->handover) { // (only then: a marker in front of every pixel kernel costs the next launch a few microseconds)
+        if (can_hand_over) { // (only then: a marker in front of every pixel kernel costs the next launch a few microseconds)
             HIPCHK(c, hipEventRecord(c->ev_pre_binary, s), "hand-over: mark");
             c->pre_binary_valid = true;
         }
         if (forked) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pre_binary, 0), "hand-over: fork");
-        const bool publish = c->handover != 0;
-        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->launch_id + 1, publish, s), "k_binary");
-        c->launch_id++;  // (counted once the launch is accepted: the device's words and these counters move together)
-        if (publish) c->binary_seq++;
+        const bool publish = can_hand_over;
+        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->pub_id + 1, publish, s), "k_binary");
+        if (publish) { // (counted once the launch is accepted: the device's words and these counters move together)
+            c->pub_id++;
+            c->binary_seq++;
+        } else c->pre_binary_valid = false; // nothing to hand over frame by frame: a RMCV_STAGE_HANDOVER run waits for the launch as a whole
         HT();
     }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
@@ -496,8 +563,7 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     hipStream_t ss = forked ? c->side : s;
     // the spinning consumer goes on the machine only once its producer is there (k_binary.hip: `started`)
     static const bool no_waitvalue = getenv("RMCV_NO_WAITVALUE") && atoi(getenv("RMCV_NO_WAITVALUE")); // dev knob (timing experiments only)
-    if (per_frame && !no_waitvalue) HIPCHK(c, hipStreamWaitValue32(ss, b.started, c->launch_id, hipStreamWaitValueEq, 0xFFFFFFFFu), "hand-over: wait for the pixel kernel to start");
-    if ((stages & RMCV_STAGE_IDENTITY) && !b.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
+    if (per_frame && !no_waitvalue) HIPCHK(c, hipStreamWaitValue32(ss, b.started, c->pub_id, hipStreamWaitValueGte, 0xFFFFFFFFu), "hand-over: wait for the pixel kernel to start");
     // the icon classifier rides in the per-frame kernel when the armours come from it (BASELINE config 5: no launch of its own)
     const bool identity_fused = one_sparse && (stages & RMCV_STAGE_ARMOURS) && (stages & RMCV_STAGE_IDENTITY);
     if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, identity_fused, c->sparse_waves, wait_seq, ss), "k_contours (fused)");
@@ -519,10 +585,7 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     if (!one_sparse && !fused && (stages & RMCV_STAGE_ARMOURS)) HIPCHK(c, launch_armours(g, b, c->lim, *p, s), "k_armours");
     if ((stages & RMCV_STAGE_IDENTITY) && !identity_fused) HIPCHK(c, launch_classify(g, b, c->lim, s), "k_classify");
-    if (stages & RMCV_STAGE_POSE) {
-        if (!b.pnp_cfg) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_POSE needs rmcv_pnp_load first");
-        HIPCHK(c, launch_pnp(g, b, c->lim, s), "k_pnp");
-    }
+    if (stages & RMCV_STAGE_POSE) HIPCHK(c, launch_pnp(g, b, c->lim, s), "k_pnp");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     return order_end(c, s);
 }
@@ -622,18 +685,6 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         c->geom.pixel_halo_nt = value;
         return RMCV_OK;
     }
-    if (option == RMCV_OPT_PIXEL_TAPER && (value == 0 || value == 1)) {
-        c->geom.pixel_taper = value;
-        return RMCV_OK;
-    }
-    if (option == RMCV_OPT_SPARSE_PRIO && value >= 0 && value <= 3) {
-        c->geom.sparse_prio = value;
-        return RMCV_OK;
-    }
-    if (option == RMCV_OPT_PIXEL_STAGGER && value >= 0 && value <= 100000) { // (20 bits of the kernel's knob word)
-        c->geom.pixel_stagger = value;
-        return RMCV_OK;
-    }
     if (option == RMCV_OPT_DENSE_DEFER && (value == 0 || value == 1)) {
         c->geom.dense_defer = value;
         return RMCV_OK;
@@ -696,6 +747,7 @@ int rmcv_batch_sync(rmcv_ctx* c)
     if (!c) return RMCV_ERR_BAD_ARG;
     hipSetDevice(c->device);
     // the event sits behind everything this context enqueued, on whichever stream (a stream handle of the caller may be gone by now)
+    if (c->external_order && c->ext_done) HIPCHK(c, hipEventSynchronize(c->ext_done), "sync (pipeline slot)");
     if (c->order_pending) HIPCHK(c, hipEventSynchronize(c->ev_order), "sync");
     HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
     return RMCV_OK;
@@ -1114,8 +1166,9 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     const Geom& g = c->geom;
     const Bufs& b = c->bufs;
     hipStream_t s = c->stream;
-    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, c->launch_id + 1, false, s), "k_binary");
-    c->launch_id++;
+    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, 0, false, s), "k_binary");
+    c->pre_binary_valid = false; // this launch published nothing: a later RMCV_STAGE_HANDOVER run has no pixel kernel to follow frame by frame
+    c->binary_enqueued = false;
     if (binary_out) HIPCHK(c, hipEventRecord(c->ev_fork, s), "image download: mark");
     // running ahead with both parameter sets known: the frame's whole sparse part is ONE kernel (the fused per-frame kernel of
     // the batch path: findContours, fits and pairing back to back), not three

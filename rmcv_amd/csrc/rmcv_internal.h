@@ -18,10 +18,7 @@ namespace rmcv {
 struct Geom {
     int device;          // HIP device of the owning context: per-device launch state (function attributes) is indexed by it
     int n_cu;            // compute units of that device (sizes the persistent grid of k_binary)
-    int sparse_prio;     // RMCV_OPT_SPARSE_PRIO: s_setprio of the per-frame kernel's waves (0..3)
     int pixel_halo_nt;   // RMCV_OPT_PIXEL_HALO_NT: the row quads a strip shares with its neighbours are loaded non-temporal too
-    int pixel_taper;     // RMCV_OPT_PIXEL_TAPER: the first 16 and last 32 strips of every XCD queue handed out as 8-row pieces
-    int pixel_stagger;   // RMCV_OPT_PIXEL_STAGGER: k_binary's workgroups of one CU start this many 10-ns ticks apart (0: together)
     int dense_defer;     // RMCV_OPT_DENSE_DEFER: frames beyond the LDS tables are left to a second launch with 8 wavefronts per frame
     int contour_tier;    // RMCV_OPT_CONTOUR_TIER: 0 = per frame (LDS tables, else mid tier, else literal scanner), 1 = literal, 2 = mid tier
     int n_frames;
@@ -150,8 +147,9 @@ int binary_launches(const Geom& g, const Bufs& b); // launches launch_binary mak
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
+// d_status_or (nullable): one word = the OR of the batch's per-frame status words
 hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
-                                  int32_t* d_frame_offs, hipStream_t s);
+                                  int32_t* d_frame_offs, hipStream_t s, int32_t* d_status_or = nullptr);
 hipError_t launch_status_clear(const Geom& g, const Bufs& b, int mask, hipStream_t s); // status[f] &= ~mask
 hipError_t launch_classify(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 // stage-wise helpers: binary (host-supplied 0/255 image) -> bit plane
@@ -177,5 +175,14 @@ hipError_t launch_export(const ExportArgs& a, hipStream_t s);
 hipError_t launch_pack_contours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_point* d_pts_out, int32_t* d_offs_out,
                                 int32_t* d_hdr /* nullable: frame 0's {n_contours, n_points, status} */, hipStream_t s, const ExportArgs* ex = nullptr); // ex: frame 0's workgroup also exports (one-frame chains)
 hipError_t launch_gather3(const int32_t* a, const int32_t* b, const int32_t* c, int32_t* d_out, hipStream_t s); // d_out[0..2] = *a, *b, *c
+
+// ---- what rmcv_pipeline.hip needs of a context beyond the public ABI (rmcv_host.hip) ----
+// external order: the pipeline chains a context's launches with its own events (it knows which stream ran what), so the context
+// does not record / wait for its own ordering event around every launch (two HIP calls per launch); rmcv_batch_sync and the getters
+// then wait for `done` (recorded by the pipeline behind the slot's last launch) instead
+void ctx_external_order(rmcv_ctx* c, hipEvent_t done);
+// rmcv_batch_compact_armours + the batch's OR-ed status word
+int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s);
+const Limits& ctx_limits(const rmcv_ctx* c);
 
 } // namespace rmcv

@@ -1,0 +1,464 @@
+// rmcv_pipeline.hip -- rmcv_pipeline_*: the pipelined batch schedule behind the C-ABI (include/rmcv_abi.h).
+//
+// The reference's process_function (/root/reference/executable/main.cpp:163-209) is a loop: newest frame in, three detection calls,
+// armours out.  On one MI355X the loop's batch form keeps `depth` batches in flight: the HBM-bound pixel kernel of batch i + 1 streams
+// while the latency-bound per-frame kernel of batch i (contours, fits, pairing: a few waves per CU) runs beside it.  Rounds 1-3 had
+// this schedule in bench.py (Python + torch streams and events); it lives here now, in the host language of the reference, and
+// bench.py, tools/pipeline_bench.c and a C++ host all drive the same three calls.
+//
+// One slot of the ring = one context (own work buffers) + one record in HBM (frame_offs | status | armours: the payload of the
+// multi-GPU gather) + its pinned host mirror.  Ticket t uses slot t % depth, pixel stream t % pixel_streams and sparse stream
+// (t % depth) % sparse_streams -- a slot always meets the same sparse stream, so a record's rewrite is ordered behind its last
+// reader on that stream by stream order alone.  Events per slot:
+//     ev_done   behind the compaction: the slot's context buffers are free            -> waited for by the slot's next pixel kernel
+//     ev_bin    behind the pixel kernel                                               -> waited for by the slot's sparse kernel
+//     ev_host   behind the record's copy to pinned memory                             -> waited for by collect / wait (host)
+//     ev_hook   (the hook's own, optional) the record has been read on another stream -> waited for by the slot's next compaction
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "rmcv_internal.h"
+
+using namespace rmcv;
+
+// HIP reads GPU_MAX_HW_QUEUES once, when the runtime starts.  Loaded before the first HIP call of the process (a C or C++ host that
+// links the library; bench.py sets the variable itself before torch starts HIP) this default takes effect; an existing value wins.
+__attribute__((constructor(101))) static void rmcv_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+
+struct rmcv_pipeline {
+    int device = 0;
+    rmcv_pipeline_config cfg{};
+    Limits lim{};
+    int64_t head_bytes = 0, record_bytes = 0;
+    std::vector<rmcv_ctx*> ring;
+    std::vector<hipStream_t> pix, sp;
+    std::vector<hipEvent_t> ev_bin, ev_done, ev_host;
+    std::vector<void*> ev_hook;       // per slot: the event the hook handed back for the slot's last record (not owned), or null
+    std::vector<uint8_t*> d_rec, h_rec;
+    std::vector<uint64_t> slot_ticket; // ticket + 1 of the batch that lives in the slot (0: none yet)
+    std::vector<int> slot_frames;
+    uint64_t next_ticket = 0, collected = 0;
+    rmcv_pipeline_hook hook = nullptr;
+    void* hook_user = nullptr;
+    // built-in gather hook
+    rmcv_comm* comm = nullptr;
+    int root = 0, n_ranks = 0, rank = 0;
+    std::vector<uint8_t*> d_recv;      // root: per slot, n_ranks x record_bytes
+    hipEvent_t ev_gather = nullptr;    // behind the last gather: one communicator's operations run in ONE order on every rank
+    bool gather_pending = false;
+    char err[256] = {0};
+};
+
+static int pfail(rmcv_pipeline* pl, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (pl) {
+        if (e != hipSuccess) snprintf(pl->err, sizeof(pl->err), "%s: %s", what, hipGetErrorString(e));
+        else snprintf(pl->err, sizeof(pl->err), "%s", what);
+    }
+    if (e != hipSuccess) (void)hipGetLastError();
+    return code;
+}
+#define PCHK(pl, call, what)                                               \
+    do {                                                                   \
+        hipError_t e__ = (call);                                           \
+        if (e__ != hipSuccess) return pfail((pl), RMCV_ERR_HIP, what, e__); \
+    } while (0)
+// a context call failed: its message is the pipeline's
+static int cfail(rmcv_pipeline* pl, rmcv_ctx* c, int rc)
+{
+    snprintf(pl->err, sizeof(pl->err), "%s", rmcv_last_error(c));
+    return rc;
+}
+
+extern "C" {
+
+void rmcv_default_pipeline_config(rmcv_pipeline_config* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->depth = 8;          // measured by alternating regions of one process (round 3): 8 batches over 4 sparse streams run 4.3-4.5 % ahead of 4 over 2
+    c->pixel_streams = 2;
+    c->sparse_streams = 4;
+    c->armour_cap = 0;     // resolved against the limits at creation: 8 per frame
+    c->sparse_waves = 4;
+    c->pixel_groups = 2;
+    c->host_results = 1;
+    c->handover = 2;
+}
+
+void rmcv_pipeline_destroy(rmcv_pipeline* pl)
+{
+    if (!pl) return;
+    hipSetDevice(pl->device);
+    for (auto s : pl->pix) if (s) hipStreamSynchronize(s);
+    for (auto s : pl->sp) if (s) hipStreamSynchronize(s);
+    for (auto c : pl->ring) rmcv_ctx_destroy(c);
+    for (auto e : pl->ev_bin) if (e) hipEventDestroy(e);
+    for (auto e : pl->ev_done) if (e) hipEventDestroy(e);
+    for (auto e : pl->ev_host) if (e) hipEventDestroy(e);
+    if (pl->ev_gather) hipEventDestroy(pl->ev_gather);
+    for (auto p : pl->d_rec) if (p) hipFree(p);
+    for (auto p : pl->d_recv) if (p) hipFree(p);
+    for (auto p : pl->h_rec) if (p) hipHostFree(p);
+    for (auto s : pl->pix) if (s) hipStreamDestroy(s);
+    for (auto s : pl->sp) if (s) hipStreamDestroy(s);
+    delete pl;
+}
+
+int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipeline_config* cfg, rmcv_pipeline** out)
+{
+    if (!out) return RMCV_ERR_BAD_ARG;
+    *out = nullptr;
+    rmcv_pipeline_config d;
+    rmcv_default_pipeline_config(&d);
+    if (cfg) {
+        if (cfg->depth > 0) d.depth = cfg->depth;
+        if (cfg->pixel_streams > 0) d.pixel_streams = cfg->pixel_streams;
+        if (cfg->sparse_streams > 0) d.sparse_streams = cfg->sparse_streams;
+        if (cfg->armour_cap > 0) d.armour_cap = cfg->armour_cap;
+        // alone a batch has the CUs to itself: the latency settings (8 wavefronts per frame, 3 pixel workgroups per CU)
+        d.sparse_waves = cfg->sparse_waves > 0 ? cfg->sparse_waves : (d.depth >= 3 ? 4 : 8);
+        d.pixel_groups = cfg->pixel_groups > 0 ? cfg->pixel_groups : (d.depth >= 2 ? 2 : 3);
+        if (cfg->host_results > 0) d.host_results = cfg->host_results;
+        if (cfg->handover > 0) d.handover = cfg->handover;
+    }
+    if (d.depth > 64 || d.pixel_streams > 16 || d.sparse_streams > 16 || d.host_results > 2 || d.handover > 2) return RMCV_ERR_BAD_ARG;
+    if (d.pixel_streams > d.depth) d.pixel_streams = d.depth;
+    if (d.sparse_streams > d.depth) d.sparse_streams = d.depth;
+    rmcv_pipeline* pl = new (std::nothrow) rmcv_pipeline();
+    if (!pl) return RMCV_ERR_NOMEM;
+    pl->device = device;
+    pl->cfg = d;
+    int rc = RMCV_OK;
+    for (int k = 0; k < d.depth && rc == RMCV_OK; k++) {
+        rmcv_ctx* c = nullptr;
+        rc = rmcv_ctx_create(device, limits, &c);
+        if (rc == RMCV_OK) {
+            pl->ring.push_back(c);
+            rc = rmcv_ctx_set_option(c, RMCV_OPT_SPARSE_WAVES, d.sparse_waves);
+            if (rc == RMCV_OK) rc = rmcv_ctx_set_option(c, RMCV_OPT_PIXEL_GROUPS, d.pixel_groups);
+            if (rc == RMCV_OK && d.handover == 1) rc = rmcv_ctx_set_option(c, RMCV_OPT_HANDOVER, 1);
+        }
+    }
+    if (rc != RMCV_OK) {
+        rmcv_pipeline_destroy(pl);
+        return rc;
+    }
+    pl->lim = ctx_limits(pl->ring[0]);
+    if (pl->cfg.armour_cap <= 0) pl->cfg.armour_cap = 8 * pl->lim.max_frames;
+    pl->head_bytes = (((int64_t)pl->lim.max_frames + 2) * 4 + 15) / 16 * 16;
+    pl->record_bytes = pl->head_bytes + (int64_t)pl->cfg.armour_cap * (int64_t)sizeof(rmcv_armour);
+    hipError_t e = hipSetDevice(device);
+    int lo = 0, hi = 0;
+    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = the numerically lowest = the highest priority
+    // pixel streams at normal priority, sparse streams above them: the per-frame kernels are latency chains whose workgroups must be
+    // placed as soon as their batch's planes are there, ahead of the next batches' streaming workgroups
+    for (int i = 0; i < d.pixel_streams && e == hipSuccess; i++) {
+        hipStream_t s = nullptr;
+        e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, 0);
+        pl->pix.push_back(s);
+    }
+    for (int i = 0; i < d.sparse_streams && e == hipSuccess; i++) {
+        hipStream_t s = nullptr;
+        e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi);
+        pl->sp.push_back(s);
+    }
+    for (int k = 0; k < d.depth && e == hipSuccess; k++) {
+        hipEvent_t a = nullptr, b = nullptr, h = nullptr;
+        uint8_t *dr = nullptr, *hr = nullptr;
+        e = hipEventCreateWithFlags(&a, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc((void**)&dr, (size_t)pl->record_bytes);
+        if (e == hipSuccess) e = hipMemset(dr, 0, (size_t)pl->record_bytes);
+        if (e == hipSuccess && d.host_results == 1) e = hipHostMalloc((void**)&hr, (size_t)pl->record_bytes, hipHostMallocDefault);
+        pl->ev_bin.push_back(a);
+        pl->ev_done.push_back(b);
+        pl->ev_host.push_back(h);
+        pl->d_rec.push_back(dr);
+        pl->h_rec.push_back(hr);
+        pl->ev_hook.push_back(nullptr);
+        pl->slot_ticket.push_back(0);
+        pl->slot_frames.push_back(0);
+        if (e == hipSuccess) ctx_external_order(pl->ring[(size_t)k], b);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_gather, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        fprintf(stderr, "rmcv_pipeline_create: %s\n", hipGetErrorString(e));
+        (void)hipGetLastError();
+        rmcv_pipeline_destroy(pl);
+        return e == hipErrorOutOfMemory ? RMCV_ERR_NOMEM : RMCV_ERR_HIP;
+    }
+    *out = pl;
+    return RMCV_OK;
+}
+
+const char* rmcv_pipeline_last_error(const rmcv_pipeline* pl) { return pl ? pl->err : "null pipeline"; }
+
+int rmcv_pipeline_get_info(const rmcv_pipeline* pl, rmcv_pipeline_info* o)
+{
+    if (!pl || !o) return RMCV_ERR_BAD_ARG;
+    memset(o, 0, sizeof(*o));
+    o->depth = pl->cfg.depth;
+    o->pixel_streams = pl->cfg.pixel_streams;
+    o->sparse_streams = pl->cfg.sparse_streams;
+    o->armour_cap = pl->cfg.armour_cap;
+    o->sparse_waves = pl->cfg.sparse_waves;
+    o->pixel_groups = pl->cfg.pixel_groups;
+    o->host_results = pl->cfg.host_results;
+    o->handover = pl->cfg.handover;
+    o->max_frames = pl->lim.max_frames;
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    o->hw_queues_env = q ? atoi(q) : 0;
+    o->hw_queues_wanted = 1 + pl->cfg.pixel_streams + pl->cfg.sparse_streams + (pl->comm ? 1 : 0);
+    o->record_bytes = pl->record_bytes;
+    o->armours_offset = pl->head_bytes;
+    o->submitted = pl->next_ticket;
+    o->collected = pl->collected;
+    return RMCV_OK;
+}
+
+rmcv_ctx* rmcv_pipeline_context(rmcv_pipeline* pl, int slot)
+{
+    if (!pl || slot < 0 || slot >= pl->cfg.depth) return nullptr;
+    return pl->ring[(size_t)slot];
+}
+
+int rmcv_pipeline_set_hook(rmcv_pipeline* pl, rmcv_pipeline_hook fn, void* user)
+{
+    if (!pl) return RMCV_ERR_BAD_ARG;
+    if (pl->comm && fn) return pfail(pl, RMCV_ERR_BAD_ARG, "the pipeline already gathers with rmcv_gather (rmcv_pipeline_set_gather): one hook at a time");
+    pl->hook = fn;
+    pl->hook_user = user;
+    return RMCV_OK;
+}
+
+int rmcv_pipeline_set_gather(rmcv_pipeline* pl, rmcv_comm* comm, int root)
+{
+    if (!pl) return RMCV_ERR_BAD_ARG;
+    if (pl->hook && comm) return pfail(pl, RMCV_ERR_BAD_ARG, "the pipeline already has a hook (rmcv_pipeline_set_hook): one at a time");
+    int rc = rmcv_pipeline_drain(pl);
+    if (rc) return rc;
+    hipSetDevice(pl->device);
+    for (auto& p : pl->d_recv) if (p) { hipFree(p); p = nullptr; }
+    pl->d_recv.clear();
+    pl->comm = nullptr;
+    pl->gather_pending = false;
+    if (!comm) return RMCV_OK;
+    int32_t n = 0, r = 0;
+    rc = rmcv_comm_info(comm, &n, &r);
+    if (rc) return pfail(pl, rc, "rmcv_comm_info");
+    if (root < 0 || root >= n) return pfail(pl, RMCV_ERR_BAD_ARG, "root out of range");
+    if (r == root)
+        for (int k = 0; k < pl->cfg.depth; k++) {
+            uint8_t* p = nullptr;
+            PCHK(pl, hipMalloc((void**)&p, (size_t)pl->record_bytes * (size_t)n), "hipMalloc (gather receive buffer)");
+            pl->d_recv.push_back(p);
+        }
+    pl->comm = comm;
+    pl->root = root;
+    pl->n_ranks = n;
+    pl->rank = r;
+    return RMCV_OK;
+}
+
+static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch, const rmcv_params* p,
+                  const rmcv_legacy_params* lp, int stages, uint64_t* ticket)
+{
+    if (!pl || !d_frames || !p) return RMCV_ERR_BAD_ARG;
+    if (!(stages & RMCV_STAGE_BINARY)) return pfail(pl, RMCV_ERR_BAD_ARG, "a pipelined batch starts at RMCV_STAGE_BINARY");
+    if (stages & RMCV_STAGE_HANDOVER) return pfail(pl, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER is the pipeline's own business (rmcv_pipeline_config::handover)");
+    hipSetDevice(pl->device);
+    const uint64_t t = pl->next_ticket;
+    const size_t k = (size_t)(t % (uint64_t)pl->cfg.depth);
+    rmcv_ctx* c = pl->ring[k];
+    hipStream_t A = pl->pix[(size_t)(t % (uint64_t)pl->cfg.pixel_streams)], B = pl->sp[k % (size_t)pl->cfg.sparse_streams];
+    const bool used = pl->slot_ticket[k] != 0;
+    int rc = rmcv_batch_set_device_frames(c, d_frames, n_frames, w, h, stride, frame_pitch); // (waits for the slot's work when the geometry changes)
+    if (rc) return cfail(pl, c, rc);
+    const int pixel = stages & (RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE), sparse = stages & ~(RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE);
+    // the slot's context buffers are free once its previous list is compacted
+    if (used) PCHK(pl, hipStreamWaitEvent(A, pl->ev_done[k], 0), "pipeline: wait for the slot");
+    rc = rmcv_batch_run(c, p, pixel, A);
+    if (rc) return cfail(pl, c, rc);
+    const bool ho = pl->cfg.handover == 1 && sparse;
+    if (!ho) {
+        PCHK(pl, hipEventRecord(pl->ev_bin[k], A), "pipeline: mark the pixel kernel");
+        PCHK(pl, hipStreamWaitEvent(B, pl->ev_bin[k], 0), "pipeline: chain the sparse stages");
+    }
+    if (sparse) {
+        // frame-level hand-over: the sparse kernel is enqueued BESIDE its own pixel kernel and takes each frame when its last strip is
+        // written (the context orders it behind what preceded that pixel kernel)
+        rc = lp ? rmcv_batch_run_legacy(c, p, lp, sparse | (ho ? RMCV_STAGE_HANDOVER : 0), B) : rmcv_batch_run(c, p, sparse | (ho ? RMCV_STAGE_HANDOVER : 0), B);
+        if (rc) return cfail(pl, c, rc);
+    }
+    // the record is rewritten: a reader on another stream (the hook's) must be through; readers on B are by stream order
+    if (pl->ev_hook[k]) {
+        PCHK(pl, hipStreamWaitEvent(B, (hipEvent_t)pl->ev_hook[k], 0), "pipeline: wait for the record's reader");
+        pl->ev_hook[k] = nullptr;
+    }
+    int32_t* offs = reinterpret_cast<int32_t*>(pl->d_rec[k]);
+    rc = ctx_compact(c, pl->d_rec[k] + pl->head_bytes, pl->cfg.armour_cap, offs, offs + pl->lim.max_frames + 1, B);
+    if (rc) return cfail(pl, c, rc);
+    // the context's buffers are free from here on: the next pixel kernel of this slot does not wait for the copy or the hook
+    PCHK(pl, hipEventRecord(pl->ev_done[k], B), "pipeline: mark the slot");
+    if (pl->cfg.host_results == 1) {
+        PCHK(pl, hipMemcpyAsync(pl->h_rec[k], pl->d_rec[k], (size_t)pl->record_bytes, hipMemcpyDeviceToHost, B), "pipeline: record to host");
+        PCHK(pl, hipEventRecord(pl->ev_host[k], B), "pipeline: mark the host copy");
+    }
+    pl->slot_ticket[k] = t + 1;
+    pl->slot_frames[k] = n_frames;
+    pl->next_ticket = t + 1;
+    if (ticket) *ticket = t;
+    if (pl->comm) {
+        // one communicator: its operations must execute in one order on every rank; they are issued in ticket order on alternating
+        // streams, so each gather first waits (an event, on the GPU) for the one before
+        if (pl->gather_pending) PCHK(pl, hipStreamWaitEvent(B, pl->ev_gather, 0), "pipeline: order the gathers");
+        rc = rmcv_gather(pl->comm, pl->d_rec[k], pl->record_bytes, pl->rank == pl->root ? pl->d_recv[k] : nullptr, pl->root, B);
+        if (rc) return pfail(pl, rc, rmcv_comm_last_error(pl->comm));
+        PCHK(pl, hipEventRecord(pl->ev_gather, B), "pipeline: mark the gather");
+        pl->gather_pending = true;
+        PCHK(pl, hipEventRecord(pl->ev_host[k], B), "pipeline: mark the gather"); // wait / collect cover the gather too
+    } else if (pl->hook) {
+        void* done = nullptr;
+        rc = pl->hook(pl->hook_user, t, pl->d_rec[k], pl->record_bytes, B, &done);
+        if (rc) return pfail(pl, rc, "the pipeline hook failed");
+        pl->ev_hook[k] = done;
+    }
+    return RMCV_OK;
+}
+
+int rmcv_pipeline_submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch,
+                         const rmcv_params* p, int stages, uint64_t* ticket)
+{
+    return submit(pl, d_frames, n_frames, w, h, stride, frame_pitch, p, nullptr, stages, ticket);
+}
+
+int rmcv_pipeline_submit_legacy(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch,
+                                const rmcv_params* p, const rmcv_legacy_params* lp, int stages, uint64_t* ticket)
+{
+    if (!lp) return RMCV_ERR_BAD_ARG;
+    return submit(pl, d_frames, n_frames, w, h, stride, frame_pitch, p, lp, stages, ticket);
+}
+
+// slot of a live ticket, or -1
+static int slot_of(rmcv_pipeline* pl, uint64_t ticket)
+{
+    if (ticket >= pl->next_ticket) return -1;
+    const size_t k = (size_t)(ticket % (uint64_t)pl->cfg.depth);
+    return pl->slot_ticket[k] == ticket + 1 ? (int)k : -1;
+}
+
+int rmcv_pipeline_wait(rmcv_pipeline* pl, uint64_t ticket)
+{
+    if (!pl) return RMCV_ERR_BAD_ARG;
+    const int k = slot_of(pl, ticket);
+    if (k < 0) return pfail(pl, RMCV_ERR_BAD_ARG, "no such ticket in flight (never issued, or its slot has been reused)");
+    hipSetDevice(pl->device);
+    PCHK(pl, hipEventSynchronize(pl->ev_done[(size_t)k]), "pipeline: wait");
+    if (pl->cfg.host_results == 1 || pl->comm) PCHK(pl, hipEventSynchronize(pl->ev_host[(size_t)k]), "pipeline: wait (host copy / gather)");
+    return RMCV_OK;
+}
+
+int rmcv_pipeline_collect(rmcv_pipeline* pl, uint64_t ticket, rmcv_armour* armours_out, int cap, int32_t* frame_offs, int32_t* n_total)
+{
+    if (!pl || cap < 0) return RMCV_ERR_BAD_ARG;
+    int rc = rmcv_pipeline_wait(pl, ticket);
+    if (rc) return rc;
+    const size_t k = (size_t)slot_of(pl, ticket);
+    const int nf = pl->slot_frames[k];
+    std::vector<uint8_t> tmp;
+    const uint8_t* rec = pl->h_rec[k];
+    if (pl->cfg.host_results != 1) { // lists stay on the device until asked for: the head first, then exactly the armours there are
+        tmp.resize((size_t)pl->head_bytes);
+        PCHK(pl, hipMemcpy(tmp.data(), pl->d_rec[k], (size_t)pl->head_bytes, hipMemcpyDeviceToHost), "pipeline: D2H head");
+        rec = tmp.data();
+    }
+    const int32_t* offs = reinterpret_cast<const int32_t*>(rec);
+    const int32_t total = offs[nf], st = offs[pl->lim.max_frames + 1];
+    if (n_total) *n_total = total;
+    if (frame_offs) memcpy(frame_offs, offs, (size_t)(nf + 1) * 4);
+    pl->collected++;
+    if (st & RMCV_FRAME_TIMEOUT) return pfail(pl, RMCV_ERR_HIP, "frame-level hand-over timed out: the pixel kernel of this batch never delivered its planes");
+    if (st & (RMCV_FRAME_OVF_CONTOURS | RMCV_FRAME_OVF_POINTS | RMCV_FRAME_OVF_BLOBS | RMCV_FRAME_OVF_ARMOURS))
+        return pfail(pl, RMCV_ERR_CAPACITY, "context limits exceeded on at least one frame of the batch (rmcv_batch_counts on the slot's context names it)");
+    if (total > pl->cfg.armour_cap) return pfail(pl, RMCV_ERR_CAPACITY, "the batch has more armours than the pipeline's armour_cap");
+    if (total > cap) return pfail(pl, RMCV_ERR_CAPACITY, "output capacity exceeded");
+    if (armours_out && total) {
+        if (pl->cfg.host_results == 1) memcpy(armours_out, rec + pl->head_bytes, (size_t)total * sizeof(rmcv_armour));
+        else PCHK(pl, hipMemcpy(armours_out, pl->d_rec[k] + pl->head_bytes, (size_t)total * sizeof(rmcv_armour), hipMemcpyDeviceToHost), "pipeline: D2H armours");
+    }
+    return RMCV_OK;
+}
+
+int rmcv_pipeline_drain(rmcv_pipeline* pl)
+{
+    if (!pl) return RMCV_ERR_BAD_ARG;
+    hipSetDevice(pl->device);
+    for (auto s : pl->pix) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
+    for (auto s : pl->sp) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
+    for (size_t k = 0; k < pl->ev_hook.size(); k++)
+        if (pl->ev_hook[k]) {
+            PCHK(pl, hipEventSynchronize((hipEvent_t)pl->ev_hook[k]), "pipeline: drain (hook)");
+            pl->ev_hook[k] = nullptr;
+        }
+    return RMCV_OK;
+}
+
+int rmcv_pipeline_record(rmcv_pipeline* pl, uint64_t ticket, void** d_record, void** hip_stream)
+{
+    if (!pl) return RMCV_ERR_BAD_ARG;
+    const int k = slot_of(pl, ticket);
+    if (k < 0) return pfail(pl, RMCV_ERR_BAD_ARG, "no such ticket in flight (never issued, or its slot has been reused)");
+    if (d_record) *d_record = pl->d_rec[(size_t)k];
+    if (hip_stream) *hip_stream = pl->sp[(size_t)k % (size_t)pl->cfg.sparse_streams];
+    return RMCV_OK;
+}
+
+int rmcv_pipeline_gathered(rmcv_pipeline* pl, uint64_t ticket, void** d_recv, int64_t* bytes)
+{
+    if (!pl || !pl->comm) return RMCV_ERR_BAD_ARG;
+    const int k = slot_of(pl, ticket);
+    if (k < 0) return pfail(pl, RMCV_ERR_BAD_ARG, "no such ticket in flight (never issued, or its slot has been reused)");
+    if (d_recv) *d_recv = pl->rank == pl->root ? pl->d_recv[(size_t)k] : nullptr;
+    if (bytes) *bytes = pl->record_bytes * pl->n_ranks;
+    return RMCV_OK;
+}
+
+// ---- device memory for hosts without HIP headers ----
+int rmcv_device_alloc(int device, int64_t bytes, void** d_ptr)
+{
+    if (!d_ptr || bytes <= 0) return RMCV_ERR_BAD_ARG;
+    *d_ptr = nullptr;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return RMCV_ERR_NO_DEVICE; }
+    const hipError_t e = hipMalloc(d_ptr, (size_t)bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? RMCV_ERR_NOMEM : RMCV_ERR_HIP; }
+    return RMCV_OK;
+}
+
+void rmcv_device_free(int device, void* d_ptr)
+{
+    if (!d_ptr) return;
+    if (hipSetDevice(device) == hipSuccess) (void)hipFree(d_ptr);
+    (void)hipGetLastError();
+}
+
+int rmcv_device_upload(int device, void* d_dst, const void* h_src, int64_t bytes)
+{
+    if (!d_dst || !h_src || bytes < 0) return RMCV_ERR_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess || hipMemcpy(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return RMCV_ERR_HIP; }
+    return RMCV_OK;
+}
+
+int rmcv_device_download(int device, void* h_dst, const void* d_src, int64_t bytes)
+{
+    if (!h_dst || !d_src || bytes < 0) return RMCV_ERR_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess || hipMemcpy(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return RMCV_ERR_HIP; }
+    return RMCV_OK;
+}
+
+} // extern "C"

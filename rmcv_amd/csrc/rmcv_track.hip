@@ -8,6 +8,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <vector>
+
 #include <algorithm>
 
 #include "../../include/rmcv_abi.h"
@@ -266,9 +268,30 @@ int rmcv_track_step(rmcv_track* tracking, int32_t* n_tracking, int cap, rmcv_tra
     if (!tracking || !n_tracking || !n_obs || *n_tracking < 0 || *n_obs < 0 || (*n_obs > 0 && !obs) || !(tick_frequency > 0)) return RMCV_ERR_BAD_ARG;
     int nt = *n_tracking, no = *n_obs;
     if (no == 0) return RMCV_OK; // :61
-    // the reference's vectors grow without bound; here `cap` is the caller's.  The list can only shrink before the survivors are
-    // appended, so nt + no bounds the result: checked BEFORE anything is touched, an error leaves both lists as they were.
-    if (nt + no > cap) return RMCV_ERR_CAPACITY;
+    // The reference's vectors grow without bound; here `cap` is the caller's.  What the pass will leave behind is counted FIRST, on
+    // indices only: the matching depends on the bounding boxes (which update() never touches) and on the lost counts, so a dry run
+    // of the loop below tells exactly how many targets survive and how many observations stay unmatched.  Only if those do not fit
+    // is RMCV_ERR_CAPACITY returned -- before anything is changed.  (A steady state of N targets matched by N observations needs
+    // cap >= N, as the reference's loop does, not 2 N.)
+    if (nt + no > cap) {
+        std::vector<int> tg((size_t)nt), ob((size_t)no);
+        for (int i = 0; i < nt; i++) tg[(size_t)i] = i;
+        for (int k = 0; k < no; k++) ob[(size_t)k] = k;
+        if (nt > 0)
+            for (size_t i = 0; i < tg.size(); i++) {
+                int index = -1;
+                float iou = 0;
+                for (size_t k = 0; k < ob.size(); k++) {
+                    int32_t hit = -1;
+                    float v = 0;
+                    rmcv_max_iou(&tracking[tg[i]].armour, &obs[ob[k]].armour, 1, &hit, &v);
+                    if (hit == 0 && v > iou) { iou = v; index = (int)k; }
+                }
+                if (iou > 0.5f) ob.erase(ob.begin() + index);
+                else if (tracking[tg[i]].lost_count > 25) tg.erase(tg.begin() + (long)i); // (and the loop's i++ skips the one that moved in)
+            }
+        if ((int)(tg.size() + ob.size()) > cap) return RMCV_ERR_CAPACITY;
+    }
     if (nt == 0) { // :63-67
         memcpy(tracking, obs, (size_t)no * sizeof(rmcv_track));
         *n_tracking = no;

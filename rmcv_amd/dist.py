@@ -30,8 +30,10 @@ def shard(n_total, rank, world):
 
 
 def record_layout(n_local, cap):
-    """(offset of armours, total bytes) of a rank's record"""
-    head = ((n_local + 1) * 4 + 15) // 16 * 16
+    """(offset of armours, total bytes) of a rank's record: [frame_offs: n_local + 1 int32 | status: int32 | pad to 16 B | armours]
+    -- the record rmcv_pipeline_* keeps per batch (include/rmcv_abi.h: rmcv_pipeline_info), whose status word is the OR of the
+    batch's per-frame status bits"""
+    head = ((n_local + 2) * 4 + 15) // 16 * 16
     return head, head + cap * ARMOUR_BYTES
 
 
@@ -96,6 +98,79 @@ def gather_detections(frame_offs, armours_u8, cap, device="cpu", group=None, dst
     if recs is None:
         return None
     return unpack_records(recs, n_local, cap)
+
+
+class _DevMem:
+    """`nbytes` bytes at a device address, for torch.as_tensor (a view, no copy)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def tensor_at(ptr, nbytes, device):
+    """uint8 tensor VIEW of `nbytes` bytes at `ptr` -- device memory for a cuda device, host memory for "cpu" (the gloo tests)"""
+    device = torch.device(device)
+    if device.type == "cuda":
+        return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
+    return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(int(ptr))))
+
+
+class TorchGatherHook:
+    """The hook of a Pipeline (rmcv_pipeline_set_hook) that gathers every batch's record to `dst` with torch.distributed --
+    RCCL over xGMI on the GPU box (backend "nccl"), gloo in the CPU tests.  Asynchronous: the collective is ordered behind the
+    record's compaction (the stream the pipeline names), the pipeline's streams do not wait for it; a record is rewritten `depth`
+    tickets later, and the pipeline orders that rewrite behind the event this hook hands back (cuda) -- a CPU caller waits with
+    wait(ticket) before it refills the record."""
+
+    def __init__(self, record_bytes, depth, device, group=None, dst=0):
+        self.depth, self.device, self.group, self.dst = int(depth), torch.device(device), group, dst
+        self.cuda = self.device.type == "cuda"
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.record_bytes = int(record_bytes)
+        self.recs = [None] * self.depth
+        self.outs = [[torch.empty(self.record_bytes, dtype=torch.uint8, device=self.device) for _ in range(self.world)]
+                     if self.rank == dst else None for _ in range(self.depth)]
+        self.works = [None] * self.depth
+        self._ext = {}
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=self.device)
+            self.events = [torch.cuda.Event() for _ in range(self.depth)]
+
+    def __call__(self, ticket, d_record, record_bytes, hip_stream):
+        k = ticket % self.depth
+        if self.recs[k] is None or self.recs[k].data_ptr() != d_record:
+            self.recs[k] = tensor_at(d_record, record_bytes, self.device)
+        if not self.cuda:
+            self.works[k] = dist.gather(self.recs[k], self.outs[k], dst=self.dst, group=self.group, async_op=True)
+            return None
+        ext = self._ext.get(hip_stream)
+        if ext is None:
+            ext = self._ext[hip_stream] = torch.cuda.ExternalStream(hip_stream, device=self.device)
+        with torch.cuda.stream(ext):        # the process group's stream waits for this one: the record is complete when it is read
+            self.works[k] = dist.gather(self.recs[k], self.outs[k], dst=self.dst, group=self.group, async_op=True)
+        with torch.cuda.stream(self.side):  # ... and the record's next rewrite waits for the collective, not the other way round
+            self.works[k].wait()
+            self.events[k].record(self.side)
+        return self.events[k].cuda_event
+
+    def wait(self, ticket):
+        """host-side: the gather of `ticket` is through (its record may be rewritten, its gathered records read)"""
+        k = ticket % self.depth
+        if self.works[k] is not None:
+            self.works[k].wait()
+            if self.cuda:
+                self.events[k].synchronize()
+
+    def wait_all(self):
+        for k in range(self.depth):
+            if self.works[k] is not None:
+                self.works[k].wait()
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+
+    def records(self, ticket):
+        """dst: the list of per-rank records of `ticket` (valid after wait, until ticket + depth is submitted); None elsewhere"""
+        return self.outs[ticket % self.depth]
 
 
 class AbiGather:

@@ -33,17 +33,25 @@ def main():
     from rmcv_amd import synth
     O.set_math_mode(0)
     ap_steps = a.steps
-    # the bench's pipelined form: `ap_steps` steps over TWO alternating records, every gather asynchronous (async_op), a record
-    # rewritten only after work.wait() on the gather that last read it; step s of rank r detects frames [(s*world + r)*n, ...)
-    recs_buf = [rdist.new_record(a.frames, a.cap, "cpu") for _ in range(2)]
-    outs = [rdist.new_gather_list(r) for r in recs_buf]
-    works, results = [None, None], []
+    # the bench's pipelined form: `ap_steps` steps through a ring of `depth` records, every record gathered by the hook the bench
+    # hands to rmcv_pipeline_set_hook (rmcv_amd.dist.TorchGatherHook: torch.distributed.gather with async_op) -- driven here by a
+    # stand-in for the ring with the same hook protocol (hook(ticket, record pointer, bytes, stream) right behind the record's
+    # production; a record is refilled only after the gather that last read it is through); step s of rank r detects frames
+    # [(s*world + r)*n, ...)
+    depth = 2
+    _, rb = rdist.record_layout(a.frames, a.cap)
+    ring = [np.zeros(rb, np.uint8) for _ in range(depth)]            # the records (host memory here, HBM on the GPU box)
+    hook = rdist.TorchGatherHook(rb, depth, "cpu")
+    results = []
+
+    def consume(ticket):
+        hook.wait(ticket)
+        if rank == 0:
+            results.append(rdist.unpack_records(hook.records(ticket), a.frames, a.cap))   # consumed before the buffers are reused
     for s in range(ap_steps):
-        k = s % 2
-        if works[k] is not None:
-            works[k].wait()
-            if rank == 0:
-                results.append(rdist.unpack_records(outs[k], a.frames, a.cap))      # consumed before the buffers are reused
+        k = s % depth
+        if s >= depth:
+            consume(s - depth)                                        # (the pipeline orders the rewrite behind the hook's event)
         offs, arms = [0], []
         base = (s * world + rank) * a.frames
         for i in range(base, base + a.frames):                          # bench.py: rank r owns frames [r*n, (r+1)*n) of its step
@@ -51,14 +59,11 @@ def main():
             arms.append(x)
             offs.append(offs[-1] + len(x))
         arm = (np.concatenate(arms) if arms else np.zeros(0, O.ARMOUR)).view(np.uint8).reshape(-1)
-        recs_buf[k].zero_()
-        rdist.fill_record(recs_buf[k], a.frames, a.cap, np.asarray(offs, np.int32), arm)
-        _, works[k] = rdist.gather_records(recs_buf[k], out=outs[k], async_op=True)
-    for s in range(max(0, ap_steps - 2), ap_steps):                     # drain, in step order
-        k = s % 2
-        works[k].wait()
-        if rank == 0:
-            results.append(rdist.unpack_records(outs[k], a.frames, a.cap))
+        ring[k][:] = 0
+        rdist.fill_record(rdist.tensor_at(ring[k].ctypes.data, rb, "cpu"), a.frames, a.cap, np.asarray(offs, np.int32), arm)
+        assert hook(s, ring[k].ctypes.data, rb, 0) is None
+    for s in range(max(0, ap_steps - depth), ap_steps):               # drain, in step order
+        consume(s)
     if rank == 0:
         g, goffs = results[0]
         h = hashlib.sha256()

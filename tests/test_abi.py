@@ -88,3 +88,45 @@ def test_gather_entry_points_check_their_arguments():
     assert L.rmcv_gather(None, None, C.c_int64(16), None, 0, None) == abi.ERR_BAD_ARG
     L.rmcv_comm_destroy.restype = None
     L.rmcv_comm_destroy(None)                                                        # a no-op
+
+
+def test_pipeline_entry_points_without_a_gpu():
+    """rmcv_pipeline_*: struct layouts, defaults, argument checks; without a GPU creation fails with RMCV_ERR_NO_DEVICE (no CPU path)"""
+    import pytest
+    import torch
+    from rmcv_amd import abi
+    L = abi.lib()
+    assert C.sizeof(abi.PipelineConfig) == 32 and C.sizeof(abi.PipelineInfo) == 80
+    cfg = abi.PipelineConfig()
+    L.rmcv_default_pipeline_config(C.byref(cfg))
+    assert (cfg.depth, cfg.pixel_streams, cfg.sparse_streams, cfg.sparse_waves, cfg.pixel_groups, cfg.host_results, cfg.handover) == (8, 2, 4, 4, 2, 1, 2)
+    h = C.c_void_p()
+    assert L.rmcv_pipeline_create(0, None, None, None) == abi.ERR_BAD_ARG
+    t = C.c_uint64(0)
+    assert L.rmcv_pipeline_submit(None, None, 1, 1, 1, 3, 3, None, 15, C.addressof(t)) == abi.ERR_BAD_ARG
+    assert L.rmcv_pipeline_collect(None, 0, None, 0, None, None) == abi.ERR_BAD_ARG
+    assert L.rmcv_pipeline_drain(None) == abi.ERR_BAD_ARG and L.rmcv_pipeline_wait(None, 0) == abi.ERR_BAD_ARG
+    assert L.rmcv_pipeline_context(None, 0) is None
+    assert L.rmcv_device_alloc(0, 0, C.byref(h)) == abi.ERR_BAD_ARG
+    libc = C.CDLL(None)                                             # (os.environ is Python's snapshot: ask the C environment)
+    libc.getenv.restype = C.c_char_p
+    assert int(libc.getenv(b"GPU_MAX_HW_QUEUES")) >= 1              # the library's load-time default (or the caller's own value)
+    if not torch.cuda.is_available():
+        from rmcv_amd import Pipeline, RmcvError
+        with pytest.raises(RmcvError) as e:
+            Pipeline(device=0, depth=2)
+        assert e.value.code == abi.ERR_NO_DEVICE
+        assert L.rmcv_device_alloc(0, 1024, C.byref(h)) == abi.ERR_NO_DEVICE
+
+
+def test_bench_refuses_silent_dev_knobs():
+    """an environment knob that changes the timed region is refused unless --dev (and then echoed in config.dev_knobs)"""
+    import sys
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.dev_knobs({}, False) == {}
+    with pytest.raises(SystemExit) as e:
+        bench.dev_knobs({"RMCV_BENCH_STAGES": "1", "HOME": "/x"}, False)
+    assert "RMCV_BENCH_STAGES" in str(e.value)
+    assert bench.dev_knobs({"RMCV_SPARSE_WAVES": "8", "RMCV_K1_BPC": ""}, True) == {"RMCV_SPARSE_WAVES": "8"}

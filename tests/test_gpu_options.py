@@ -3,8 +3,8 @@ documents, full path on a small batch, lists compared with the default's byte fo
 import numpy as np
 import pytest
 
-from rmcv_amd import (CAMP_BLUE, OPT_CONTOUR_TIER, OPT_DENSE_DEFER, OPT_HANDOVER, OPT_PIXEL_GROUPS, OPT_PIXEL_HALO_NT, OPT_PIXEL_STAGGER, OPT_PIXEL_TAPER,
-                      OPT_SPARSE_PRIO, OPT_SPARSE_WAVES, STAGE_ALL, Context, default_params, synth)
+from rmcv_amd import (CAMP_BLUE, OPT_CONTOUR_TIER, OPT_DENSE_DEFER, OPT_HANDOVER, OPT_PIXEL_GROUPS, OPT_PIXEL_HALO_NT,
+                      OPT_SPARSE_WAVES, STAGE_ALL, Context, default_params, synth)
 from rmcv_amd.abi import RmcvError
 
 pytestmark = pytest.mark.gpu
@@ -28,8 +28,8 @@ def test_every_option_leaves_the_results_alone():
     c.run(default_params(), STAGE_ALL)
     c.sync()
     ref = _lists(c)
-    cases = [(OPT_SPARSE_WAVES, 4), (OPT_PIXEL_GROUPS, 1), (OPT_PIXEL_GROUPS, 5), (OPT_PIXEL_TAPER, 1), (OPT_PIXEL_HALO_NT, 1), (OPT_PIXEL_STAGGER, 700), (OPT_SPARSE_PRIO, 0),
-             (OPT_SPARSE_PRIO, 2), (OPT_DENSE_DEFER, 1), (OPT_HANDOVER, 1), (OPT_CONTOUR_TIER, 2)]
+    cases = [(OPT_SPARSE_WAVES, 4), (OPT_PIXEL_GROUPS, 1), (OPT_PIXEL_GROUPS, 5), (OPT_PIXEL_HALO_NT, 1),
+             (OPT_DENSE_DEFER, 1), (OPT_HANDOVER, 1), (OPT_CONTOUR_TIER, 2)]
     for opt, val in cases:
         c.set_option(opt, val)
         if opt == OPT_DENSE_DEFER:
@@ -38,7 +38,8 @@ def test_every_option_leaves_the_results_alone():
         c.sync()
         got = _lists(c)
         assert all(a == b for a, b in zip(got, ref)), (opt, val)
-    for opt, val in ((OPT_SPARSE_PRIO, 4), (OPT_PIXEL_TAPER, 2), (OPT_PIXEL_HALO_NT, 2), (OPT_PIXEL_STAGGER, -1), (OPT_DENSE_DEFER, 2), (99, 0)):
+    for opt, val in ((8, 0), (9, 3), (10, 1),                                   # round 3's measurement knobs: removed
+                     (OPT_PIXEL_HALO_NT, 2), (OPT_DENSE_DEFER, 2), (99, 0)):
         with pytest.raises(RmcvError):
             c.set_option(opt, val)
     c.close()

@@ -1,0 +1,229 @@
+"""rmcv_pipeline_* (include/rmcv_abi.h): the pipelined batch schedule behind the C-ABI -- the process loop of the reference
+(executable/main.cpp:163-209) in batch form.  Streams of DISTINCT batches go through a depth-8 ring; every batch's armour list must
+come back equal to the oracle's, in submission order, whatever else is in flight beside it."""
+import ctypes as C
+import json
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from rmcv_amd import (CAMP_BLUE, STAGE_ALL, STAGE_BINARY, STAGE_CONTOURS, STAGE_IDENTITY, STAGE_NO_IMAGE, LegacyParams, Pipeline, RmcvError,
+                      default_params, synth)
+from rmcv_amd import abi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_lists(oracle, frames):
+    with ThreadPoolExecutor(16) as ex:
+        return list(ex.map(lambda f: oracle.detect_frame(f)["armours"], frames))
+
+
+def check_batch(oracle, frames, arm, offs):
+    refs = oracle_lists(oracle, frames)
+    assert len(offs) == len(frames) + 1
+    for f, r in enumerate(refs):
+        assert arm[offs[f]:offs[f + 1]].tobytes() == r.tobytes(), f
+    assert offs[-1] == sum(len(r) for r in refs)
+
+
+@pytest.mark.parametrize("one_dense", [False, True], ids=["plain", "one_dense_frame_per_batch"])
+def test_24_distinct_batches_through_a_depth_8_pipeline(oracle, one_dense):
+    """24 distinct 256-frame batches (1280x1024), eight in flight: the list of every batch equals the oracle's, in submission order.
+    With one frame per batch beyond findContours' LDS tables (a lit window + 2000 specks: the mid tier), which finishes long after
+    its batch's other frames."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, w, h, nb = 256, 1280, 1024, 24
+    pl = Pipeline(device=0, depth=8, max_frames=n, max_width=w, max_height=h, max_contours=4096)
+    assert (pl.info.depth, pl.info.pixel_streams, pl.info.sparse_streams, pl.info.sparse_waves, pl.info.pixel_groups) == (8, 2, 4, 4, 2)
+    p = default_params()
+    host, devf, got = [], [], {}
+    for i in range(nb):
+        fr = synth.batch(500000 + 7919 * i, n, w, h, CAMP_BLUE, i % 2, threads=16)
+        if one_dense:
+            fr[(37 * i) % n] = synth.frame(900000 + i, w, h, CAMP_BLUE, 14)
+        host.append(fr)
+        devf.append(torch.from_numpy(fr).to(dev))
+        t = pl.submit(devf[i].data_ptr(), n, h, w, p, STAGE_ALL)
+        assert t == i
+        if i >= 8:                                                    # the slot of ticket i - 8 has just been handed to ticket i ...
+            with pytest.raises(RmcvError):
+                pl.collect(i - 8)
+        if i >= 7:                                                    # ... so its predecessor is collected while seven others are in flight
+            got[i - 7] = pl.collect(i - 7)
+    pl.drain()
+    for i in range(nb - 7, nb):
+        got[i] = pl.collect(i)
+    with pytest.raises(RmcvError):
+        pl.collect(0)                                                  # long gone
+    with pytest.raises(RmcvError):
+        pl.collect(nb)                                                 # never issued
+    for i in range(nb):
+        arm, offs = got[i]
+        check_batch(oracle, host[i], arm, offs)
+    if one_dense:
+        st = pl.context_of(nb - 1).counts()["status"]
+        assert np.count_nonzero(st & abi.FRAME_MID_PATH) == 1 and not (st & 15).any()
+    assert pl.get_info().submitted == nb
+    pl.close()
+
+
+def test_pipeline_stage_getters_sizes_and_modes(oracle):
+    """smaller geometries, ragged batch sizes, the geometry changing in mid-stream, lists kept on the device (host_results = 2), a
+    detection-only stage mask; per-stage getters on the slot's context"""
+    import torch
+    dev = torch.device("cuda", 0)
+    pl = Pipeline(device=0, depth=3, pixel_streams=2, sparse_streams=2, host_results=2, max_frames=40, max_width=1920, max_height=1200)
+    assert pl.info.host_results == 2 and pl.info.depth == 3
+    p = default_params()
+    plan = [(40, 640, 512, STAGE_ALL), (13, 1920, 1200, STAGE_ALL), (40, 1280, 1024, STAGE_ALL | STAGE_NO_IMAGE), (1, 1280, 720, STAGE_ALL),
+            (40, 640, 512, STAGE_ALL), (7, 1280, 1024, STAGE_ALL), (40, 1920, 1200, STAGE_ALL)]
+    keep = []
+    for i, (n, w, h, st) in enumerate(plan):
+        fr = synth.batch(31000 + 100 * i, n, w, h, CAMP_BLUE, i % 2, threads=16)
+        d = torch.from_numpy(fr).to(dev)
+        keep.append((fr, d))
+        t = pl.submit(d.data_ptr(), n, h, w, p, st)
+        arm, offs = pl.collect(t)
+        check_batch(oracle, fr, arm, offs)
+        c = pl.context_of(t)
+        f = n // 2
+        r = oracle.detect_frame(fr[f])
+        pts, co = c.contours(f)
+        assert np.array_equal(co, r["offs"]) and np.array_equal(pts, r["pts"])
+        assert c.blobs(f)[0].tobytes() == r["blobs"].tobytes()
+        if not (st & STAGE_NO_IMAGE):
+            assert np.array_equal(c.binary(f), r["binary"])
+    with pytest.raises(RmcvError):
+        pl.submit(keep[0][1].data_ptr(), 40, 512, 640, p, STAGE_ALL & ~STAGE_BINARY)     # a pipelined batch starts at the pixel kernel
+    with pytest.raises(RmcvError):
+        pl.submit(keep[0][1].data_ptr(), 41, 512, 640, p, STAGE_ALL)                      # more frames than the ring's contexts hold
+    t = pl.submit(keep[0][1].data_ptr(), 40, 512, 640, p, STAGE_BINARY | STAGE_CONTOURS)  # a partial path is fine (its list is the previous run's)
+    pl.wait(t)
+    pts, co = pl.context_of(t).contours(3)
+    r = oracle.detect_frame(keep[0][0][3])
+    assert np.array_equal(co, r["offs"]) and np.array_equal(pts, r["pts"])
+    pl.close()
+
+
+def test_pipeline_capacity_errors_name_the_need():
+    import torch
+    dev = torch.device("cuda", 0)
+    n, w, h = 16, 1280, 1024
+    fr = synth.batch(4200, n, w, h, CAMP_BLUE, 0, threads=16)
+    d = torch.from_numpy(fr).to(dev)
+    pl = Pipeline(device=0, depth=2, armour_cap=3, max_frames=n, max_width=w, max_height=h)
+    t = pl.submit(d.data_ptr(), n, h, w, default_params(), STAGE_ALL)
+    out = np.empty(64, abi.ARMOUR)
+    offs = np.empty(n + 1, np.int32)
+    tot = C.c_int32(0)
+    rc = abi.lib().rmcv_pipeline_collect(pl._h, t, abi.ptr(out), 64, abi.ptr(offs), C.addressof(tot))
+    assert rc == abi.ERR_CAPACITY and tot.value > 3 and offs[n] == tot.value         # the ring's armour_cap is too small: says how many there are
+    pl.close()
+    pl = Pipeline(device=0, depth=2, max_frames=n, max_width=w, max_height=h, max_contours=4)
+    t = pl.submit(d.data_ptr(), n, h, w, default_params(), STAGE_ALL)
+    with pytest.raises(RmcvError) as e:
+        pl.collect(t)
+    assert e.value.code == abi.ERR_CAPACITY                                           # a frame exceeded a context limit: the status word says so
+    assert (pl.context_of(t).counts()["status"] & abi.FRAME_OVF_CONTOURS).any()
+    pl.close()
+
+
+def test_pipeline_hook_sees_every_record_in_order():
+    """the hook rides behind every batch's compaction, on the stream the record is produced on; what it enqueues there sees the
+    finished record.  Here: a device-to-device copy of the record into a log (torch, on the hook's stream)."""
+    import torch
+    from rmcv_amd import dist as rdist
+    dev = torch.device("cuda", 0)
+    n, w, h, depth, nb = 32, 1280, 1024, 4, 10
+    pl = Pipeline(device=0, depth=depth, max_frames=n, max_width=w, max_height=h)
+    rb = pl.info.record_bytes
+    log = torch.zeros((nb, rb), dtype=torch.uint8, device=dev)
+    seen = []
+
+    def hook(ticket, d_record, nbytes, stream):
+        assert nbytes == rb
+        seen.append(ticket)
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+            log[ticket].copy_(rdist.tensor_at(d_record, nbytes, dev), non_blocking=True)
+        return None
+    pl.set_hook(hook)
+    sets = [torch.from_numpy(synth.batch(8800 + 50 * i, n, w, h, CAMP_BLUE, 0, threads=16)).to(dev) for i in range(nb)]
+    for i in range(nb):
+        pl.submit(sets[i].data_ptr(), n, h, w, default_params(), STAGE_ALL)
+    pl.drain()
+    torch.cuda.synchronize()
+    assert seen == list(range(nb))
+    head = pl.info.armours_offset
+    for i in range(nb - depth, nb):
+        arm, offs = pl.collect(i)
+        rec = log[i].cpu().numpy()
+        assert rec[:(n + 1) * 4].view(np.int32).tolist() == offs.tolist()
+        assert rec[head:head + len(arm) * 88].tobytes() == arm.tobytes()
+    for i in range(nb - depth):                                       # the log keeps what the ring has long overwritten
+        assert log[i].cpu().numpy()[:(n + 1) * 4].view(np.int32)[n] > 0
+    pl.set_hook(None)
+    pl.close()
+
+
+def test_pipeline_identity_and_legacy_stages(oracle):
+    """RMCV_STAGE_IDENTITY (BASELINE config 5) and the legacy blob stage through the ring equal the plain batch entry points"""
+    import torch
+    from rmcv_amd import Context
+    dev = torch.device("cuda", 0)
+    n, w, h = 12, 1920, 1200
+    fr = synth.batch(61000, n, w, h, CAMP_BLUE, 0, threads=16)
+    d = torch.from_numpy(fr).to(dev)
+    svm = synth.svm_weights()
+    pl = Pipeline(device=0, depth=2, max_frames=n, max_width=w, max_height=h)
+    for c in pl.contexts:
+        c.svm_load(*svm)
+    ref = Context(device=0, max_frames=n, max_width=w, max_height=h)
+    ref.svm_load(*svm)
+    ref.upload(fr)
+    ref.run(default_params(), STAGE_ALL | STAGE_IDENTITY)
+    ref.sync()
+    t = pl.submit(d.data_ptr(), n, h, w, default_params(), STAGE_ALL | STAGE_IDENTITY)
+    arm, offs = pl.collect(t)
+    ra, ro = ref.armours()
+    assert arm.tobytes() == ra.tobytes() and offs.tolist() == ro.tolist() and len(arm) > 0
+    assert pl.context_of(t).identities().tolist() == ref.identities().tolist()
+    lp = LegacyParams(1.5, 80, 70, 10, 99999, 0)
+    ref.run_legacy(lp, default_params(), STAGE_ALL)
+    ref.sync()
+    t = pl.submit(d.data_ptr(), n, h, w, default_params(), STAGE_ALL, legacy=lp)
+    arm, offs = pl.collect(t)
+    ra, ro = ref.armours()
+    assert arm.tobytes() == ra.tobytes() and offs.tolist() == ro.tolist()
+    ref.close()
+    pl.close()
+
+
+def test_c_host_drives_the_same_pipeline(oracle):
+    """tools/pipeline_bench.c: the three calls from a C program (no Python, no torch in that process) -- a small run, its armour
+    counts against the oracle's for the same synthetic frames"""
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        pytest.skip("no C compiler on this box")
+    exe = os.path.join(ROOT, "gpurun_out", "pipeline_bench_test")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    libdir = os.path.join(ROOT, "rmcv_amd", "lib")
+    subprocess.run([cc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "pipeline_bench.c"), "-o", exe, "-L", libdir,
+                    "-lrmcv_hip", "-Wl,-rpath," + libdir, "-lpthread"], check=True, timeout=120)
+    n, depth, sets, steps = 16, 4, 4, 6
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}   # the library's own default applies
+    cp = subprocess.run([exe, "--frames", str(n), "--depth", str(depth), "--sets", str(sets), "--steps", str(steps), "--repeats", "2", "--warmup", "2",
+                         "--warmup-seconds", "0.05"], capture_output=True, text=True, timeout=600, env=env)
+    assert cp.returncode == 0, cp.stderr
+    out = json.loads(cp.stdout.strip().splitlines()[-1])
+    assert out["steps"] == steps and out["depth"] == depth and out["value"] > 0
+    assert out["gpu_max_hw_queues"] == 12                                      # set by the library when it was loaded
+    per_set = [sum(len(a) for a in oracle_lists(oracle, synth.batch(k * 1000003, n, 1280, 1024, CAMP_BLUE, 0, threads=16))) for k in range(sets)]
+    assert out["armours_set0"] == per_set[0]
+    assert out["armours_last_%d_batches" % depth] == sum(per_set)               # the last four steps cover every set once (sets == depth)

@@ -229,3 +229,17 @@ def test_association_loop_capacity_error_changes_nothing():
     assert buf[:6].tobytes() == before and obs.tobytes() == obs_before
     with pytest.raises(RmcvError):
         Context.track_step(tr, [mk(k, 20) for k in (0, 1, 20, 21, 22)], cap=8)
+
+
+def test_association_loop_steady_state_needs_no_spare_capacity():
+    """N tracked targets re-observed by N matching observations leave N entries (executable/main.cpp:69-83): cap = N is enough
+    (round 3 asked for n_tracking + n_obs <= cap up front, i.e. 2 N)"""
+    mk = lambda new, k, stamp: new(arm(50.0 * k, 10.0, 30.0, 30.0), 1, stamp, (float(k), 0.0, 1.0))
+    ta = Context.track_step([], [mk(Context.track_new, k, 10) for k in range(6)], cap=6)
+    tb = O.track_step([], [mk(O.track_new, k, 10) for k in range(6)], cap=16)
+    for stamp in (20, 30, 40):
+        ta = Context.track_step(ta, [mk(Context.track_new, k, stamp) for k in (3, 1, 0, 5, 4, 2)], cap=6)
+        tb = O.track_step(tb, [mk(O.track_new, k, stamp) for k in (3, 1, 0, 5, 4, 2)], cap=16)
+        assert len(ta) == 6 and ta.tobytes() == tb.tobytes()
+    with pytest.raises(RmcvError):                                  # one observation that matches nothing: 7 entries do not fit 6
+        Context.track_step(ta, [mk(Context.track_new, k, 50) for k in (0, 1, 2, 3, 4, 9)], cap=6)
