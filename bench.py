@@ -39,6 +39,9 @@ sys.path.insert(0, ROOT)
 # run 8 batches in flight over 2 pixel + 4 sparse streams; with the null stream and RCCL's that is more than 4 (a step's kernels
 # that share a queue with another batch's cannot overlap: the gather of every step cost 15 % at 4).  12 (8 and 16 measure the same).
 # librmcv_hip.so sets the same default when it is loaded; torch may start HIP before that, so it is set here as well.
+# NOT more: with 16 or 24 queues and two pipelines' worth of streams in the process (the dev tool RMCV_BENCH_AB) every step took
+# 0.63-0.67 ms instead of 0.257, and stayed there after the second pipeline was closed (tools/pipe_two.py): beyond ~12 active
+# queues the hardware scheduler time-slices them.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 FRAMES = 256
@@ -210,12 +213,12 @@ def main():
     legacy = LegacyParams(1.5, 80, 70, 10, 99999, int(os.environ.get("RMCV_LEGACY_FIT", "0"))) if args.workload == "legacy" else None
     max_contours = 4096 if args.variant >= 10 else 2048           # (the dense streams have up to ~2100 contours per frame)
 
-    def make_pipeline(depth, pix, sp, w=W, h=H, mc=max_contours, with_svm=svm):
+    def make_pipeline(depth, pix, sp, w=W, h=H, mc=max_contours, with_svm=svm, host_results=None):
         # a lone batch has the CUs to itself: 8 wavefronts per frame and 3 pixel workgroups per CU; batches in flight share every CU:
         # 4 and 2 (the library's own rule, rmcv_pipeline_create; the dev knobs override it)
         pl = Pipeline(device=local_rank, depth=depth, pixel_streams=pix, sparse_streams=sp, armour_cap=n * 8,
                       sparse_waves=int(knobs.get("RMCV_SPARSE_WAVES", 0)), pixel_groups=int(knobs.get("RMCV_PIXEL_GROUPS", 0)),
-                      host_results=2 if args.device_results else 1, handover=1 if args.handover else 2,
+                      host_results=host_results or (2 if args.device_results else 1), handover=1 if args.handover else 2,
                       max_frames=n, max_width=w, max_height=h, max_contours=mc)
         for c in pl.contexts:
             if with_svm:
@@ -367,6 +370,7 @@ def main():
         kind = f_[0]
         pairs_ = 12
         pls, stg, opt_ = {0: pl, 1: pl}, {0: stages, 1: stages}, None
+        # A is always the run's own pipeline, B a second one (at most two rings, i.e. 12 streams, exist at a time)
         if kind == "lib":        # "lib:<path>": THIS build against another build of librmcv_hip.so (tools/build_variant*.sh)
             from rmcv_amd import abi as abi_
             lib_a, lib_b = abi_.lib(), abi_.load(os.path.abspath(f_[1]))
@@ -374,10 +378,22 @@ def main():
             pls[1] = make_pipeline(ns, args.pixel_streams, args.sparse_streams)
             abi_.use(lib_a)
             label, pairs_ = "this build vs %s" % f_[1], int(f_[2]) if len(f_) > 2 else 12
-        elif kind == "sched":    # "sched:<depth,pix,sparse>:<depth,pix,sparse>": two shapes of the schedule
-            sh = [[int(x) for x in f_[1].split(",")], [int(x) for x in f_[2].split(",")]]
-            pls = {v: make_pipeline(*sh[v]) for v in (0, 1)}
-            label, pairs_ = "sched %s vs %s" % (sh[0], sh[1]), int(f_[3]) if len(f_) > 3 else 12
+        elif kind == "sched":    # "sched:<depth,pix,sparse>": the run's schedule against another shape
+            sh = [int(x) for x in f_[1].split(",")]
+            pls[1] = make_pipeline(*sh)
+            label, pairs_ = "sched %s vs %s" % ([ns, args.pixel_streams, args.sparse_streams], sh), int(f_[2]) if len(f_) > 2 else 12
+        elif kind == "env":      # "env:<NAME>:<b>": against a pipeline created under another value of an environment knob of the library
+            before = os.environ.get(f_[1])
+            os.environ[f_[1]] = f_[2]
+            pls[1] = make_pipeline(ns, args.pixel_streams, args.sparse_streams)
+            if before is None:
+                os.environ.pop(f_[1])
+            else:
+                os.environ[f_[1]] = before
+            label, pairs_ = "%s=%s vs %s" % (f_[1], before, f_[2]), int(f_[3]) if len(f_) > 3 else 12
+        elif kind == "hostres":  # "hostres:<b>": rmcv_pipeline_config::host_results (1: lists copied to pinned memory every step, 2: left in HBM)
+            pls[1] = make_pipeline(ns, args.pixel_streams, args.sparse_streams, host_results=int(f_[1]))
+            label, pairs_ = "host_results %d vs %s" % (info.host_results, f_[1]), int(f_[2]) if len(f_) > 2 else 12
         elif kind == "stages":   # "stages:<mask>:<mask>": what each stage COSTS the step (1 = pixel kernel only, 3 = + findContours, ...)
             stg = {0: int(f_[1]) | (stages & ~15), 1: int(f_[2]) | (stages & ~15)}
             label, pairs_ = "stage masks %s vs %s" % (f_[1], f_[2]), int(f_[3]) if len(f_) > 3 else 12

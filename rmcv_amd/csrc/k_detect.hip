@@ -185,8 +185,14 @@ static constexpr int COMPACT_FRAMES = 16;
 __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __restrict__ armours,
                                                         const int32_t* __restrict__ n_armours, int n_frames, int max_armours,
                                                         rmcv_armour* __restrict__ out, int cap, int32_t* __restrict__ frame_offs,
-                                                        const int32_t* __restrict__ status, int32_t* __restrict__ status_or)
+                                                        const int32_t* __restrict__ status, int32_t* __restrict__ status_or,
+                                                        uint8_t* __restrict__ host_rec, int host_head)
 {
+    // host_rec (nullable): the same record a second time, in pinned host memory mapped into the device's address space -- the
+    // kernel's own stores cross PCIe as posted writes, and only the armours there are travel (a copy of the whole record behind the
+    // kernel was a hand-over to the copy engine with a system-scope fence of its own, per step)
+    int32_t* const h_offs = reinterpret_cast<int32_t*>(host_rec);
+    rmcv_armour* const h_out = reinterpret_cast<rmcv_armour*>(host_rec + host_head);
     __shared__ int s_part[256];
     __shared__ int s_base, s_st;
     __shared__ int s_off[COMPACT_FRAMES], s_cnt[COMPACT_FRAMES];
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
         const int excl = s_base + s_part[tid] - c;
         if (f < n_frames && f >= f_begin && f < f_begin + COMPACT_FRAMES) {
             frame_offs[f] = excl;
+            if (host_rec) h_offs[f] = excl;
             s_off[f - f_begin] = excl;
             s_cnt[f - f_begin] = c;
         }
@@ -220,6 +227,10 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
     if (tid == 0 && blockIdx.x == 0) {
         frame_offs[n_frames] = s_base;
         if (status_or) *status_or = s_st;
+        if (host_rec) {
+            h_offs[n_frames] = s_base;
+            h_offs[status_or - frame_offs] = s_st; // (the status word's place in the record)
+        }
     }
     constexpr int DW = (int)(sizeof(rmcv_armour) / 4);
     for (int fi = wave; fi < COMPACT_FRAMES && f_begin + fi < n_frames; fi += 4) {
@@ -227,7 +238,12 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
         const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(armours + (int64_t)(f_begin + fi) * max_armours);
         uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(out + excl);
         const int nd = min(c, max(0, cap - excl)) * DW; // armours beyond the capacity of the list are dropped (the caller is told)
-        for (int i = lane; i < nd; i += 64) dst[i] = src[i];
+        uint32_t* __restrict__ hdst = reinterpret_cast<uint32_t*>(h_out + excl);
+        if (host_rec) {
+            for (int i = lane; i < nd; i += 64) { const uint32_t v = src[i]; dst[i] = v; hdst[i] = v; }
+        } else {
+            for (int i = lane; i < nd; i += 64) dst[i] = src[i];
+        }
     }
 }
 
@@ -243,10 +259,11 @@ hipError_t launch_status_clear(const Geom& g, const Bufs& b, int mask, hipStream
 }
 
 hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
-                                  int32_t* d_frame_offs, hipStream_t s, int32_t* d_status_or)
+                                  int32_t* d_frame_offs, hipStream_t s, int32_t* d_status_or, uint8_t* hd_record, int host_head)
 {
+    if (hd_record && !d_status_or) return hipErrorInvalidValue; // (the host mirror has the record's layout, status word included)
     return launch(k_compact_armours, dim3(std::max(1, (g.n_frames + COMPACT_FRAMES - 1) / COMPACT_FRAMES)), dim3(256), 0, s, b.armours, b.n_armours, g.n_frames, lim.max_armours, d_out,
-                       cap, d_frame_offs, b.status, d_status_or);
+                       cap, d_frame_offs, b.status, d_status_or, hd_record, host_head);
 }
 
 static hipError_t launch_pairs_tail(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s)

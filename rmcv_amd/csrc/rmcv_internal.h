@@ -147,9 +147,10 @@ int binary_launches(const Geom& g, const Bufs& b); // launches launch_binary mak
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
-// d_status_or (nullable): one word = the OR of the batch's per-frame status words
+// d_status_or (nullable): one word = the OR of the batch's per-frame status words; hd_record (nullable, needs d_status_or): the
+// record [frame_offs | ... status ... | armours at host_head] once more, in mapped pinned host memory (device address)
 hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
-                                  int32_t* d_frame_offs, hipStream_t s, int32_t* d_status_or = nullptr);
+                                  int32_t* d_frame_offs, hipStream_t s, int32_t* d_status_or = nullptr, uint8_t* hd_record = nullptr, int host_head = 0);
 hipError_t launch_status_clear(const Geom& g, const Bufs& b, int mask, hipStream_t s); // status[f] &= ~mask
 hipError_t launch_classify(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 // stage-wise helpers: binary (host-supplied 0/255 image) -> bit plane
@@ -182,7 +183,7 @@ hipError_t launch_gather3(const int32_t* a, const int32_t* b, const int32_t* c, 
 // then wait for `done` (recorded by the pipeline behind the slot's last launch) instead
 void ctx_external_order(rmcv_ctx* c, hipEvent_t done);
 // rmcv_batch_compact_armours + the batch's OR-ed status word
-int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s);
+int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s, void* hd_record = nullptr, int host_head = 0);
 const Limits& ctx_limits(const rmcv_ctx* c);
 
 } // namespace rmcv

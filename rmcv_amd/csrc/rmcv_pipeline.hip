@@ -12,7 +12,7 @@
 // reader on that stream by stream order alone.  Events per slot:
 //     ev_done   behind the compaction: the slot's context buffers are free            -> waited for by the slot's next pixel kernel
 //     ev_bin    behind the pixel kernel                                               -> waited for by the slot's sparse kernel
-//     ev_host   behind the record's copy to pinned memory                             -> waited for by collect / wait (host)
+//     ev_host   behind the record's gather (rmcv_pipeline_set_gather)                   -> waited for by collect / wait (host)
 //     ev_hook   (the hook's own, optional) the record has been read on another stream -> waited for by the slot's next compaction
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,7 +38,7 @@ struct rmcv_pipeline {
     std::vector<hipStream_t> pix, sp;
     std::vector<hipEvent_t> ev_bin, ev_done, ev_host;
     std::vector<void*> ev_hook;       // per slot: the event the hook handed back for the slot's last record (not owned), or null
-    std::vector<uint8_t*> d_rec, h_rec;
+    std::vector<uint8_t*> d_rec, h_rec, hd_rec; // the record in HBM, its pinned host mirror, the mirror's device address
     std::vector<uint64_t> slot_ticket; // ticket + 1 of the batch that lives in the slot (0: none yet)
     std::vector<int> slot_frames;
     uint64_t next_ticket = 0, collected = 0;
@@ -167,15 +167,25 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
         e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi);
         pl->sp.push_back(s);
     }
+    // Events: HIP's default (a system-scope release when the event fires).  hipEventDisableSystemFence / hipEventReleaseToDevice for the
+    // device-only events ev_bin / ev_done measured the same as the default (round 4, alternating pipelines of one process against a
+    // calibration pair: 1.049-1.063 against 1.051-1.061 for two identical pipelines), so nothing non-default is asked for.
+    const unsigned dev_flags = hipEventDisableTiming;
     for (int k = 0; k < d.depth && e == hipSuccess; k++) {
         hipEvent_t a = nullptr, b = nullptr, h = nullptr;
         uint8_t *dr = nullptr, *hr = nullptr;
-        e = hipEventCreateWithFlags(&a, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
+        e = hipEventCreateWithFlags(&a, dev_flags);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b, dev_flags); // (the host reads the record's mirror behind ev_done: it must stay a system-scope event)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc((void**)&dr, (size_t)pl->record_bytes);
         if (e == hipSuccess) e = hipMemset(dr, 0, (size_t)pl->record_bytes);
-        if (e == hipSuccess && d.host_results == 1) e = hipHostMalloc((void**)&hr, (size_t)pl->record_bytes, hipHostMallocDefault);
+        uint8_t* hdr = nullptr;
+        if (e == hipSuccess && d.host_results == 1) {
+            e = hipHostMalloc((void**)&hr, (size_t)pl->record_bytes, hipHostMallocMapped);
+            if (e == hipSuccess) memset(hr, 0, (size_t)pl->record_bytes);
+            if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&hdr, hr, 0);
+        }
+        pl->hd_rec.push_back(hdr);
         pl->ev_bin.push_back(a);
         pl->ev_done.push_back(b);
         pl->ev_host.push_back(h);
@@ -302,14 +312,12 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
         pl->ev_hook[k] = nullptr;
     }
     int32_t* offs = reinterpret_cast<int32_t*>(pl->d_rec[k]);
-    rc = ctx_compact(c, pl->d_rec[k] + pl->head_bytes, pl->cfg.armour_cap, offs, offs + pl->lim.max_frames + 1, B);
+    // host_results: the compaction kernel stores the record a second time, straight into the slot's pinned host mirror (posted
+    // writes over PCIe, only the armours there are); the slot's event -- a default event: system-scope release -- makes them visible
+    rc = ctx_compact(c, pl->d_rec[k] + pl->head_bytes, pl->cfg.armour_cap, offs, offs + pl->lim.max_frames + 1, B, pl->hd_rec[k], (int)pl->head_bytes);
     if (rc) return cfail(pl, c, rc);
-    // the context's buffers are free from here on: the next pixel kernel of this slot does not wait for the copy or the hook
+    // the context's buffers are free from here on: the next pixel kernel of this slot does not wait for the hook
     PCHK(pl, hipEventRecord(pl->ev_done[k], B), "pipeline: mark the slot");
-    if (pl->cfg.host_results == 1) {
-        PCHK(pl, hipMemcpyAsync(pl->h_rec[k], pl->d_rec[k], (size_t)pl->record_bytes, hipMemcpyDeviceToHost, B), "pipeline: record to host");
-        PCHK(pl, hipEventRecord(pl->ev_host[k], B), "pipeline: mark the host copy");
-    }
     pl->slot_ticket[k] = t + 1;
     pl->slot_frames[k] = n_frames;
     pl->next_ticket = t + 1;
@@ -360,7 +368,7 @@ int rmcv_pipeline_wait(rmcv_pipeline* pl, uint64_t ticket)
     if (k < 0) return pfail(pl, RMCV_ERR_BAD_ARG, "no such ticket in flight (never issued, or its slot has been reused)");
     hipSetDevice(pl->device);
     PCHK(pl, hipEventSynchronize(pl->ev_done[(size_t)k]), "pipeline: wait");
-    if (pl->cfg.host_results == 1 || pl->comm) PCHK(pl, hipEventSynchronize(pl->ev_host[(size_t)k]), "pipeline: wait (host copy / gather)");
+    if (pl->comm) PCHK(pl, hipEventSynchronize(pl->ev_host[(size_t)k]), "pipeline: wait (gather)");
     return RMCV_OK;
 }
 
