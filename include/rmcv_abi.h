@@ -179,6 +179,12 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * lose 1-5 % on others; the whole path moved by -0.4 % at 1280 px and +6 % at 1920 px on a box of the first kind).  A measurement
  * knob; results are identical. */
 #define RMCV_OPT_PIXEL_HALO_NT 11
+/* RMCV_OPT_OVERLOADS: which functions the reference's UNQUALIFIED abs / atan2 / sin / cos on floats are (src/objdetect.cpp:24, 79,
+ * 131-143, 153, 157; src/core.cpp:335-337) -- that depends on the headers the reference's translation units see:
+ * bit 0: abs(float) is int abs(int), the argument truncated towards zero (<cmath> alone under libstdc++); bit 1: atan2 / sin / cos
+ * are the double functions, the arithmetic around them double.  0 (default): the float overloads everywhere.  Changes results --
+ * by design: it follows the reference build it replaces.  INTEGRATION.md has the probe that tells which value a build needs. */
+#define RMCV_OPT_OVERLOADS 13
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */

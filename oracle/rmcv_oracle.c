@@ -33,6 +33,24 @@ static float m_sinf(float x) { return g_math_mode ? sinf(x) : pm_sinf(x); }
 static float m_cosf(float x) { return g_math_mode ? cosf(x) : pm_cosf(x); }
 static double m_fmod180(double x) { return g_math_mode ? fmod(x, 180.0) : pm_fmod180(x); }
 
+/* the reference calls abs / atan2 / sin / cos UNQUALIFIED on floats (src/objdetect.cpp:24,79,131-143,153,157,
+ * src/core.cpp:335-337), and which function that is depends on the headers its translation unit happens to see.  Mode bits:
+ *   bit 0  abs(float) resolves to int abs(int) (<cmath> alone under libstdc++: the argument is truncated towards zero)
+ *   bit 1  atan2 / sin / cos on floats resolve to the double functions of <math.h> (the arithmetic around them is then double too)
+ * 0 (default): the float overloads everywhere (libc++; libstdc++ once <stdlib.h> and <math.h> are in sight).
+ * INTEGRATION.md shows the three-line probe that tells a maintainer which mode their build is. */
+static int g_overloads = 0;
+void orc_set_overload_mode(int mode) { g_overloads = mode & 3; }
+int orc_get_overload_mode(void) { return g_overloads; }
+float orc_abs_ov(float x) { return (g_overloads & 1) ? (float)abs((int)x) : fabsf(x); }
+/* `atan2(y, x) * 180.0f / static_cast<float>(CV_PI)` assigned to a float (objdetect.cpp:137) */
+static float ov_atan2_deg(float y, float x)
+{
+    const float pi_f = (float)3.1415926535897932384626433832795; /* static_cast<float>(CV_PI) */
+    if (g_overloads & 2) return (float)(m_atan2((double)y, (double)x) * (double)180.0f / (double)pi_f);
+    return m_atan2f(y, x) * 180.0f / pi_f;
+}
+
 #define ORC_PI 3.1415926535897932384626433832795 /* CV_PI */
 
 void orc_default_params(orc_params* p)
@@ -1104,7 +1122,7 @@ static float point_distance(const float a[2], const float b[2])
 }
 
 static void extend_cord(const float pt1[2], const float pt2[2], float deltaLen, float dst1[2], float dst2[2])
-{ /* core.cpp:295-380; unqualified abs/atan2/sin/cos on floats = float overloads */
+{ /* core.cpp:295-380; unqualified abs/atan2/sin/cos on floats: float overloads unless orc_set_overload_mode says otherwise */
     if (pt1[0] == pt2[0]) {
         dst1[0] = pt1[0];
         dst2[0] = pt1[0];
@@ -1117,9 +1135,17 @@ static void extend_cord(const float pt1[2], const float pt2[2], float deltaLen, 
         else                 { dst1[0] = pt1[0] - deltaLen; dst2[0] = pt2[0] + deltaLen; }
     } else {
         float k = (float)(pt1[1] - pt2[1]) / (float)(pt1[0] - pt2[0]);
-        float theta = m_atan2f(fabsf(pt1[1] - pt2[1]), fabsf(pt1[0] - pt2[0]));
-        float zoomY = m_sinf(theta) * deltaLen;
-        float zoomX = m_cosf(theta) * deltaLen;
+        float ay = orc_abs_ov(pt1[1] - pt2[1]), ax = orc_abs_ov(pt1[0] - pt2[0]); /* :336 (float)abs(...) */
+        float theta, zoomY, zoomX;
+        if (g_overloads & 2) { /* the double functions: float theta = atan2(double, double); sin(theta) * deltaLen in double */
+            theta = (float)m_atan2((double)ay, (double)ax);
+            zoomY = (float)(m_sin((double)theta) * (double)deltaLen);
+            zoomX = (float)(m_cos((double)theta) * (double)deltaLen);
+        } else {
+            theta = m_atan2f(ay, ax);
+            zoomY = m_sinf(theta) * deltaLen;
+            zoomX = m_cosf(theta) * deltaLen;
+        }
         if (k > 0) {
             if (pt1[0] > pt2[0]) {
                 dst1[0] = pt1[0] + zoomX; dst1[1] = pt1[1] + zoomY;
@@ -1215,7 +1241,7 @@ int orc_filter_lightblobs(const orc_point* pts, const int32_t* offs, int n_conto
         float ratio = mx / mn; /* :71-73 */
         if (!(ratio >= ratio_lo && ratio <= ratio_hi)) negative_flag = 1;
         float angle = ell.angle > 90 ? ell.angle - 90 : ell.angle + 90; /* :78 */
-        if (fabsf(angle - 90) > tilt_max) negative_flag = 1;            /* :79 */
+        if (orc_abs_ov(angle - 90) > tilt_max) negative_flag = 1;       /* :79 */
         if (negative_flag) {
             if (neg_idx) neg_idx[nn] = c;
             nn++;
@@ -1243,22 +1269,22 @@ int orc_filter_armours(const orc_lightblob* lb, int n, float angle_diff_max, flo
         if (lb[i].target != enemy) continue;
         for (int j = i + 1; j < n; j++) {
             if (lb[j].target != enemy) continue;
-            float angle_difference = fabsf(lb[i].angle - lb[j].angle); /* :131 */
+            float angle_difference = orc_abs_ov(lb[i].angle - lb[j].angle); /* :131 */
             if (angle_difference > angle_diff_max) continue;
-            float y = fabsf(lb[i].center[1] - lb[j].center[1]);
-            float x = fabsf(lb[i].center[0] - lb[j].center[0]);
-            float rect_angle = m_atan2f(y, x) * 180.0f / (float)ORC_PI; /* :137 */
-            float shear_i = fabsf(lb[i].angle > 90 ? fabsf(lb[i].angle - rect_angle) - 90
-                                                   : fabsf(180 - lb[i].angle - rect_angle) - 90);
-            float shear_j = fabsf(lb[j].angle > 90 ? fabsf(lb[j].angle - rect_angle) - 90
-                                                   : fabsf(180 - lb[j].angle - rect_angle) - 90);
+            float y = orc_abs_ov(lb[i].center[1] - lb[j].center[1]);
+            float x = orc_abs_ov(lb[i].center[0] - lb[j].center[0]);
+            float rect_angle = ov_atan2_deg(y, x); /* :137 */
+            float shear_i = orc_abs_ov(lb[i].angle > 90 ? orc_abs_ov(lb[i].angle - rect_angle) - 90
+                                                        : orc_abs_ov(180 - lb[i].angle - rect_angle) - 90);
+            float shear_j = orc_abs_ov(lb[j].angle > 90 ? orc_abs_ov(lb[j].angle - rect_angle) - 90
+                                                        : orc_abs_ov(180 - lb[j].angle - rect_angle) - 90);
             if (shear_i > shear_max || shear_j > shear_max) continue; /* :144 */
             float height_i = lb[i].size[1], height_j = lb[j].size[1];
             float mn = height_i < height_j ? height_i : height_j, mx = height_i < height_j ? height_j : height_i;
             float ratio = mn / mx;
             if (ratio < length_ratio_max) continue; /* :149 */
-            if (fabsf(lb[i].center[1] - lb[j].center[1]) > (lb[i].size[1] + lb[j].size[1]) / 2) continue; /* :153 */
-            if (fabsf(lb[i].center[0] - lb[j].center[0]) > (lb[i].size[1] + lb[j].size[1]) * 2) continue; /* :157 */
+            if (orc_abs_ov(lb[i].center[1] - lb[j].center[1]) > (lb[i].size[1] + lb[j].size[1]) / 2) continue; /* :153 */
+            if (orc_abs_ov(lb[i].center[0] - lb[j].center[0]) > (lb[i].size[1] + lb[j].size[1]) * 2) continue; /* :157 */
             if (na < cap && out) {
                 orc_make_armour(&lb[i], &lb[j], &out[na]);
                 out[na].blob_i = i;

@@ -67,6 +67,11 @@ typedef struct {                /* literals of executable/main.cpp:172-176 are t
  * reference itself would link).  tests compare the two. */
 void orc_set_math_mode(int mode);
 int  orc_get_math_mode(void);
+/* which functions the reference's unqualified abs / atan2 / sin / cos on floats resolve to -- bit 0: abs -> int abs(int),
+ * bit 1: atan2 / sin / cos -> the double functions; 0 (default): the float overloads */
+void orc_set_overload_mode(int mode);
+int  orc_get_overload_mode(void);
+float orc_abs_ov(float x);
 
 void orc_default_params(orc_params* p);
 

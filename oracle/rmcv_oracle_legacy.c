@@ -373,7 +373,7 @@ int orc_match_lightblob(const orc_point* pts, int n, float min_ratio, float max_
     float ratio = mx / mn;                    /* :19 */
     if (ratio > max_ratio || ratio < min_ratio) return 0;
     float angle = ellipse.angle > 90 ? ellipse.angle - 90 : ellipse.angle + 90; /* :23 */
-    if (fabsf(angle - 90) > tilt_angle) return 0;
+    if (orc_abs_ov(angle - 90) > tilt_angle) return 0; /* :24, an unqualified abs on a float: SURVEY A.6 */
     *box_out = box;
     return 1;
 }

@@ -38,6 +38,7 @@ OPT_CONTOUR_TIER = 5
 OPT_HANDOVER = 6
 OPT_DENSE_DEFER = 7
 OPT_PIXEL_HALO_NT = 11
+OPT_OVERLOADS = 13
 STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE, STAGE_NO_IMAGE = 1, 2, 4, 8, 15, 16, 32, 64
 STAGE_HANDOVER = 128
 SVM_FEATURES = 1200

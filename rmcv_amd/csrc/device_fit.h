@@ -754,7 +754,22 @@ __device__ __forceinline__ float point_distance(const float a[2], const float b[
     return (float)dsqrt(dx * dx + dy * dy);
 }
 
-__device__ inline void extend_cord(const float pt1[2], const float pt2[2], float deltaLen, float dst1[2], float dst2[2])
+// the reference's unqualified abs / atan2 / sin / cos on floats -- `ov` bit 0: abs(float) resolves to int abs(int)
+// (the argument is truncated towards zero), bit 1: atan2 / sin / cos resolve to the double functions; 0: the float overloads
+// (RMCV_OPT_OVERLOADS; oracle: orc_set_overload_mode)
+__device__ __forceinline__ float abs_ov(float x, int ov)
+{
+    if (ov & 1) { const int i = (int)x; return (float)(i < 0 ? -i : i); }
+    return __builtin_fabsf(x);
+}
+// `atan2(y, x) * 180.0f / static_cast<float>(CV_PI)` assigned to a float (objdetect.cpp:137)
+__device__ __forceinline__ float atan2_deg_ov(float y, float x, int ov)
+{
+    if (ov & 2) return (float)(pm_atan2((double)y, (double)x) * (double)180.0f / (double)(float)RMCV_PI);
+    return pm_atan2f(y, x) * 180.0f / (float)RMCV_PI;
+}
+
+__device__ inline void extend_cord(const float pt1[2], const float pt2[2], float deltaLen, float dst1[2], float dst2[2], int ov)
 {
     if (pt1[0] == pt2[0]) {
         dst1[0] = pt1[0];
@@ -768,9 +783,17 @@ __device__ inline void extend_cord(const float pt1[2], const float pt2[2], float
         else                 { dst1[0] = pt1[0] - deltaLen; dst2[0] = pt2[0] + deltaLen; }
     } else {
         const float k = (float)(pt1[1] - pt2[1]) / (float)(pt1[0] - pt2[0]);
-        const float theta = pm_atan2f(__builtin_fabsf(pt1[1] - pt2[1]), __builtin_fabsf(pt1[0] - pt2[0]));
-        const float zoomY = pm_sinf(theta) * deltaLen;
-        const float zoomX = pm_cosf(theta) * deltaLen;
+        const float ay = abs_ov(pt1[1] - pt2[1], ov), ax = abs_ov(pt1[0] - pt2[0], ov); // :336 (float)abs(...)
+        float theta, zoomY, zoomX;
+        if (ov & 2) { // the double functions: float theta = atan2(double, double); sin(theta) * deltaLen in double
+            theta = (float)pm_atan2((double)ay, (double)ax);
+            zoomY = (float)(pm_sin((double)theta) * (double)deltaLen);
+            zoomX = (float)(pm_cos((double)theta) * (double)deltaLen);
+        } else {
+            theta = pm_atan2f(ay, ax);
+            zoomY = pm_sinf(theta) * deltaLen;
+            zoomX = pm_cosf(theta) * deltaLen;
+        }
         if (k > 0) {
             if (pt1[0] > pt2[0]) {
                 dst1[0] = pt1[0] + zoomX; dst1[1] = pt1[1] + zoomY;
@@ -797,7 +820,7 @@ __device__ __forceinline__ void line_center(const float a[2], const float b[2], 
     out[1] = a[1] / 2 + b[1] / 2;
 }
 
-__device__ inline void make_armour(const rmcv_lightblob* a, const rmcv_lightblob* b, rmcv_armour* out)
+__device__ inline void make_armour(const rmcv_lightblob* a, const rmcv_lightblob* b, rmcv_armour* out, int ov)
 {
     const rmcv_lightblob *L = a, *R = b;
     if (b->center[0] < a->center[0]) { L = b; R = a; }
@@ -811,8 +834,8 @@ __device__ inline void make_armour(const rmcv_lightblob* a, const rmcv_lightblob
     const float offsetL = __builtin_roundf((distanceL / 0.50f - distanceL) / 2);
     const float offsetR = __builtin_roundf((distanceR / 0.50f - distanceR) / 2);
     float ic[4][2];
-    extend_cord(v[0], v[1], offsetL, ic[0], ic[1]);
-    extend_cord(v[3], v[2], offsetR, ic[3], ic[2]);
+    extend_cord(v[0], v[1], offsetL, ic[0], ic[1], ov);
+    extend_cord(v[3], v[2], offsetR, ic[3], ic[2], ov);
     float minx = ic[0][0], maxx = minx, miny = ic[0][1], maxy = miny;
     for (int i = 0; i < 4; i++) {
         out->icon[i][0] = ic[i][0];

@@ -89,7 +89,7 @@ hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const 
     SparseTail X;
     memset(&X, 0, sizeof(X));
     X.fused = 1;
-    X.G = {p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi};
+    X.G = {p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi, g.overloads};
     X.slot_ell = b.slot_ell;
     FitTail& T = X.T;
     T.blobs = b.blobs;
@@ -108,6 +108,7 @@ hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const 
     T.angle_diff_max = p.angle_diff_max;
     T.shear_max = p.shear_max;
     T.length_ratio_max = p.length_ratio_max;
+    T.ov = g.overloads;
     if (identity && pairs) X.C = classify_args(g, b);
     return launch_contours_x(g, b, lim, X, waves, wait_seq, s);
 }

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ poin
                                             int max_contours, int max_points, float tilt_max, float ratio_lo, float ratio_hi,
                                             double area_lo, double area_hi, int32_t* __restrict__ slot_kind,
                                             rmcv_rrect* __restrict__ slot_ell, const int32_t* __restrict__ elig,
-                                            const int32_t* __restrict__ n_elig)
+                                            const int32_t* __restrict__ n_elig, int ov)
 {
     __shared__ WaveLds lds[4];
     __builtin_amdgcn_s_setprio(3); // latency-bound: issue ahead of the streaming pixel kernel of the next batch sharing the CU
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ poin
     // the work list holds the discovery indices of the contours with >= 6 points (k_contours / load_contours wrote it
     // and marked the others "skipped"), so wavefronts are only spent on contours that reach the fit
     const int ne = n_elig[f];
-    const FitGates G = {tilt_max, ratio_lo, ratio_hi, area_lo, area_hi};
+    const FitGates G = {tilt_max, ratio_lo, ratio_hi, area_lo, area_hi, ov};
     for (int e = blockIdx.y * 4 + wave; e < ne; e += 4 * gridDim.y)
         fit_contour_slot(f, elig[(int64_t)f * max_contours + e], n, pts, cs, cl, max_contours, max_points, G, slot_kind, slot_ell, L, lane);
 }
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void k_fit(const rmcv_point* __restrict__ poin
 struct MatchArgs {
     float min_ratio, max_ratio, tilt_angle, min_area, max_area;
     int fit_ellipse, mode;
+    int ov; // SURVEY A.6 (device_fit.h: abs_ov)
     int wcap, hcap, ccap; // hull table sizes of this launch (device_hull.h)
     int pass;             // 0: all contours, small tables, what does not fit is marked MATCH_DEFERRED; 1: the marked ones, full tables
     const uint8_t* frames; // may be null: no camp vote (the blob gets CAMP_NEUTRAL)
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(64) void k_match(const rmcv_point* __restrict__ poi
                     const float ratio = mx / mn; // :19
                     bool ok = !(ratio > A.max_ratio || ratio < A.min_ratio);
                     const float angle = ellipse.angle > 90 ? ellipse.angle - 90 : ellipse.angle + 90; // :23
-                    if (__builtin_fabsf(angle - 90) > A.tilt_angle) ok = false;                       // :24
+                    if (abs_ov(angle - 90, A.ov) > A.tilt_angle) ok = false;                           // :24
                     if (ok) {
                         int camp = RMCV_CAMP_NEUTRAL;
                         if (A.frames) // :43-51
@@ -150,10 +151,10 @@ __global__ __launch_bounds__(64) void k_match(const rmcv_point* __restrict__ poi
 __global__ __launch_bounds__(64) void k_armours(const rmcv_lightblob* __restrict__ blobs, const int32_t* __restrict__ n_blobs,
                                                int max_blobs, float angle_diff_max, float shear_max,
                                                float length_ratio_max, int enemy, rmcv_armour* __restrict__ armours,
-                                               int32_t* __restrict__ n_armours, int32_t* __restrict__ status, int max_armours)
+                                               int32_t* __restrict__ n_armours, int32_t* __restrict__ status, int max_armours, int ov)
 {
     armours_frame(blockIdx.x, threadIdx.x, blobs, n_blobs[blockIdx.x], max_blobs, angle_diff_max, shear_max, length_ratio_max, enemy,
-                  armours, n_armours, status, max_armours);
+                  armours, n_armours, status, max_armours, ov);
 }
 
 // the tail of filter_lightblobs (ordered compaction) and filter_armours (pair loop) of one frame in one launch:
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(64) void k_pairs(const int32_t* __restrict__ slot_k
             // L2 the pixel kernels of the other batches are streaming through: it cost the step 3 %
             __threadfence_block();
         armours_frame(f, lane, T.blobs, np, T.max_blobs, T.angle_diff_max, T.shear_max, T.length_ratio_max, T.enemy, T.armours,
-                      T.n_armours, T.status, T.max_armours);
+                      T.n_armours, T.status, T.max_armours, T.ov);
     }
 }
 
@@ -285,6 +286,7 @@ static hipError_t launch_pairs_tail(const Geom& g, const Bufs& b, const Limits& 
     T.angle_diff_max = p.angle_diff_max;
     T.shear_max = p.shear_max;
     T.length_ratio_max = p.length_ratio_max;
+    T.ov = g.overloads;
     return launch(k_pairs, dim3(g.n_frames), dim3(64), 0, s, b.slot_kind, b.slot_ell, b.n_contours, lim.max_contours, T);
 }
 
@@ -292,7 +294,7 @@ static hipError_t launch_fit(const Geom& g, const Bufs& b, const Limits& lim, co
 {
     hipError_t e = launch(k_fit, dim3(g.n_frames, FIT_CHUNKS), dim3(256), 0, s, b.points, b.cont_start, b.cont_len, b.n_contours,
                        lim.max_contours, lim.max_points, p.tilt_max, p.ratio_lo, p.ratio_hi, p.area_lo, p.area_hi, b.slot_kind,
-                       b.slot_ell, b.elig, b.n_elig);
+                       b.slot_ell, b.elig, b.n_elig, g.overloads);
     if (e != hipSuccess) return e;
     return launch_pairs_tail(g, b, lim, p, pairs, s);
 }
@@ -305,6 +307,7 @@ hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const r
     A.min_ratio = lp.min_ratio;
     A.max_ratio = lp.max_ratio;
     A.tilt_angle = lp.tilt_angle;
+    A.ov = g.overloads;
     A.min_area = lp.min_area;
     A.max_area = lp.max_area;
     A.fit_ellipse = lp.fit_ellipse;
@@ -352,7 +355,7 @@ hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim,
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s)
 {
     return launch(k_armours, dim3(g.n_frames), dim3(64), 0, s, b.blobs, b.n_blobs, lim.max_blobs, p.angle_diff_max,
-                       p.shear_max, p.length_ratio_max, p.camp, b.armours, b.n_armours, b.status, lim.max_armours);
+                       p.shear_max, p.length_ratio_max, p.camp, b.armours, b.n_armours, b.status, lim.max_armours, g.overloads);
 }
 
 } // namespace rmcv

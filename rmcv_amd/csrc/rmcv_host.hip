@@ -685,6 +685,11 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         c->geom.pixel_halo_nt = value;
         return RMCV_OK;
     }
+    if (option == RMCV_OPT_OVERLOADS && value >= 0 && value <= 3) {
+        c->geom.overloads = value;
+        resident_none(c); // (results run ahead with the other setting are not this setting's)
+        return RMCV_OK;
+    }
     if (option == RMCV_OPT_DENSE_DEFER && (value == 0 || value == 1)) {
         c->geom.dense_defer = value;
         return RMCV_OK;

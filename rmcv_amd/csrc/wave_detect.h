@@ -340,6 +340,7 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
 struct FitGates {
     float tilt_max, ratio_lo, ratio_hi;
     double area_lo, area_hi;
+    int ov; // SURVEY A.6 (device_fit.h: abs_ov)
 };
 // (start, len): the contour's place in the frame's point list -- the caller's copy, so that a workgroup that has just produced
 // them need not read them back from global memory (a dependent round trip per contour: microseconds beside streaming kernels)
@@ -383,7 +384,7 @@ __device__ inline void fit_contour_slot_at(int f, int k, int n, const rmcv_point
             const float ratio = mx / mn; // :71-73
             if (!(ratio >= G.ratio_lo && ratio <= G.ratio_hi)) negative = true;
             const float angle = ell.angle > 90 ? ell.angle - 90 : ell.angle + 90; // :78
-            if (__builtin_fabsf(angle - 90) > G.tilt_max) negative = true;        // :79
+            if (abs_ov(angle - 90, G.ov) > G.tilt_max) negative = true;           // :79
             kind = negative ? 2 : 1;
         }
     }
@@ -412,6 +413,7 @@ struct FitTail { // what k_pairs needs to finish filter_lightblobs and run filte
     int32_t* n_armours;
     int max_blobs, max_armours, enemy, do_pairs;
     float angle_diff_max, shear_max, length_ratio_max;
+    int ov; // SURVEY A.6 (device_fit.h: abs_ov)
 };
 
 // ordered compaction of the per-contour results of frame f into the reference's `positive` / `negative` lists
@@ -456,23 +458,21 @@ __device__ inline int blob_compact_frame(int f, int lane, const int32_t* slot_ki
 }
 
 __device__ __forceinline__ bool pair_ok(const rmcv_lightblob& a, const rmcv_lightblob& b, float angle_diff_max,
-                                        float shear_max, float length_ratio_max)
+                                        float shear_max, float length_ratio_max, int ov)
 {
-    const float angle_difference = __builtin_fabsf(a.angle - b.angle); // objdetect.cpp:131
+    const float angle_difference = abs_ov(a.angle - b.angle, ov); // objdetect.cpp:131
     if (angle_difference > angle_diff_max) return false;
-    const float y = __builtin_fabsf(a.center[1] - b.center[1]);
-    const float x = __builtin_fabsf(a.center[0] - b.center[0]);
-    const float rect_angle = pm_atan2f(y, x) * 180.0f / (float)RMCV_PI; // :137
-    const float shear_i = __builtin_fabsf(a.angle > 90 ? __builtin_fabsf(a.angle - rect_angle) - 90
-                                                       : __builtin_fabsf(180 - a.angle - rect_angle) - 90);
-    const float shear_j = __builtin_fabsf(b.angle > 90 ? __builtin_fabsf(b.angle - rect_angle) - 90
-                                                       : __builtin_fabsf(180 - b.angle - rect_angle) - 90);
+    const float y = abs_ov(a.center[1] - b.center[1], ov);
+    const float x = abs_ov(a.center[0] - b.center[0], ov);
+    const float rect_angle = atan2_deg_ov(y, x, ov); // :137
+    const float shear_i = abs_ov(a.angle > 90 ? abs_ov(a.angle - rect_angle, ov) - 90 : abs_ov(180 - a.angle - rect_angle, ov) - 90, ov);
+    const float shear_j = abs_ov(b.angle > 90 ? abs_ov(b.angle - rect_angle, ov) - 90 : abs_ov(180 - b.angle - rect_angle, ov) - 90, ov);
     if (shear_i > shear_max || shear_j > shear_max) return false; // :144
     const float hi = a.size[1], hj = b.size[1];
     const float mn = hi < hj ? hi : hj, mx = hi < hj ? hj : hi;
     if (mn / mx < length_ratio_max) return false;                                                     // :149
-    if (__builtin_fabsf(a.center[1] - b.center[1]) > (a.size[1] + b.size[1]) / 2) return false;       // :153
-    if (__builtin_fabsf(a.center[0] - b.center[0]) > (a.size[1] + b.size[1]) * 2) return false;       // :157
+    if (abs_ov(a.center[1] - b.center[1], ov) > (a.size[1] + b.size[1]) / 2) return false;       // :153
+    if (abs_ov(a.center[0] - b.center[0], ov) > (a.size[1] + b.size[1]) * 2) return false;       // :157
     return true;
 }
 
@@ -481,7 +481,7 @@ __device__ __forceinline__ bool pair_ok(const rmcv_lightblob& a, const rmcv_ligh
 // are tested -- and the accepted ones built -- in one round instead of one round per i.
 __device__ inline void armours_frame(int f, int lane, const rmcv_lightblob* blobs, int n, int max_blobs, float angle_diff_max,
                                      float shear_max, float length_ratio_max, int enemy, rmcv_armour* armours, int32_t* n_armours,
-                                     int32_t* status, int max_armours)
+                                     int32_t* status, int max_armours, int ov)
 {
     const rmcv_lightblob* lb = blobs + (int64_t)f * max_blobs;
     rmcv_armour* out = armours + (int64_t)f * max_armours;
@@ -498,13 +498,13 @@ __device__ inline void armours_frame(int f, int lane, const rmcv_lightblob* blob
             if (base + lane < total) {
                 a = lb[i];
                 b = lb[j];
-                ok = a.target == enemy && b.target == enemy && pair_ok(a, b, angle_diff_max, shear_max, length_ratio_max); // :124-157
+                ok = a.target == enemy && b.target == enemy && pair_ok(a, b, angle_diff_max, shear_max, length_ratio_max, ov); // :124-157
             }
             const uint64_t m = __ballot(ok);
             if (ok) {
                 const int o = na + lanes_below(m, lane);
                 if (o < max_armours) {
-                    make_armour(&a, &b, &out[o]); // :161 -> core.cpp:21-49
+                    make_armour(&a, &b, &out[o], ov); // :161 -> core.cpp:21-49
                     out[o].blob_i = i;
                     out[o].blob_j = j;
                 }

@@ -56,6 +56,11 @@ def set_math_mode(mode):
     lib().orc_set_math_mode(int(mode))
 
 
+def set_overload_mode(mode):
+    """bit 0 = the reference's unqualified abs(float) is int abs(int); bit 1 = its atan2 / sin / cos are the double functions"""
+    lib().orc_set_overload_mode(int(mode))
+
+
 def default_params(**kw):
     p = Params()
     lib().orc_default_params(C.byref(p))
