@@ -71,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--variant", type=variant_id, default=0,
                     help="synthetic stream: plain (0, the metric's), stress (1), dense1..dense4 (11..14; dense = dense4: +2000 specks and 13 "
                          "bright windows per frame, 5 %% foreground -- frames beyond findContours' LDS tables; a workload beside the metric)")
+    ap.add_argument("--one-dense", action="store_true", help="one dense4 frame in every batch of the stream (a camera frame with a lit window; a workload beside the metric)")
     ap.add_argument("--handover", action="store_true",
                     help="frame-level hand-over: every step's sparse kernel runs beside its own pixel kernel (rmcv_pipeline_config::handover)")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames per pass of the CPU-baseline sample (0 = skip)")
@@ -86,6 +87,9 @@ def parse_args(argv=None):
                          "round 3: alternating regions of ONE process put it 4.3-4.5 %% ahead of round 2's 4 over 2 on C3 and 1 %% on C5")
     ap.add_argument("--pixel-streams", type=int, default=2)
     ap.add_argument("--sparse-streams", type=int, default=4)
+    ap.add_argument("--dense-streams", type=int, default=0,
+                    help="streams for the second, 8-wavefront launch that takes a batch's frames beyond findContours' LDS tables "
+                         "(rmcv_pipeline_config::dense_streams; 0: the library's default, 2; -1: no such launch)")
     ap.add_argument("--device-results", action="store_true",
                     help="leave the armour lists in HBM (rmcv_pipeline_config::host_results = 2) instead of copying every step's to pinned host memory")
     ap.add_argument("--gather", choices=("auto", "torch", "abi"), default="auto",
@@ -204,21 +208,22 @@ def main():
 
     # At least FOUR frame sets even when fewer batches are in flight; with 8 in flight, 8 (as round 3 measured it).
     n_sets = max(ns, 4)
-    frames_k, host = frame_sets(n_sets, W, H, args.variant)
+    frames_k, host = frame_sets(n_sets, W, H, args.variant, args.one_dense)
     stages = STAGE_ALL | (STAGE_IDENTITY if args.workload == "c5" else 0) | (STAGE_POSE if args.pose else 0)
     if knobs.get("RMCV_BENCH_STAGES"):                            # dev knob: a partial path is NOT the metric
         stages = int(knobs["RMCV_BENCH_STAGES"])
     svm = synth.svm_weights() if args.workload == "c5" else None   # svm.xml is not in the reference: seeded stand-in weights
     params = default_params()                                     # main.cpp:172-176: BLUE, lb 80, close, ...
     legacy = LegacyParams(1.5, 80, 70, 10, 99999, int(os.environ.get("RMCV_LEGACY_FIT", "0"))) if args.workload == "legacy" else None
-    max_contours = 4096 if args.variant >= 10 else 2048           # (the dense streams have up to ~2100 contours per frame)
+    max_contours = 4096 if args.variant >= 10 or args.one_dense else 2048   # (the dense streams have up to ~2100 contours per frame)
 
-    def make_pipeline(depth, pix, sp, w=W, h=H, mc=max_contours, with_svm=svm, host_results=None):
+    def make_pipeline(depth, pix, sp, dense=0, w=W, h=H, mc=max_contours, with_svm=svm, host_results=None):
         # a lone batch has the CUs to itself: 8 wavefronts per frame and 3 pixel workgroups per CU; batches in flight share every CU:
         # 4 and 2 (the library's own rule, rmcv_pipeline_create; the dev knobs override it)
         pl = Pipeline(device=local_rank, depth=depth, pixel_streams=pix, sparse_streams=sp, armour_cap=n * 8,
                       sparse_waves=int(knobs.get("RMCV_SPARSE_WAVES", 0)), pixel_groups=int(knobs.get("RMCV_PIXEL_GROUPS", 0)),
                       host_results=host_results or (2 if args.device_results else 1), handover=1 if args.handover else 2,
+                      dense_streams=dense or args.dense_streams,
                       max_frames=n, max_width=w, max_height=h, max_contours=mc)
         for c in pl.contexts:
             if with_svm:
@@ -378,7 +383,7 @@ def main():
             pls[1] = make_pipeline(ns, args.pixel_streams, args.sparse_streams)
             abi_.use(lib_a)
             label, pairs_ = "this build vs %s" % f_[1], int(f_[2]) if len(f_) > 2 else 12
-        elif kind == "sched":    # "sched:<depth,pix,sparse>": the run's schedule against another shape
+        elif kind == "sched":    # "sched:<depth,pix,sparse[,dense]>": the run's schedule against another shape
             sh = [int(x) for x in f_[1].split(",")]
             pls[1] = make_pipeline(*sh)
             label, pairs_ = "sched %s vs %s" % ([ns, args.pixel_streams, args.sparse_streams], sh), int(f_[2]) if len(f_) > 2 else 12
@@ -550,14 +555,14 @@ def main():
                                                 (" [legacy blob stage: FindLightBlobs, minAreaRect boxes, camp vote]" if legacy else "") +
                                                 (" + solve_PnP (IPPE square) and world position per armour" if args.pose else ""),
                                                 " + RCCL gather of armour lists (C4)" if world > 1 else ""),
-                   "frames_per_gpu": n, "stream_variant": args.variant, "parallelism": "frame-shard x%d" % world,
+                   "frames_per_gpu": n, "stream_variant": args.variant, "one_dense_frame_per_batch": args.one_dense, "parallelism": "frame-shard x%d" % world,
                    "host_api": "rmcv_pipeline_submit (librmcv_hip.so): one call per step",
-                   "batches_in_flight": info.depth, "pixel_streams": info.pixel_streams, "sparse_streams": info.sparse_streams,
+                   "batches_in_flight": info.depth, "pixel_streams": info.pixel_streams, "sparse_streams": info.sparse_streams, "dense_streams": info.dense_streams,
                    "frame_sets": n_sets, "gpu_max_hw_queues": info.hw_queues_env, "pixel_groups_per_cu": groups_in_steps,
                    "sparse_waves_per_frame": waves_in_steps, "results_to_host_every_step": info.host_results == 1,
                    "stages": stages, "dev_knobs": knobs or None,
                    "armours_rank0_shard": n_arm_local, "armours_by_frame_set": [arm_by_set.get(k) for k in range(n_sets)], "armours_gathered": gathered,
-                   "frames_over_capacity": bad, "frames_slow_path": slow, "frames_mid_tier": mid,
+                   "frames_over_capacity": bad, "frames_slow_path": slow, "frames_mid_tier": mid, "batches_with_dense_frames_split_off": int(pl.get_info().dense_split),
                    "rccl_ranks": (dist.get_world_size() if use_dist else None), "gather": gather_note,
                    "frame_level_handover": info.handover == 1},
         "lone_batch_ms": {"median": round(lone[len(lone) // 2], 4), "min": round(lone[0], 4), "passes": len(lone),
@@ -616,7 +621,7 @@ def main():
                                        "hbm_frac": round(n * 3 * W * H / d3 / 1e9 / HBM_PEAK_GBS, 4),
                                        "note": "same armour lists; the 0/255 image is not materialised"}
 
-    if extras and args.workload == "c3" and args.variant == 0:
+    if extras and args.workload == "c3" and args.variant == 0 and not args.one_dense:
         # ---- throughput against scene density (beside the metric), the steps' own loop and schedule: the plain stream, dense levels
         # (up to +2000 specks and 13 lit windows per frame), and a plain batch with ONE dense4 frame in it (a camera frame with a lit
         # window must not stall its launch).  Four frame sets per level (consecutive steps never share input).
@@ -653,7 +658,7 @@ def main():
                                 "note": "steady-state regions of the steps' own loop (%d batches in flight over %d sparse streams, 4 frame sets per level); "
                                         "x_plain = against this sweep's own plain level; not the metric" % (info.depth, info.sparse_streams)}
 
-    if extras and args.workload == "c3" and args.variant == 0 and not args.pose:
+    if extras and args.workload == "c3" and args.variant == 0 and not args.pose and not args.one_dense:
         # ---- BASELINE config 5 in short: 256 x 1920x1200 + icon rectification + SVM, 4 batches in flight over 4 frame sets
         t_c5 = time.perf_counter()
         W5, H5 = WORKLOADS["c5"]

@@ -409,16 +409,24 @@ typedef struct {            /* 0 in any field = the default; rmcv_default_pipeli
     int32_t host_results;   /* 1: every list is copied to pinned host memory behind its compaction (collect then copies from there);
                              * 2: lists stay on the device until collected                      (1)  */
     int32_t handover;       /* 1: RMCV_OPT_HANDOVER + RMCV_STAGE_HANDOVER (frame-level hand-over); 2: off           (2)  */
+    int32_t dense_streams;  /* streams for a batch's frames beyond findContours' LDS tables (a lit window, hundreds of specks): WHILE a
+                             * few frames per batch are that dense (1 .. max_frames / 8 in the batch that last left the slot; needs
+                             * host_results = 1 and sparse_waves = 4), the per-frame launch leaves them to a second launch with 8
+                             * wavefronts per frame that runs -- with the compaction behind it -- on one of these streams: the sparse
+                             * stream goes on with the next batch instead of waiting for a 0.5-1 ms frame (one lit window per batch:
+                             * 1.3 x the plain step time without, 1.01 x with).  Batches without such frames, and batches full of them,
+                             * run as if this were off.  -1: off                                                              (4)  */
+    int32_t _pad;
 } rmcv_pipeline_config;
 typedef struct {
-    int32_t depth, pixel_streams, sparse_streams, armour_cap, sparse_waves, pixel_groups, host_results, handover;
+    int32_t depth, pixel_streams, sparse_streams, armour_cap, sparse_waves, pixel_groups, host_results, handover, dense_streams;
     int32_t max_frames;
     int32_t hw_queues_env;     /* what GPU_MAX_HW_QUEUES reads in this process (0: unset) */
-    int32_t hw_queues_wanted;  /* 1 + pixel_streams + sparse_streams (+ 1 with a communicator) */
-    int32_t _pad;
-    int64_t record_bytes;      /* a batch's record in HBM: [frame_offs: max_frames + 1 int32 | status: int32 | pad to 16 B | armours: armour_cap x 88 B] */
+    int32_t hw_queues_wanted;  /* 1 + pixel_streams + sparse_streams + dense_streams (+ 1 with a communicator) */
+    int64_t record_bytes;      /* a batch's record in HBM: [frame_offs: max_frames + 1 int32 | status: int32 | dense frames: int32 | pad to 16 B | armours: armour_cap x 88 B] */
     int64_t armours_offset;    /* = the layout of rmcv_amd/dist.py, the payload of rmcv_gather */
     uint64_t submitted, collected;
+    uint64_t dense_split;      /* batches whose dense frames were given a launch and a stream of their own (see dense_streams) */
 } rmcv_pipeline_info;
 void rmcv_default_pipeline_config(rmcv_pipeline_config* c);
 int  rmcv_pipeline_create(int device, const rmcv_limits* limits /* nullable */, const rmcv_pipeline_config* cfg /* nullable */, rmcv_pipeline** out);

@@ -59,11 +59,16 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
         // RMCV_OPT_DENSE_DEFER (off by default): the 4-wavefront launch leaves the frames beyond its LDS tables alone and the
         // 8-wavefront kernel takes them in a launch of its own right behind (1.4-1.5x faster per frame; a workgroup of any other
         // frame reads one word and ends).  Pays where every frame is dense, costs where a few are: DESIGN.md 5c.
+        // g.dense_defer: 1 = both launches here, on this stream; 2 / 3 = the first / the second launch only (rmcv_pipeline.hip puts the
+        // second on a stream of its own, so that a batch's few dense frames do not hold up the sparse stream)
         const bool defer = g.dense_defer && (force & 3) == 0 && b.mid;
-        hipError_t e = launch_contours_w4(g, b, lim, X, force | (defer ? 4 : 0), Q, grid, s);
-        if (e != hipSuccess || !defer) return e;
+        if (g.dense_defer == 3 && !defer) return hipSuccess; // (nothing was deferred: the first launch finished every frame)
+        hipError_t e = g.dense_defer == 3 ? hipSuccess : launch_contours_w4(g, b, lim, X, force | (defer ? 4 : 0), Q, grid, s);
+        if (e != hipSuccess || !defer || g.dense_defer == 2) return e;
         SparseSched Q2 = Q;
         Q2.frame_ready = nullptr; // the first launch has consumed the planes already
+        static const bool second_w4 = getenv("RMCV_DEFER_W4") && atoi(getenv("RMCV_DEFER_W4")); // dev knob: the second launch with 4 wavefronts per frame too
+        if (second_w4) return launch_contours_w4(g, b, lim, X, 2 | 8, Q2, grid, s);
         return launch(k_contours_w8, dim3(grid), dim3(512), lds_bytes(g.h), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
                        g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
                        lim.max_contours, lim.max_points, 2 | 8, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy, b.mid, b.mid_stride,

@@ -195,17 +195,18 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
     int32_t* const h_offs = reinterpret_cast<int32_t*>(host_rec);
     rmcv_armour* const h_out = reinterpret_cast<rmcv_armour*>(host_rec + host_head);
     __shared__ int s_part[256];
-    __shared__ int s_base, s_st;
+    __shared__ int s_base, s_st, s_mid;
     __shared__ int s_off[COMPACT_FRAMES], s_cnt[COMPACT_FRAMES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f_begin = blockIdx.x * COMPACT_FRAMES; // this workgroup's frames
-    if (tid == 0) { s_base = 0; s_st = 0; }
+    if (tid == 0) { s_base = 0; s_st = 0; s_mid = 0; }
     __syncthreads();
     for (int f0 = 0; f0 < n_frames; f0 += 256) {
         const int f = f0 + tid;
         const int c = f < n_frames ? n_armours[f] : 0;
         // the batch's status bits OR-ed into one word (rmcv_pipeline_collect reads it with the list instead of n_frames words)
-        if (status_or && blockIdx.x == 0 && f < n_frames) { const int st = status[f]; if (st) atomicOr(&s_st, st); }
+        // ... and the number of frames that were beyond findContours' LDS tables (the pipeline's schedule follows it)
+        if (status_or && blockIdx.x == 0 && f < n_frames) { const int st = status[f]; if (st) { atomicOr(&s_st, st); if (st & RMCV_FRAME_MID_PATH) atomicAdd(&s_mid, 1); } }
         s_part[tid] = c;
         __syncthreads();
         for (int d = 1; d < 256; d <<= 1) { // inclusive Hillis-Steele scan
@@ -227,10 +228,11 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
     }
     if (tid == 0 && blockIdx.x == 0) {
         frame_offs[n_frames] = s_base;
-        if (status_or) *status_or = s_st;
+        if (status_or) { status_or[0] = s_st; status_or[1] = s_mid; }
         if (host_rec) {
             h_offs[n_frames] = s_base;
             h_offs[status_or - frame_offs] = s_st; // (the status word's place in the record)
+            h_offs[status_or - frame_offs + 1] = s_mid;
         }
     }
     constexpr int DW = (int)(sizeof(rmcv_armour) / 4);

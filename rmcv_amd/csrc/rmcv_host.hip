@@ -312,6 +312,7 @@ void ctx_external_order(rmcv_ctx* c, hipEvent_t done)
     c->ext_done = done;
 }
 const Limits& ctx_limits(const rmcv_ctx* c) { return c->lim; }
+void ctx_defer_phase(rmcv_ctx* c, int phase) { c->geom.dense_defer = phase; }
 int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s, void* hd_record, int host_head)
 {
     HIPCHK(c, launch_compact_armours(c->geom, c->bufs, c->lim, (rmcv_armour*)d_armours_out, cap, (int32_t*)d_frame_offs, s, (int32_t*)d_status_or, (uint8_t*)hd_record, host_head), "k_compact_armours");

@@ -148,7 +148,7 @@ int binary_launches(const Geom& g, const Bufs& b); // launches launch_binary mak
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
-// d_status_or (nullable): one word = the OR of the batch's per-frame status words; hd_record (nullable, needs d_status_or): the
+// d_status_or (nullable): TWO words = the OR of the batch's per-frame status words, the number of frames with RMCV_FRAME_MID_PATH; hd_record (nullable, needs d_status_or): the
 // record [frame_offs | ... status ... | armours at host_head] once more, in mapped pinned host memory (device address)
 hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& lim, rmcv_armour* d_out, int cap,
                                   int32_t* d_frame_offs, hipStream_t s, int32_t* d_status_or = nullptr, uint8_t* hd_record = nullptr, int host_head = 0);
@@ -186,5 +186,7 @@ void ctx_external_order(rmcv_ctx* c, hipEvent_t done);
 // rmcv_batch_compact_armours + the batch's OR-ed status word
 int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s, void* hd_record = nullptr, int host_head = 0);
 const Limits& ctx_limits(const rmcv_ctx* c);
+// Geom::dense_defer for the runs that follow: 0 off, 1 both launches on the run's stream (RMCV_OPT_DENSE_DEFER), 2 / 3 the first / second only
+void ctx_defer_phase(rmcv_ctx* c, int phase);
 
 } // namespace rmcv

@@ -35,13 +35,16 @@ struct rmcv_pipeline {
     Limits lim{};
     int64_t head_bytes = 0, record_bytes = 0;
     std::vector<rmcv_ctx*> ring;
-    std::vector<hipStream_t> pix, sp;
-    std::vector<hipEvent_t> ev_bin, ev_done, ev_host;
+    std::vector<hipStream_t> pix, sp, dn; // pixel streams, sparse streams, streams of the dense frames' second launch
+    std::vector<hipEvent_t> ev_bin, ev_done, ev_host, ev_sp; // ev_sp: behind a slot's first sparse launch
     std::vector<void*> ev_hook;       // per slot: the event the hook handed back for the slot's last record (not owned), or null
     std::vector<uint8_t*> d_rec, h_rec, hd_rec; // the record in HBM, its pinned host mirror, the mirror's device address
     std::vector<uint64_t> slot_ticket; // ticket + 1 of the batch that lives in the slot (0: none yet)
     std::vector<int> slot_frames;
+    std::vector<hipStream_t> slot_stream; // the stream the slot's record was finished on
     uint64_t next_ticket = 0, collected = 0;
+    bool split_now = false;            // the batches of the moment have a FEW dense frames: give those a launch and a stream of their own
+    uint64_t split_batches = 0;        // batches submitted that way
     rmcv_pipeline_hook hook = nullptr;
     void* hook_user = nullptr;
     // built-in gather hook
@@ -88,6 +91,7 @@ void rmcv_default_pipeline_config(rmcv_pipeline_config* c)
     c->pixel_groups = 2;
     c->host_results = 1;
     c->handover = 2;
+    c->dense_streams = 4;
 }
 
 void rmcv_pipeline_destroy(rmcv_pipeline* pl)
@@ -96,16 +100,19 @@ void rmcv_pipeline_destroy(rmcv_pipeline* pl)
     hipSetDevice(pl->device);
     for (auto s : pl->pix) if (s) hipStreamSynchronize(s);
     for (auto s : pl->sp) if (s) hipStreamSynchronize(s);
+    for (auto s : pl->dn) if (s) hipStreamSynchronize(s);
     for (auto c : pl->ring) rmcv_ctx_destroy(c);
     for (auto e : pl->ev_bin) if (e) hipEventDestroy(e);
     for (auto e : pl->ev_done) if (e) hipEventDestroy(e);
     for (auto e : pl->ev_host) if (e) hipEventDestroy(e);
+    for (auto e : pl->ev_sp) if (e) hipEventDestroy(e);
     if (pl->ev_gather) hipEventDestroy(pl->ev_gather);
     for (auto p : pl->d_rec) if (p) hipFree(p);
     for (auto p : pl->d_recv) if (p) hipFree(p);
     for (auto p : pl->h_rec) if (p) hipHostFree(p);
     for (auto s : pl->pix) if (s) hipStreamDestroy(s);
     for (auto s : pl->sp) if (s) hipStreamDestroy(s);
+    for (auto s : pl->dn) if (s) hipStreamDestroy(s);
     delete pl;
 }
 
@@ -125,10 +132,13 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
         d.pixel_groups = cfg->pixel_groups > 0 ? cfg->pixel_groups : (d.depth >= 2 ? 2 : 3);
         if (cfg->host_results > 0) d.host_results = cfg->host_results;
         if (cfg->handover > 0) d.handover = cfg->handover;
+        if (cfg->dense_streams != 0) d.dense_streams = cfg->dense_streams;
     }
-    if (d.depth > 64 || d.pixel_streams > 16 || d.sparse_streams > 16 || d.host_results > 2 || d.handover > 2) return RMCV_ERR_BAD_ARG;
+    if (d.dense_streams < 0 || d.sparse_waves != 4 || d.handover == 1 || d.host_results != 1) d.dense_streams = 0; // (the deferral exists for the 4-wavefront kernel; the policy reads the host mirror)
+    if (d.depth > 64 || d.pixel_streams > 16 || d.sparse_streams > 16 || d.dense_streams > 16 || d.host_results > 2 || d.handover > 2) return RMCV_ERR_BAD_ARG;
     if (d.pixel_streams > d.depth) d.pixel_streams = d.depth;
     if (d.sparse_streams > d.depth) d.sparse_streams = d.depth;
+    if (d.dense_streams > d.depth) d.dense_streams = d.depth;
     rmcv_pipeline* pl = new (std::nothrow) rmcv_pipeline();
     if (!pl) return RMCV_ERR_NOMEM;
     pl->device = device;
@@ -150,7 +160,7 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     }
     pl->lim = ctx_limits(pl->ring[0]);
     if (pl->cfg.armour_cap <= 0) pl->cfg.armour_cap = 8 * pl->lim.max_frames;
-    pl->head_bytes = (((int64_t)pl->lim.max_frames + 2) * 4 + 15) / 16 * 16;
+    pl->head_bytes = (((int64_t)pl->lim.max_frames + 3) * 4 + 15) / 16 * 16;
     pl->record_bytes = pl->head_bytes + (int64_t)pl->cfg.armour_cap * (int64_t)sizeof(rmcv_armour);
     hipError_t e = hipSetDevice(device);
     int lo = 0, hi = 0;
@@ -171,8 +181,15 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     // device-only events ev_bin / ev_done measured the same as the default (round 4, alternating pipelines of one process against a
     // calibration pair: 1.049-1.063 against 1.051-1.061 for two identical pipelines), so nothing non-default is asked for.
     const unsigned dev_flags = hipEventDisableTiming;
+    for (int i = 0; i < d.dense_streams && e == hipSuccess; i++) { // normal priority: a dense frame is long work, not a latency chain
+        hipStream_t s = nullptr;
+        e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, 0);
+        pl->dn.push_back(s);
+    }
     for (int k = 0; k < d.depth && e == hipSuccess; k++) {
-        hipEvent_t a = nullptr, b = nullptr, h = nullptr;
+        hipEvent_t a = nullptr, b = nullptr, h = nullptr, sp_ = nullptr;
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sp_, hipEventDisableTiming);
+        pl->ev_sp.push_back(sp_);
         uint8_t *dr = nullptr, *hr = nullptr;
         e = hipEventCreateWithFlags(&a, dev_flags);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b, dev_flags); // (the host reads the record's mirror behind ev_done: it must stay a system-scope event)
@@ -194,6 +211,7 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
         pl->ev_hook.push_back(nullptr);
         pl->slot_ticket.push_back(0);
         pl->slot_frames.push_back(0);
+        pl->slot_stream.push_back(nullptr);
         if (e == hipSuccess) ctx_external_order(pl->ring[(size_t)k], b);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_gather, hipEventDisableTiming);
@@ -221,14 +239,16 @@ int rmcv_pipeline_get_info(const rmcv_pipeline* pl, rmcv_pipeline_info* o)
     o->pixel_groups = pl->cfg.pixel_groups;
     o->host_results = pl->cfg.host_results;
     o->handover = pl->cfg.handover;
+    o->dense_streams = pl->cfg.dense_streams;
     o->max_frames = pl->lim.max_frames;
     const char* q = getenv("GPU_MAX_HW_QUEUES");
     o->hw_queues_env = q ? atoi(q) : 0;
-    o->hw_queues_wanted = 1 + pl->cfg.pixel_streams + pl->cfg.sparse_streams + (pl->comm ? 1 : 0);
+    o->hw_queues_wanted = 1 + pl->cfg.pixel_streams + pl->cfg.sparse_streams + pl->cfg.dense_streams + (pl->comm ? 1 : 0);
     o->record_bytes = pl->record_bytes;
     o->armours_offset = pl->head_bytes;
     o->submitted = pl->next_ticket;
     o->collected = pl->collected;
+    o->dense_split = pl->split_batches;
     return RMCV_OK;
 }
 
@@ -300,40 +320,70 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
         PCHK(pl, hipEventRecord(pl->ev_bin[k], A), "pipeline: mark the pixel kernel");
         PCHK(pl, hipStreamWaitEvent(B, pl->ev_bin[k], 0), "pipeline: chain the sparse stages");
     }
+    // Dense frames (beyond findContours' LDS tables: hundreds of borders, 0.5-1 ms on one workgroup) are left by the per-frame launch
+    // to a second launch with 8 wavefronts per frame on a stream of its own, the compaction behind it: the sparse stream B is free
+    // for the next batch when the batch's ordinary frames are through (one lit window per batch used to cost the whole loop 20-35 %).
+    // When: while the batch that last left this slot had SOME such frames but not many (its count sits in the record's host mirror:
+    // a camera's lit window stays for many batches).  A batch without any pays nothing (the second launch costs the plain stream
+    // 1-3 %: 256 workgroups of 8 wavefronts and 80 KB of LDS to be placed just to find their frame is not marked); a batch full of
+    // them is better off with every frame finished where it is (measured: 0.312 against 0.360 ms per step at 233 dense frames of 256).
+    if (used && !pl->dn.empty() && hipEventQuery(pl->ev_done[k]) == hipSuccess) {
+        const int32_t dense = reinterpret_cast<const int32_t*>(pl->h_rec[k])[pl->lim.max_frames + 2];
+        pl->split_now = dense > 0 && dense * 8 <= pl->slot_frames[k];
+    }
+    (void)hipGetLastError(); // (hipErrorNotReady is not an error)
+    const bool split = pl->split_now && !pl->dn.empty() && !lp && (sparse & RMCV_STAGE_CONTOURS) && (sparse & RMCV_STAGE_BLOBS);
+    if (split) pl->split_batches++;
+    hipStream_t T = split ? pl->dn[k % pl->dn.size()] : B; // the stream the batch's list is finished on
+    // (a record's rewrite is ordered behind its readers by stream order: the slot meets the same stream every time -- unless the
+    // caller mixes stage masks that finish on different streams; then the old stream is drained first)
+    if (used && pl->slot_stream[k] && pl->slot_stream[k] != T) PCHK(pl, hipStreamSynchronize(pl->slot_stream[k]), "pipeline: change of the slot's stream");
     if (sparse) {
         // frame-level hand-over: the sparse kernel is enqueued BESIDE its own pixel kernel and takes each frame when its last strip is
         // written (the context orders it behind what preceded that pixel kernel)
-        rc = lp ? rmcv_batch_run_legacy(c, p, lp, sparse | (ho ? RMCV_STAGE_HANDOVER : 0), B) : rmcv_batch_run(c, p, sparse | (ho ? RMCV_STAGE_HANDOVER : 0), B);
+        if (split) {
+            ctx_defer_phase(c, 2); // the first launch only: frames beyond the LDS tables are marked and left alone
+            rc = rmcv_batch_run(c, p, sparse & ~RMCV_STAGE_POSE, B);
+            if (rc == RMCV_OK) {
+                PCHK(pl, hipEventRecord(pl->ev_sp[k], B), "pipeline: mark the first sparse launch");
+                PCHK(pl, hipStreamWaitEvent(T, pl->ev_sp[k], 0), "pipeline: chain the dense frames");
+                ctx_defer_phase(c, 3); // the second launch only (+ the pose stage, which needs every frame's armours)
+                rc = rmcv_batch_run(c, p, sparse, T);
+            }
+            ctx_defer_phase(c, 0);
+        } else
+            rc = lp ? rmcv_batch_run_legacy(c, p, lp, sparse | (ho ? RMCV_STAGE_HANDOVER : 0), B) : rmcv_batch_run(c, p, sparse | (ho ? RMCV_STAGE_HANDOVER : 0), B);
         if (rc) return cfail(pl, c, rc);
     }
     // the record is rewritten: a reader on another stream (the hook's) must be through; readers on B are by stream order
     if (pl->ev_hook[k]) {
-        PCHK(pl, hipStreamWaitEvent(B, (hipEvent_t)pl->ev_hook[k], 0), "pipeline: wait for the record's reader");
+        PCHK(pl, hipStreamWaitEvent(T, (hipEvent_t)pl->ev_hook[k], 0), "pipeline: wait for the record's reader");
         pl->ev_hook[k] = nullptr;
     }
     int32_t* offs = reinterpret_cast<int32_t*>(pl->d_rec[k]);
     // host_results: the compaction kernel stores the record a second time, straight into the slot's pinned host mirror (posted
     // writes over PCIe, only the armours there are); the slot's event -- a default event: system-scope release -- makes them visible
-    rc = ctx_compact(c, pl->d_rec[k] + pl->head_bytes, pl->cfg.armour_cap, offs, offs + pl->lim.max_frames + 1, B, pl->hd_rec[k], (int)pl->head_bytes);
+    rc = ctx_compact(c, pl->d_rec[k] + pl->head_bytes, pl->cfg.armour_cap, offs, offs + pl->lim.max_frames + 1, T, pl->hd_rec[k], (int)pl->head_bytes);
     if (rc) return cfail(pl, c, rc);
     // the context's buffers are free from here on: the next pixel kernel of this slot does not wait for the hook
-    PCHK(pl, hipEventRecord(pl->ev_done[k], B), "pipeline: mark the slot");
+    PCHK(pl, hipEventRecord(pl->ev_done[k], T), "pipeline: mark the slot");
     pl->slot_ticket[k] = t + 1;
     pl->slot_frames[k] = n_frames;
+    pl->slot_stream[k] = T;
     pl->next_ticket = t + 1;
     if (ticket) *ticket = t;
     if (pl->comm) {
         // one communicator: its operations must execute in one order on every rank; they are issued in ticket order on alternating
         // streams, so each gather first waits (an event, on the GPU) for the one before
-        if (pl->gather_pending) PCHK(pl, hipStreamWaitEvent(B, pl->ev_gather, 0), "pipeline: order the gathers");
-        rc = rmcv_gather(pl->comm, pl->d_rec[k], pl->record_bytes, pl->rank == pl->root ? pl->d_recv[k] : nullptr, pl->root, B);
+        if (pl->gather_pending) PCHK(pl, hipStreamWaitEvent(T, pl->ev_gather, 0), "pipeline: order the gathers");
+        rc = rmcv_gather(pl->comm, pl->d_rec[k], pl->record_bytes, pl->rank == pl->root ? pl->d_recv[k] : nullptr, pl->root, T);
         if (rc) return pfail(pl, rc, rmcv_comm_last_error(pl->comm));
-        PCHK(pl, hipEventRecord(pl->ev_gather, B), "pipeline: mark the gather");
+        PCHK(pl, hipEventRecord(pl->ev_gather, T), "pipeline: mark the gather");
         pl->gather_pending = true;
-        PCHK(pl, hipEventRecord(pl->ev_host[k], B), "pipeline: mark the gather"); // wait / collect cover the gather too
+        PCHK(pl, hipEventRecord(pl->ev_host[k], T), "pipeline: mark the gather"); // wait / collect cover the gather too
     } else if (pl->hook) {
         void* done = nullptr;
-        rc = pl->hook(pl->hook_user, t, pl->d_rec[k], pl->record_bytes, B, &done);
+        rc = pl->hook(pl->hook_user, t, pl->d_rec[k], pl->record_bytes, T, &done);
         if (rc) return pfail(pl, rc, "the pipeline hook failed");
         pl->ev_hook[k] = done;
     }
@@ -409,6 +459,7 @@ int rmcv_pipeline_drain(rmcv_pipeline* pl)
     hipSetDevice(pl->device);
     for (auto s : pl->pix) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
     for (auto s : pl->sp) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
+    for (auto s : pl->dn) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
     for (size_t k = 0; k < pl->ev_hook.size(); k++)
         if (pl->ev_hook[k]) {
             PCHK(pl, hipEventSynchronize((hipEvent_t)pl->ev_hook[k]), "pipeline: drain (hook)");
@@ -423,7 +474,7 @@ int rmcv_pipeline_record(rmcv_pipeline* pl, uint64_t ticket, void** d_record, vo
     const int k = slot_of(pl, ticket);
     if (k < 0) return pfail(pl, RMCV_ERR_BAD_ARG, "no such ticket in flight (never issued, or its slot has been reused)");
     if (d_record) *d_record = pl->d_rec[(size_t)k];
-    if (hip_stream) *hip_stream = pl->sp[(size_t)k % (size_t)pl->cfg.sparse_streams];
+    if (hip_stream) *hip_stream = pl->slot_stream[(size_t)k];
     return RMCV_OK;
 }
 

@@ -30,10 +30,10 @@ def shard(n_total, rank, world):
 
 
 def record_layout(n_local, cap):
-    """(offset of armours, total bytes) of a rank's record: [frame_offs: n_local + 1 int32 | status: int32 | pad to 16 B | armours]
-    -- the record rmcv_pipeline_* keeps per batch (include/rmcv_abi.h: rmcv_pipeline_info), whose status word is the OR of the
-    batch's per-frame status bits"""
-    head = ((n_local + 2) * 4 + 15) // 16 * 16
+    """(offset of armours, total bytes) of a rank's record: [frame_offs: n_local + 1 int32 | status: int32 | dense frames: int32 |
+    pad to 16 B | armours] -- the record rmcv_pipeline_* keeps per batch (include/rmcv_abi.h: rmcv_pipeline_info): the status word
+    is the OR of the batch's per-frame status bits, the next one counts its frames beyond findContours' LDS tables"""
+    head = ((n_local + 3) * 4 + 15) // 16 * 16
     return head, head + cap * ARMOUR_BYTES
 
 

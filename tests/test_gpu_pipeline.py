@@ -32,16 +32,18 @@ def check_batch(oracle, frames, arm, offs):
     assert offs[-1] == sum(len(r) for r in refs)
 
 
-@pytest.mark.parametrize("one_dense", [False, True], ids=["plain", "one_dense_frame_per_batch"])
-def test_24_distinct_batches_through_a_depth_8_pipeline(oracle, one_dense):
+@pytest.mark.parametrize("one_dense,dense_streams", [(False, 0), (True, 0), (True, -1), (True, 1)],
+                         ids=["plain", "one_dense_frame_per_batch", "one_dense_no_second_launch", "one_dense_one_dense_stream"])
+def test_24_distinct_batches_through_a_depth_8_pipeline(oracle, one_dense, dense_streams):
     """24 distinct 256-frame batches (1280x1024), eight in flight: the list of every batch equals the oracle's, in submission order.
     With one frame per batch beyond findContours' LDS tables (a lit window + 2000 specks: the mid tier), which finishes long after
     its batch's other frames."""
     import torch
     dev = torch.device("cuda", 0)
     n, w, h, nb = 256, 1280, 1024, 24
-    pl = Pipeline(device=0, depth=8, max_frames=n, max_width=w, max_height=h, max_contours=4096)
+    pl = Pipeline(device=0, depth=8, dense_streams=dense_streams, max_frames=n, max_width=w, max_height=h, max_contours=4096)
     assert (pl.info.depth, pl.info.pixel_streams, pl.info.sparse_streams, pl.info.sparse_waves, pl.info.pixel_groups) == (8, 2, 4, 4, 2)
+    assert pl.info.dense_streams == {0: 4, -1: 0, 1: 1}[dense_streams]
     p = default_params()
     host, devf, got = [], [], {}
     for i in range(nb):
@@ -71,6 +73,10 @@ def test_24_distinct_batches_through_a_depth_8_pipeline(oracle, one_dense):
         st = pl.context_of(nb - 1).counts()["status"]
         assert np.count_nonzero(st & abi.FRAME_MID_PATH) == 1 and not (st & 15).any()
     assert pl.get_info().submitted == nb
+    # the dense frames get their own launch and stream from the second ring cycle on (the first cycle has nothing to go by), and only
+    # where there are some
+    split = pl.get_info().dense_split
+    assert (split >= nb - 2 * 8) if (one_dense and dense_streams >= 0) else split == 0
     pl.close()
 
 
