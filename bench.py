@@ -97,6 +97,10 @@ def parse_args(argv=None):
                          "default for more than one rank: rmcv_gather's multi-rank path has not run on hardware yet -- no multi-GPU box "
                          "was available to this build) or rmcv_gather, the C-ABI entry point that calls RCCL itself (what a C++ host "
                          "uses: rmcv_pipeline_set_gather; the default for a launched single rank, where it moves nothing)")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the roofline kernel: warm-up, then 3 x 20 cold launches of k_binary (3 workgroups per CU, contexts and frame sets "
+                         "in turn) between HIP events -- the command tools/profile_round4.sh runs under rocprofv3, so that the trace's average "
+                         "duration of k_binary is ONE kind of launch (the full command mixes cold, warm, overlapping and 2-per-CU launches)")
     ap.add_argument("--dev", action="store_true", help="accept the environment knobs that change the timed region (%s)" % ", ".join(DEV_KNOBS))
     return ap.parse_args(argv)
 
@@ -261,6 +265,31 @@ def main():
     if use_dist and abi_gather is None:
         hook = rdist.TorchGatherHook(info.record_bytes, ns, dev)
         pl.set_hook(hook)
+
+    if args.roofline_only:
+        ctxs = pl.contexts
+        for k, c in enumerate(ctxs):
+            c.bind_device_frames(frames_k[k % n_sets].data_ptr(), n, H, W)
+            c.set_option(OPT_PIXEL_GROUPS, 3)
+        stream = torch.cuda.Stream(device=dev)
+        sh, R, each = stream.cuda_stream, 20, []
+        for rep in range(4):                                         # the first repeat is the warm-up (clocks, code objects)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                e0.record(stream)
+                for i in range(R):
+                    ctxs[(rep * R + i) % len(ctxs)].run(params, STAGE_BINARY, sh)
+                e1.record(stream)
+            torch.cuda.synchronize()
+            each.append(e0.elapsed_time(e1) / R)
+        ms = sorted(each[1:])[1]
+        print(json.dumps({"roofline_only": True, "kernel": "k_binary", "workgroups_per_cu": 3, "launches": 4 * R, "avg_launch_ms_each_repeat": [round(x, 4) for x in each],
+                          "avg_launch_ms": round(ms, 4), "achieved_GBps": round(n * BYTES_PER_FRAME / (ms * 1e-3) / 1e9, 1),
+                          "frac": round(n * BYTES_PER_FRAME / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME,
+                          "note": "cold: every launch on another context's frames and buffers, one stream, HIP events around each 20 launches"}), flush=True)
+        pl.close()
+        return
 
     cur = {"pl": pl, "stages": stages, "sets": frames_k, "w": W, "h": H}
     step_no = [0]
