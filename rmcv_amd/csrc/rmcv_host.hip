@@ -372,7 +372,7 @@ static int ensure_staging(rmcv_ctx* c)
 static int ensure_mid(rmcv_ctx* c, int n_frames)
 {
     if (n_frames <= c->mid_frames || c->mid_failed) return RMCV_OK;
-    static const bool no_mid = getenv("RMCV_NO_MID") && atoi(getenv("RMCV_NO_MID")); // test knob: behave as if the allocation had failed
+    const bool no_mid = getenv("RMCV_NO_MID") && atoi(getenv("RMCV_NO_MID")); // test knob: behave as if the allocation had failed (read at every binding)
     if (c->bufs.mid) { // grow: nothing of this context may still be running on the old block
         const int rcs = rmcv_batch_sync(c);
         if (rcs) return rcs;

@@ -156,3 +156,28 @@ def test_mid_tier_fuzz_random_scenes(oracle):
         mid += st == FRAME_MID_PATH
     assert mid > 280                                          # (a few scenes nest deeper than the fixed point's 32 rounds: literal)
     c.close()
+
+
+def test_without_the_mid_tiers_scratch_dense_frames_take_the_scanner(oracle, monkeypatch):
+    """the mid tier's scratch block (4.5-5.7 MB per frame slot) is allocated when frames are bound, and if it cannot be had the tier
+    is simply absent: frames beyond the LDS tables go to the sequential scanner -- same lists, RMCV_FRAME_SLOW_PATH instead of
+    RMCV_FRAME_MID_PATH (context creation used to fail instead)"""
+    n, w, h = 6, 1280, 1024
+    fr = synth.batch(3300, n, w, h, CAMP_BLUE, 0, threads=8)
+    fr[2] = synth.frame(3302, w, h, CAMP_BLUE, 14)
+    refs = [oracle.detect_frame(f) for f in fr]
+    for no_mid, bit in ((False, FRAME_MID_PATH), (True, FRAME_SLOW_PATH)):
+        if no_mid:
+            monkeypatch.setenv("RMCV_NO_MID", "1")
+        c = Context(device=0, max_frames=n, max_width=w, max_height=h, max_contours=4096)
+        c.upload(fr)
+        c.run(default_params(), STAGE_ALL)
+        c.sync()
+        st = c.counts()["status"]
+        assert st[2] & bit and not (st & 15).any() and np.count_nonzero(st & (FRAME_MID_PATH | FRAME_SLOW_PATH)) == 1, (no_mid, st)
+        arm, offs = c.armours()
+        for f in range(n):
+            pts, co = c.contours(f)
+            assert np.array_equal(co, refs[f]["offs"]) and np.array_equal(pts, refs[f]["pts"]), (no_mid, f)
+            assert arm[offs[f]:offs[f + 1]].tobytes() == refs[f]["armours"].tobytes(), (no_mid, f)
+        c.close()

@@ -102,3 +102,52 @@ def test_handover_flag_needs_its_pixel_kernel():
     c.sync()
     assert not c.counts()["status"].any()
     c.close()
+
+
+@pytest.mark.parametrize("w,h,n", [(1920, 1200, 3), (1280, 720, 5), (1280, 1000, 4), (1280, 720, 1)])
+def test_handover_small_batches_whose_last_strip_is_partial(oracle, w, h, n):
+    """a launch with fewer strips than half the CUs hands every strip out as four 8-row pieces; with h % 32 in
+    1..23 a piece of the last strip lies below the image and used to SUBTRACT rows from the frame's progress word -- the per-frame
+    kernel then waited for a count that never came (RMCV_FRAME_TIMEOUT after 2 s).  Forked (one stream) and explicit form."""
+    import torch
+    fr = synth.batch(52000 + h, n, w, h, CAMP_BLUE, 1, threads=16)
+    refs = [oracle.detect_frame(f) for f in fr]
+    c = Context(device=0, max_frames=8, max_width=w, max_height=h)
+    c.set_option(OPT_HANDOVER, 1)
+    c.upload(fr)
+    for explicit in (False, True, False):
+        if explicit:
+            sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+            c.run(default_params(), STAGE_BINARY, sa.cuda_stream)
+            c.run(default_params(), (STAGE_ALL & ~STAGE_BINARY) | STAGE_HANDOVER, sb.cuda_stream)
+        else:
+            c.run(default_params(), STAGE_ALL)
+        c.sync()
+        torch.cuda.synchronize()
+        assert not c.counts()["status"].any()
+        arm, offs = c.armours()
+        for f in range(n):
+            assert np.array_equal(c.binary(f), refs[f]["binary"]), (explicit, f)
+            assert arm[offs[f]:offs[f + 1]].tobytes() == refs[f]["armours"].tobytes(), (explicit, f)
+    c.close()
+
+
+def test_handover_after_a_pixel_kernel_that_did_not_publish(oracle):
+    """rmcv_extract_color launches the pixel kernel WITHOUT progress words; a RMCV_STAGE_HANDOVER run behind it must
+    not wait for a label nothing writes (it used to block its stream for good) -- it is refused: there is no batch pixel kernel to follow"""
+    w, h = 1280, 1024
+    fr = synth.batch(63000, 1, w, h, CAMP_BLUE, 0, threads=4)
+    c = Context(device=0, max_frames=1, max_width=w, max_height=h)
+    c.set_option(OPT_HANDOVER, 1)
+    c.upload(fr)
+    c.run(default_params(), STAGE_BINARY)
+    c.sync()
+    c.extract_color_csr(fr[0])
+    with pytest.raises(RmcvError):
+        c.run(default_params(), (STAGE_ALL & ~STAGE_BINARY) | STAGE_HANDOVER)
+    c.upload(fr)
+    c.run(default_params(), STAGE_ALL)                     # and the context goes on working
+    c.sync()
+    arm, offs = c.armours()
+    assert arm.tobytes() == oracle.detect_frame(fr[0])["armours"].tobytes()
+    c.close()

@@ -233,3 +233,67 @@ def test_c_host_drives_the_same_pipeline(oracle):
     per_set = [sum(len(a) for a in oracle_lists(oracle, synth.batch(k * 1000003, n, 1280, 1024, CAMP_BLUE, 0, threads=16))) for k in range(sets)]
     assert out["armours_set0"] == per_set[0]
     assert out["armours_last_%d_batches" % depth] == sum(per_set)               # the last four steps cover every set once (sets == depth)
+
+
+def test_pipeline_gathers_single_rank(oracle):
+    """BASELINE config 4's plumbing on one GPU: the built-in hook (rmcv_pipeline_set_gather: rmcv_gather on an rmcv_comm, here a group
+    of one) and the torch.distributed hook (rmcv_amd.dist.TorchGatherHook on a one-rank nccl group) both deliver every batch's record,
+    ticket by ticket, while the ring keeps running"""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+    from rmcv_amd import dist as rdist
+    dev = torch.device("cuda", 0)
+    n, w, h, depth, nb = 24, 1280, 1024, 3, 9
+    sets = [synth.batch(120000 + 300 * i, n, w, h, CAMP_BLUE, i % 2, threads=16) for i in range(nb)]
+    dsets = [torch.from_numpy(s).to(dev) for s in sets]
+    refs = [oracle_lists(oracle, s) for s in sets]
+
+    def check(i, recs, cap):
+        arm, offs = rdist.unpack_records(recs, n, cap)
+        assert offs.tolist() == np.cumsum([0] + [len(r) for r in refs[i]]).tolist(), i
+        assert arm.tobytes() == np.concatenate(refs[i]).tobytes(), i
+    # ---- rmcv_gather through rmcv_pipeline_set_gather
+    L = abi.lib()
+    idb = (C.c_uint8 * abi.COMM_ID_BYTES)()
+    assert L.rmcv_comm_unique_id(idb) == 0
+    hc = C.c_void_p()
+    assert L.rmcv_comm_create(idb, 1, 0, 0, C.byref(hc)) == 0
+    pl = Pipeline(device=0, depth=depth, max_frames=n, max_width=w, max_height=h)
+    pl.set_gather(hc, 0)
+    assert pl.get_info().hw_queues_wanted == 1 + 2 + 3 + min(4, depth) + 1
+    for i in range(nb):
+        t = pl.submit(dsets[i].data_ptr(), n, h, w, default_params(), STAGE_ALL)
+        if i >= depth - 1:
+            j = i - (depth - 1)
+            pl.wait(j)
+            d, nbytes = pl.gathered(j)
+            assert nbytes == pl.info.record_bytes
+            check(j, [rdist.tensor_at(d, nbytes, dev)], pl.info.armour_cap)
+    pl.close()
+    L.rmcv_comm_destroy.restype = None
+    L.rmcv_comm_destroy.argtypes = [C.c_void_p]
+    L.rmcv_comm_destroy(hc)
+    # ---- torch.distributed through the hook
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        pl = Pipeline(device=0, depth=depth, max_frames=n, max_width=w, max_height=h)
+        hook = rdist.TorchGatherHook(pl.info.record_bytes, depth, dev)
+        pl.set_hook(hook)
+        for i in range(nb):
+            pl.submit(dsets[i].data_ptr(), n, h, w, default_params(), STAGE_ALL)
+            if i >= depth - 1:
+                j = i - (depth - 1)
+                hook.wait(j)
+                check(j, hook.records(j), pl.info.armour_cap)
+        pl.drain()
+        hook.wait_all()
+        pl.set_hook(None)
+        pl.close()
+    finally:
+        dist.destroy_process_group()
