@@ -105,7 +105,7 @@ static constexpr int RSRC3 = 0x00020000;     // raw buffer descriptor word 3, gf
 // Register budget: 6 waves per SIMD = at most 80 VGPRs.  Two launches of consecutive batches overlap (2 workgroups per CU each = 4
 // waves per SIMD) next to one wave of the 4-wavefront sparse kernel (168 VGPRs): 4 x 80 + 168 <= 512.  At 88 the sparse kernel
 // would no longer fit beside them and the batches in flight would take turns instead of sharing the CUs.
-template <int CA, int CB, bool FAST, bool PUB>
+template <int CA, int CB, int FAST /* 0: byte-wise loader, 1: row-quad items, 2: linear items (rows contiguous in memory) */, bool PUB>
 #ifndef RMCV_K1_MINBLOCKS
 #define RMCV_K1_MINBLOCKS 6
 #endif
@@ -249,6 +249,75 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
                 q += q_step;
                 rq += r_step;
                 if (q >= wq) { q -= wq; rq++; }
+            }
+        } else if (FAST == 2) {
+            // LINEAR items (stride == 3 w: the strip's rows are ONE contiguous run in memory, as they are in the LDS plane since w % 64
+            // == 0): the strip is a sequence of 256-pixel blocks -- block j = pixels [256 j, 256 j + 256) of that run = 768 contiguous
+            // bytes = words [4 j, 4 j + 4) of T -- and an item is FOUR CONSECUTIVE blocks: the wave's four loads of an item read 3 KB
+            // in one piece (row-quad items: four 768-byte pieces a row apart), and a row whose width is no multiple of 256 (1920 =
+            // 7.5 blocks) wastes nothing: 270 blocks = 68 items per strip instead of 9 x 8 = 72 with every eighth half empty.
+            // Lane i loads pixels 4 i .. 4 i + 3 of each block; after the quad transpose lane l of a quad holds 16 pixels of block l.
+            const uint32_t px_total = (uint32_t)__umul24(srh, w);      // a multiple of 64; of 256 for the common sizes, not always of 1024
+            const int n_blk = (int)((px_total + 255u) >> 8);
+            const int n_itl = (n_blk + 3) >> 2;
+            const uint32_t px_lo = (uint32_t)__umul24(rr_lo, w), px_span = (uint32_t)__umul24(rr_hi - rr_lo, w); // the run's pixels inside the image
+            const uint32_t q_lo = (uint32_t)(4 * w), q_hi = (uint32_t)__umul24(srh - 4, w); // pixels of the first / last four rows: shared with the neighbours
+            const bool whole = rr_lo == 0 && rr_hi == srh;             // every row of the strip is inside the image
+            uint16_t* const T16 = reinterpret_cast<uint16_t*>(T);
+            const uint32_t lds_l = (uint32_t)(lane & 3) * 16u + (uint32_t)(lane >> 2); // halfword of this lane's 16 pixels inside an item's 64 halfwords
+            for (int it0 = wv; it0 < n_itl; it0 += 4 * U) {
+                auto batch = [&](auto chk) {
+                    constexpr bool CHK = decltype(chk)::value;
+                    u32x3v v[U][4];
+                    int itv[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int it_ = it0 + 4 * u;
+                        const int it = (L & 1) ? it_ : n_itl - 1 - it_; // sweep direction: neighbouring strips meet at their shared rows
+                        itv[u] = (CHK && it_ >= n_itl) ? -1 : it;
+                        const uint32_t blk0 = (uint32_t)it * 4u;
+#ifdef RMCV_K1_NOLOAD
+                        const uint32_t base = OOB_S - 2304u;
+#else
+                        const uint32_t base = strip_base + blk0 * 768u;
+#endif
+                        uint32_t vo[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            vo[k] = base + (uint32_t)k * 768u + lane_off;
+                            if (CHK) { // this lane's four pixels of block k: inside the strip's blocks and inside the image?
+                                const uint32_t pix = (blk0 + (uint32_t)k) * 256u + (uint32_t)lane * 4u;
+                                if (it_ >= n_itl || (int)(blk0 + k) >= n_blk || pix - px_lo >= px_span) vo[k] = OOB_S + lane_off;
+                            }
+                        }
+                        const uint32_t p0 = blk0 * 256u;
+                        if (halo && !halo_nt && (p0 < q_lo || p0 + 1024u > q_hi)) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b96(r_in, vo[k], 0, RMCV_K1_HALOAUX);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b96(r_in, vo[k], 0, RMCV_K1_LDAUX);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t d[12] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][1].x, v[u][1].y, v[u][1].z,
+                                                v[u][2].x, v[u][2].y, v[u][2].z, v[u][3].x, v[u][3].y, v[u][3].z};
+                        const uint32_t m = thresh16<CA, CB>(d, lb);
+                        const uint32_t p1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xF, 0xF, true);
+                        const uint32_t t1 = (m & M1) | (((p1 << 8) >> S1) & ~M1);
+                        const uint32_t p2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)t1, 0x4E, 0xF, 0xF, true);
+                        const uint32_t t2 = __builtin_amdgcn_perm(p2, t1, P2);
+                        uint16_t* dst = T16 + (uint32_t)itv[u] * 64u + lds_l;
+                        // an item beyond the strip's, or 16 pixels beyond the strip's last (the ragged end of its last item)
+                        if (CHK && (itv[u] < 0 || (uint32_t)itv[u] * 1024u + (uint32_t)(lane & 3) * 256u + (uint32_t)(lane >> 2) * 16u >= px_total)) dst = s_spare + tid;
+                        *dst = (uint16_t)t2;
+                    }
+                };
+                // unchecked: every row inside the image, a full batch, and not the strip's last item if that one is ragged
+                const bool has_last = (L & 1) ? (it0 + 4 * (U - 1) >= n_itl - 1) : (it0 == 0);
+                if (whole && it0 + 4 * (U - 1) < n_itl && ((px_total & 1023u) == 0 || !has_last)) batch(std::false_type{});
+                else batch(std::true_type{});
             }
         } else
         for (int it0 = wv; it0 < n_it; it0 += 4 * U) {
@@ -514,6 +583,9 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     const int64_t per_frame = std::max<int64_t>(std::max<int64_t>(g.frame_pitch, g.plane_pitch * 8), (int64_t)g.w * g.h);
     const int chunk = aligned ? (int)std::min<int64_t>(g.n_frames, std::max<int64_t>(1, (lim - 1) / per_frame)) : g.n_frames;
     const bool fast = aligned && (int64_t)chunk * per_frame < lim;
+    // rows contiguous in memory: the linear loader (Geom::pixel_rowquad, from RMCV_K1_LINEAR=0 when the context is made: the row-quad
+    // loader everywhere -- a dev knob for A/B runs)
+    const bool linear = fast && !g.pixel_rowquad && g.stride == 3 * g.w;
     // persistent grid: `groups` workgroups per CU (RMCV_OPT_PIXEL_GROUPS; RMCV_K1_BPC overrides for A/B runs): alone the kernel is
     // equally fast with 2 and 3 and slower with 4 and more; 2 leaves room on every CU for the kernels of the other batches in flight
     static const int bpc_env = getenv("RMCV_K1_BPC") ? atoi(getenv("RMCV_K1_BPC")) : 0;
@@ -539,11 +611,13 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
         uint32_t* rowmask = b.rowmask + (int64_t)f0 * g.h;
         // beyond 64 KiB of dynamic LDS (frames wider than ~6700 pixels) the kernel has to be told; per device and instantiation
         const bool pub = publish && b.frame_ready != nullptr; // (the caller decides: rmcv_host.hip run_stages)
-        static size_t lds_set[MAX_DEVICES][4] = {};
-        const int inst = (fast ? 1 : 0) | (pub ? 2 : 0);
+        static size_t lds_set[MAX_DEVICES][6] = {};
+        const int mode = fast ? (linear ? 2 : 1) : 0;
+        const int inst = mode * 2 + (pub ? 1 : 0);
         if (planes > 60 * 1024 && planes > lds_set[g.device][inst]) {
-            const void* fn = fast ? (pub ? reinterpret_cast<const void*>(k_binary<CA, CB, true, true>) : reinterpret_cast<const void*>(k_binary<CA, CB, true, false>))
-                                  : (pub ? reinterpret_cast<const void*>(k_binary<CA, CB, false, true>) : reinterpret_cast<const void*>(k_binary<CA, CB, false, false>));
+            const void* fn = mode == 2 ? (pub ? reinterpret_cast<const void*>(k_binary<CA, CB, 2, true>) : reinterpret_cast<const void*>(k_binary<CA, CB, 2, false>))
+                           : mode == 1 ? (pub ? reinterpret_cast<const void*>(k_binary<CA, CB, 1, true>) : reinterpret_cast<const void*>(k_binary<CA, CB, 1, false>))
+                                       : (pub ? reinterpret_cast<const void*>(k_binary<CA, CB, 0, true>) : reinterpret_cast<const void*>(k_binary<CA, CB, 0, false>));
             const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes);
             if (ea != hipSuccess) return ea;
             lds_set[g.device][inst] = planes;
@@ -552,8 +626,9 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     launch(k_binary<CA, CB, F, P>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
            morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail,               \
            pub ? b.frame_ready + f0 : nullptr, seq, pub ? b.started : nullptr, g.pixel_halo_nt)
-        const hipError_t e = fast ? (pub ? RMCV_K1_LAUNCH(true, true) : RMCV_K1_LAUNCH(true, false))
-                                  : (pub ? RMCV_K1_LAUNCH(false, true) : RMCV_K1_LAUNCH(false, false));
+        const hipError_t e = mode == 2 ? (pub ? RMCV_K1_LAUNCH(2, true) : RMCV_K1_LAUNCH(2, false))
+                             : mode == 1 ? (pub ? RMCV_K1_LAUNCH(1, true) : RMCV_K1_LAUNCH(1, false))
+                                         : (pub ? RMCV_K1_LAUNCH(0, true) : RMCV_K1_LAUNCH(0, false));
 #undef RMCV_K1_LAUNCH
         if (e != hipSuccess) return e;
     }
