@@ -688,15 +688,15 @@ def main():
                                         "x_plain = against this sweep's own plain level; not the metric" % (info.depth, info.sparse_streams)}
 
     if extras and args.workload == "c3" and args.variant == 0 and not args.pose and not args.one_dense:
-        # ---- BASELINE config 5 in short: 256 x 1920x1200 + icon rectification + SVM, 4 batches in flight over 4 frame sets
+        # ---- BASELINE config 5 in short: 256 x 1920x1200 + icon rectification + SVM, the steps' own schedule over 4 frame sets
         t_c5 = time.perf_counter()
         W5, H5 = WORKLOADS["c5"]
         barrier()
         sets5, _ = frame_sets(4, W5, H5, 0)
         svm5 = synth.svm_weights()
-        pl5 = make_pipeline(min(ns, 4), min(args.pixel_streams, 2), min(args.sparse_streams, 4), w=W5, h=H5, mc=2048, with_svm=svm5)
+        pl5 = make_pipeline(ns, args.pixel_streams, args.sparse_streams, w=W5, h=H5, mc=2048, with_svm=svm5)
         cur.update(pl=pl5, sets=sets5, w=W5, h=H5, stages=STAGE_ALL | STAGE_IDENTITY)
-        for _ in range(8):
+        for _ in range(2 * ns):
             step()
         rep5, _ = regions(20, 3)
         d5 = median(rep5) / 20
