@@ -72,8 +72,6 @@ def parse_args(argv=None):
                     help="synthetic stream: plain (0, the metric's), stress (1), dense1..dense4 (11..14; dense = dense4: +2000 specks and 13 "
                          "bright windows per frame, 5 %% foreground -- frames beyond findContours' LDS tables; a workload beside the metric)")
     ap.add_argument("--one-dense", action="store_true", help="one dense4 frame in every batch of the stream (a camera frame with a lit window; a workload beside the metric)")
-    ap.add_argument("--handover", action="store_true",
-                    help="frame-level hand-over: every step's sparse kernel runs beside its own pixel kernel (rmcv_pipeline_config::handover)")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames per pass of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (C2, C5, density sweep, per-frame chain)")
     ap.add_argument("--density-sweep", action="store_true", help="the density sweep with all five levels instead of the default three")
@@ -226,7 +224,7 @@ def main():
         # 4 and 2 (the library's own rule, rmcv_pipeline_create; the dev knobs override it)
         pl = Pipeline(device=local_rank, depth=depth, pixel_streams=pix, sparse_streams=sp, armour_cap=n * 8,
                       sparse_waves=int(knobs.get("RMCV_SPARSE_WAVES", 0)), pixel_groups=int(knobs.get("RMCV_PIXEL_GROUPS", 0)),
-                      host_results=host_results or (2 if args.device_results else 1), handover=1 if args.handover else 2,
+                      host_results=host_results or (2 if args.device_results else 1),
                       dense_streams=dense or args.dense_streams,
                       max_frames=n, max_width=w, max_height=h, max_contours=mc)
         for c in pl.contexts:
@@ -592,8 +590,7 @@ def main():
                    "stages": stages, "dev_knobs": knobs or None,
                    "armours_rank0_shard": n_arm_local, "armours_by_frame_set": [arm_by_set.get(k) for k in range(n_sets)], "armours_gathered": gathered,
                    "frames_over_capacity": bad, "frames_slow_path": slow, "frames_mid_tier": mid, "batches_with_dense_frames_split_off": int(pl.get_info().dense_split),
-                   "rccl_ranks": (dist.get_world_size() if use_dist else None), "gather": gather_note,
-                   "frame_level_handover": info.handover == 1},
+                   "rccl_ranks": (dist.get_world_size() if use_dist else None), "gather": gather_note},
         "lone_batch_ms": {"median": round(lone[len(lone) // 2], 4), "min": round(lone[0], 4), "passes": len(lone),
                           "note": "one batch at a time on one stream, events around detect + compaction (latency, not the metric)"},
         **({"ab": ab} if ab else {}),

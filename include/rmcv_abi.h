@@ -107,10 +107,6 @@ typedef struct {            /* capacities of one context; 0 = default */
                                  src/imgproc.cpp:9-35, src/core.cpp:202-216, executable/main.cpp:180-181; needs rmcv_svm_load */
 
 /* per-frame status bits reported by rmcv_batch_counts */
-#define RMCV_STAGE_HANDOVER 128 /* modifier of a run WITHOUT RMCV_STAGE_BINARY: the pixel kernel of this batch has been ENQUEUED (an
-                                 * earlier rmcv_batch_run(..., RMCV_STAGE_BINARY, other_stream) on this context) and may still be running --
-                                 * do not wait for it as a whole; the sparse kernel takes each frame when its rows are complete
-                                 * (frame-level hand-over).  A full run handed ONE stream does the same by itself on a side stream. */
 #define RMCV_FRAME_OVF_CONTOURS 1
 #define RMCV_FRAME_OVF_POINTS 2
 #define RMCV_FRAME_OVF_BLOBS 4
@@ -120,8 +116,6 @@ typedef struct {            /* capacities of one context; 0 = default */
 #define RMCV_FRAME_MID_PATH 64  /* informational: findContours of this frame ran on the mid tier (tables in global memory: the frame is
                                  * beyond the LDS tables -- > 4096 border visits, > 1024 non-empty words, > 512 contours -- but was not
                                  * handed to the sequential scanner) */
-#define RMCV_FRAME_TIMEOUT 128  /* error: the frame's bit plane never arrived (frame-level hand-over: the pixel kernel this run was told
-                                 * to wait for did not run) */
 #define RMCV_FRAME_HULL 32      /* legacy matcher: a contour exceeded the hull tables (dimensions > 4096) or is not a closed border */
 
 typedef struct rmcv_ctx rmcv_ctx;
@@ -161,11 +155,9 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * RMCV_FRAME_SLOW_PATH); 1: the sequential scanner for every frame; 2: the mid tier for every frame.  A test / diagnosis knob:
  * results are identical. */
 #define RMCV_OPT_CONTOUR_TIER 5
-/* RMCV_OPT_HANDOVER: 1: the per-frame sparse kernel of a batch runs beside the batch's own pixel kernel and takes each frame as
- * soon as its last strip is written (full runs fork it onto a side stream of the context; RMCV_STAGE_HANDOVER is honoured);
- * 0 (default): it starts when the whole pixel kernel is through (RMCV_STAGE_HANDOVER then simply waits for it).  Results are
- * identical; so were the measured step rates, and a lone batch is slower with it -- see DESIGN.md.  Needs hipStreamWaitValue32. */
-#define RMCV_OPT_HANDOVER 6
+/* (option id 6 was RMCV_OPT_HANDOVER, the frame-level hand-over from the pixel kernel to the sparse kernel of rounds 3-4: correct,
+ * tested, and measured equal or slower in every schedule, twice -- removed with its progress words, its write-through stores and
+ * the second instantiation of every pixel kernel; HISTORY.md 5b has the design) */
 /* RMCV_OPT_DENSE_DEFER: 1: with RMCV_OPT_SPARSE_WAVES = 4, a frame beyond the LDS tables of findContours (hundreds of borders:
  * RMCV_FRAME_MID_PATH) is left to a second launch with 8 wavefronts per frame right behind the first; 0 (default): every frame is
  * finished by the first launch.  Results are identical.  Measured: worth 14 % where EVERY frame is that dense, costs
@@ -408,21 +400,20 @@ typedef struct {            /* 0 in any field = the default; rmcv_default_pipeli
     int32_t pixel_groups;   /* RMCV_OPT_PIXEL_GROUPS                          (2 if depth >= 2 else 3) */
     int32_t host_results;   /* 1: every list is copied to pinned host memory behind its compaction (collect then copies from there);
                              * 2: lists stay on the device until collected                      (1)  */
-    int32_t handover;       /* 1: RMCV_OPT_HANDOVER + RMCV_STAGE_HANDOVER (frame-level hand-over); 2: off           (2)  */
     int32_t dense_streams;  /* streams for a batch's frames beyond findContours' LDS tables (a lit window, hundreds of specks): WHILE a
                              * few frames per batch are that dense (1 .. max_frames / 8 in the batch that last left the slot; needs
                              * host_results = 1 and sparse_waves = 4), the per-frame launch leaves them to a second launch with 8
-                             * wavefronts per frame that runs -- with the compaction behind it -- on one of these streams: the sparse
+                              * wavefronts per frame that runs -- with the compaction behind it -- on one of these streams: the sparse
                              * stream goes on with the next batch instead of waiting for a 0.5-1 ms frame (one lit window per batch:
                              * 1.3 x the plain step time without, 1.01 x with).  Batches without such frames, and batches full of them,
                              * run as if this were off.  -1: off                                                              (4)  */
-    int32_t _pad;
 } rmcv_pipeline_config;
 typedef struct {
-    int32_t depth, pixel_streams, sparse_streams, armour_cap, sparse_waves, pixel_groups, host_results, handover, dense_streams;
+    int32_t depth, pixel_streams, sparse_streams, armour_cap, sparse_waves, pixel_groups, host_results, dense_streams;
     int32_t max_frames;
     int32_t hw_queues_env;     /* what GPU_MAX_HW_QUEUES reads in this process (0: unset) */
     int32_t hw_queues_wanted;  /* 1 + pixel_streams + sparse_streams + dense_streams (+ 1 with a communicator) */
+    int32_t _pad;
     int64_t record_bytes;      /* a batch's record in HBM: [frame_offs: max_frames + 1 int32 | status: int32 | dense frames: int32 | pad to 16 B | armours: armour_cap x 88 B] */
     int64_t armours_offset;    /* = the layout of rmcv_amd/dist.py, the payload of rmcv_gather */
     uint64_t submitted, collected;

@@ -35,12 +35,10 @@ OPT_PIXEL_GROUPS = 2
 OPT_FRAME_UPLOAD = 3
 OPT_RUN_AHEAD = 4
 OPT_CONTOUR_TIER = 5
-OPT_HANDOVER = 6
 OPT_DENSE_DEFER = 7
 OPT_PIXEL_HALO_NT = 11
 OPT_OVERLOADS = 13
 STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE, STAGE_NO_IMAGE = 1, 2, 4, 8, 15, 16, 32, 64
-STAGE_HANDOVER = 128
 SVM_FEATURES = 1200
 FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_SLOW_PATH, FRAME_MID_PATH = 1, 2, 4, 8, 16, 64
 
@@ -89,15 +87,14 @@ class Limits(C.Structure):
 class PipelineConfig(C.Structure):
     """rmcv_pipeline_config (0 in a field = the default)"""
     _fields_ = [("depth", C.c_int32), ("pixel_streams", C.c_int32), ("sparse_streams", C.c_int32), ("armour_cap", C.c_int32),
-                ("sparse_waves", C.c_int32), ("pixel_groups", C.c_int32), ("host_results", C.c_int32), ("handover", C.c_int32),
-                ("dense_streams", C.c_int32), ("_pad", C.c_int32)]
+                ("sparse_waves", C.c_int32), ("pixel_groups", C.c_int32), ("host_results", C.c_int32), ("dense_streams", C.c_int32)]
 
 
 class PipelineInfo(C.Structure):
     """rmcv_pipeline_info"""
     _fields_ = [("depth", C.c_int32), ("pixel_streams", C.c_int32), ("sparse_streams", C.c_int32), ("armour_cap", C.c_int32),
-                ("sparse_waves", C.c_int32), ("pixel_groups", C.c_int32), ("host_results", C.c_int32), ("handover", C.c_int32),
-                ("dense_streams", C.c_int32), ("max_frames", C.c_int32), ("hw_queues_env", C.c_int32), ("hw_queues_wanted", C.c_int32),
+                ("sparse_waves", C.c_int32), ("pixel_groups", C.c_int32), ("host_results", C.c_int32), ("dense_streams", C.c_int32),
+                ("max_frames", C.c_int32), ("hw_queues_env", C.c_int32), ("hw_queues_wanted", C.c_int32), ("_pad", C.c_int32),
                 ("record_bytes", C.c_int64), ("armours_offset", C.c_int64), ("submitted", C.c_uint64), ("collected", C.c_uint64),
                 ("dense_split", C.c_uint64)]
 

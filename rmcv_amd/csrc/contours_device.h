@@ -257,7 +257,6 @@ struct ContoursLds {
     int nnodes, nkept, cursor, flags, nrows, nslots, nelig, lit[3];
     int nmulti;
     int revoked;  // cycles_frame: some acceptance was revoked in this round
-    int cur_ok;   // frame-level hand-over: the frame's planes arrived
     int wnext;    // fused tail: next entry of the sorted work list
     int sink[64]; // per-lane sinks: lanes != 0 add 0 here so that a wave-wide atomic stays convergent and does not serialise on one word
 };

@@ -2,7 +2,7 @@
 // rm::utils::flatten_image, src/core.cpp:202-216; svm->predict, executable/main.cpp:180-181).  One wavefront per armour; shared by
 // the stand-alone k_classify (k_classify.hip, the stage-wise entry points) and the fused tail of the per-frame sparse kernel
 // (k_contours_kernel.inc: a frame's armours are classified by the workgroup that has just built them, so BASELINE config 5 needs
-// no launch of its own for it and the classification rides on the frame-level hand-over like the rest of the sparse work).
+// no launch of its own for it).
 #pragma once
 #include <float.h>
 

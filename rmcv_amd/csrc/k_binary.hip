@@ -37,13 +37,8 @@ namespace rmcv {
 #ifndef RMCV_K1_STAUX
 #define RMCV_K1_STAUX 2 // cache-policy bits of the byte-image stores (2 = nt)
 #endif
-#ifndef RMCV_K1_PLAUX
-#define RMCV_K1_PLAUX 16 // cache-policy bits of the bit-plane stores: sc1 = written through to the agent-coherent level, so that the
-                         // sparse kernel -- which may run BESIDE this launch, on another XCD with its own L2 -- sees a frame's words
-                         // as soon as the frame's progress word says so, without an L2 write-back (frame-level hand-over, below)
-#endif
 #ifndef RMCV_K1_PLAIN_PLAUX
-#define RMCV_K1_PLAIN_PLAUX 0 // ... of the bit-plane stores when nothing runs beside this launch (no hand-over)
+#define RMCV_K1_PLAIN_PLAUX 0 // cache-policy bits of the bit-plane stores (plain: the sparse kernel of the same batch finds the words in L2)
 #endif
 #ifndef RMCV_K1_HALOAUX
 #define RMCV_K1_HALOAUX 0 // cache-policy bits of the loads of the row quads a strip shares with its neighbours (0 = cacheable: the neighbour finds them in L2)
@@ -105,7 +100,7 @@ static constexpr int RSRC3 = 0x00020000;     // raw buffer descriptor word 3, gf
 // Register budget: 6 waves per SIMD = at most 80 VGPRs.  Two launches of consecutive batches overlap (2 workgroups per CU each = 4
 // waves per SIMD) next to one wave of the 4-wavefront sparse kernel (168 VGPRs): 4 x 80 + 168 <= 512.  At 88 the sparse kernel
 // would no longer fit beside them and the batches in flight would take turns instead of sharing the CUs.
-template <int CA, int CB, int FAST /* 0: byte-wise loader, 1: row-quad items, 2: linear items (rows contiguous in memory) */, bool PUB>
+template <int CA, int CB, int FAST /* 0: byte-wise loader, 1: row-quad items, 2: linear items (rows contiguous in memory) */>
 #ifndef RMCV_K1_MINBLOCKS
 #define RMCV_K1_MINBLOCKS 6
 #endif
@@ -114,16 +109,9 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
                                                  uint8_t* __restrict__ binary, uint64_t* __restrict__ bits, int prow,
                                                  int64_t plane_pitch, int strips, int n_blocks, uint32_t* __restrict__ rowmask,
                                                  int* __restrict__ strip_ctr, int taper_head, int taper_tail,
-                                                 unsigned long long* __restrict__ frame_ready, uint32_t seq, unsigned* started, int halo_nt /* RMCV_OPT_PIXEL_HALO_NT */)
+                                                 int halo_nt /* RMCV_OPT_PIXEL_HALO_NT */)
 {
     extern __shared__ uint64_t smem[];
-    // "this launch is RUNNING": the stream that carries the sparse kernel of the batch waits for this word (hipStreamWaitValue32,
-    // rmcv_host.hip) before it lets workgroups loose that spin for this launch's frames -- a spinning consumer must never be on
-    // the machine before its producer is (workgroups that wait for a kernel the dispatcher has not placed yet can keep it from
-    // being placed).  ONE workgroup says so (the word lives in host-visible signal memory: when all 768 workgroups of a launch
-    // stored to it, the burst of system-scope stores held up the sparse kernel's own start by 0.2 us per store -- 60 / 108 / 175 us
-    // at 1 / 2 / 3 workgroups per CU); workgroup 0 is among the first the dispatcher places.
-    if (PUB && started && threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(started, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef RMCV_PROFILE_HANDOVER
     if (blockIdx.x == 0 && threadIdx.x == 0) printf("[kb start] %lld\n", (long long)wall_clock64());
 #endif
@@ -155,29 +143,12 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
     __shared__ uint64_t s_lut[256];
     __shared__ uint16_t s_spare[256]; // where a lane without a place in the plane writes (no write sits behind a branch)
     if (FAST) s_lut[tid] = (uint64_t)expand4(tid) | ((uint64_t)expand4(tid >> 4) << 32);
-    // Frame-level hand-over to the sparse kernel (which may run beside this launch, rmcv_host.hip): when a strip's plane words and
-    // row masks are stored, its rows are added to frame_ready[f].  The words only ever grow -- they are zeroed when a geometry is
-    // bound, and every launch adds h to every frame's --, so the frame is complete for launch number L of that geometry when its
-    // word reaches L * h.  Published after the barrier at the top of the NEXT iteration (every wave's stores are then
-    // acknowledged), by one thread.
-    int pub_f = -1, pub_rows = 0;
     int ticket = 0;
     if (tid == 0) ticket = atomicAdd(&strip_ctr[xcd * CTR_STRIDE], 1);
     for (;;) {
     // dynamic strip queue per XCD: a workgroup takes the next strip of its XCD's range when it is done with the previous
     // one, so CUs that also host kernels of another stream simply take fewer strips (a static split made them the tail)
     __syncthreads(); // also: the LDS planes of the previous strip are free
-    if (PUB && frame_ready && pub_f >= 0 && tid == 0) {
-        // A fire-and-forget add: nothing waits for its result (its acknowledgement is awaited together with the ticket fetch below).
-        // Two earlier forms were measured and dropped: a release FENCE before the add -- at agent scope that is an L2 write-back
-        // (buffer_wbl2), per strip, 8192 times a launch: the kernel ran 12 x slower --, and a load + compare-and-swap that
-        // restarted words carrying an older launch label -- two dependent round trips to the coherence point on every strip's
-        // critical path: 0.39 ms instead of 0.237.  No fence is needed: the only data the consumer reads, the strip's plane words
-        // and row masks, are stored with sc1 (written through to the agent-coherent level), every wave waited for its stores'
-        // acknowledgements before the barrier above, and this add is issued after it.
-        __hip_atomic_fetch_add(frame_ready + pub_f, (unsigned long long)pub_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    pub_f = -1;
     // Every launch finds the heads at 0: the workgroup that leaves last zeroes them (below), so there is no memset per step
     // and no host-side mirror of device state that a failed or foreign launch could put out of step.
     // Pieces: the first taper_head and the last taper_tail strips of an XCD's range are handed out as four 8-row pieces each.
@@ -204,7 +175,7 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
     if (L >= n_blocks) continue; // tail of the last XCD's range: draw on, so that every head advances alike
     const int f = L / strips, strip = L - f * strips;
     const int y0 = strip * SR + piece * (SR / 4);
-    if (y0 >= h) continue; // a piece of the frame's last strip that lies below the image (h % SR <= 24): nothing to load, store or publish
+    if (y0 >= h) continue; // a piece of the frame's last strip that lies below the image (h % SR <= 24): nothing to load or store
     const int srh = sr + 2 * halo;
     const uint8_t* frame = frames + (int64_t)f * frame_pitch;
 
@@ -471,8 +442,7 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
     if (ww <= 32 && tid < sr && y0 + tid < h) {
         uint32_t m = 0;
         for (int k = 0; k < ww; k++) m |= (uint32_t)(R[(tid + halo) * ww + k] != 0) << k;
-        if (PUB) __hip_atomic_store(&rowmask[(int64_t)f * h + y0 + tid], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1, like the plane words)
-        else rowmask[(int64_t)f * h + y0 + tid] = m;
+        rowmask[(int64_t)f * h + y0 + tid] = m;
     }
     // ---------------- phase 4: expand to bytes + bit plane
     if (FAST) {
@@ -487,12 +457,8 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
                 const bool ok = it < nw && y < h;
                 uint64_t word = 0;
                 if (ok) word = R[__umul24(s_ + halo, ww) + k];
-                // written through (sc1) only when this launch publishes per-frame progress (the consumer may then read the words
-                // from another XCD while the launch still runs); otherwise plain: the sparse kernel of the same batch finds them
-                // in L2 (same-box A/B of the whole bench: plain is 0-4 % faster, tools/ab_process_r3.sh pl)
                 const uint32_t po = ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB;
-                // (PUB is a template parameter: as a run-time branch the two stores cost the 80-register kernel five spilled dwords)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, PUB ? RMCV_K1_PLAUX : RMCV_K1_PLAIN_PLAUX);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, RMCV_K1_PLAIN_PLAUX); // (plain: the sparse kernel of the same batch finds the words in L2)
                 k += k_step;
                 s_ += s_step;
                 if (k >= ww) { k -= ww; s_++; }
@@ -537,8 +503,7 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
                     }
                 }
                 if ((q & 3) == 0) {
-                    if (PUB) __hip_atomic_store(&plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1)
-                    else plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)] = word;
+                    plane[(int64_t)(y + 1) * prow + 1 + (q >> 2)] = word;
                 }
             }
             s += dr;
@@ -546,8 +511,6 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
             if (q >= wq) { q -= wq; s++; }
         }
     }
-    pub_f = f;
-    pub_rows = min(sr, h - y0); // > 0: pieces below the image were skipped above
     } // strip loop
     // Leaving: this workgroup has drawn its last index.  strip_ctr[8] counts the leavers; the last one of the launch knows that
     // nobody will draw again and zeroes the eight heads and the count for the next launch (launches of one context are ordered:
@@ -567,7 +530,7 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
 }
 
 template <int CA, int CB>
-static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, int groups, uint32_t seq, bool publish,
+static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, int groups,
                                   hipStream_t s)
 {
     const int strips = (g.h + SR - 1) / SR;
@@ -610,49 +573,32 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
         uint64_t* bits = b.bits + (int64_t)f0 * g.plane_pitch;
         uint32_t* rowmask = b.rowmask + (int64_t)f0 * g.h;
         // beyond 64 KiB of dynamic LDS (frames wider than ~6700 pixels) the kernel has to be told; per device and instantiation
-        const bool pub = publish && b.frame_ready != nullptr; // (the caller decides: rmcv_host.hip run_stages)
-        static size_t lds_set[MAX_DEVICES][6] = {};
+        static size_t lds_set[MAX_DEVICES][3] = {};
         const int mode = fast ? (linear ? 2 : 1) : 0;
-        const int inst = mode * 2 + (pub ? 1 : 0);
+        const int inst = mode;
         if (planes > 60 * 1024 && planes > lds_set[g.device][inst]) {
-            const void* fn = mode == 2 ? (pub ? reinterpret_cast<const void*>(k_binary<CA, CB, 2, true>) : reinterpret_cast<const void*>(k_binary<CA, CB, 2, false>))
-                           : mode == 1 ? (pub ? reinterpret_cast<const void*>(k_binary<CA, CB, 1, true>) : reinterpret_cast<const void*>(k_binary<CA, CB, 1, false>))
-                                       : (pub ? reinterpret_cast<const void*>(k_binary<CA, CB, 0, true>) : reinterpret_cast<const void*>(k_binary<CA, CB, 0, false>));
+            const void* fn = mode == 2 ? reinterpret_cast<const void*>(k_binary<CA, CB, 2>) : mode == 1 ? reinterpret_cast<const void*>(k_binary<CA, CB, 1>) : reinterpret_cast<const void*>(k_binary<CA, CB, 0>);
             const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes);
             if (ea != hipSuccess) return ea;
             lds_set[g.device][inst] = planes;
         }
-#define RMCV_K1_LAUNCH(F, P)                                                                                                          \
-    launch(k_binary<CA, CB, F, P>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
+#define RMCV_K1_LAUNCH(F)                                                                                                             \
+    launch(k_binary<CA, CB, F>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \
            morph, binary, bits, g.prow, g.plane_pitch, strips, n_blocks, rowmask, b.strip_ctr, taper_head, taper_tail,               \
-           pub ? b.frame_ready + f0 : nullptr, seq, pub ? b.started : nullptr, g.pixel_halo_nt)
-        const hipError_t e = mode == 2 ? (pub ? RMCV_K1_LAUNCH(2, true) : RMCV_K1_LAUNCH(2, false))
-                             : mode == 1 ? (pub ? RMCV_K1_LAUNCH(1, true) : RMCV_K1_LAUNCH(1, false))
-                                         : (pub ? RMCV_K1_LAUNCH(0, true) : RMCV_K1_LAUNCH(0, false));
+           g.pixel_halo_nt)
+        const hipError_t e = mode == 2 ? RMCV_K1_LAUNCH(2) : mode == 1 ? RMCV_K1_LAUNCH(1) : RMCV_K1_LAUNCH(0);
 #undef RMCV_K1_LAUNCH
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-// number of launches launch_binary makes for this geometry (the 32-bit buffer extents bound a launch's frames)
-int binary_launches(const Geom& g, const Bufs& b)
-{
-    const bool aligned = (g.w % 64 == 0) && (g.stride % 16 == 0) && (g.frame_pitch % 16 == 0) && ((uintptr_t)b.frames % 16 == 0);
-    if (!aligned) return 1;
-    const int64_t lim = 0xFFFFF000ll;
-    const int64_t per_frame = std::max<int64_t>(std::max<int64_t>(g.frame_pitch, g.plane_pitch * 8), (int64_t)g.w * g.h);
-    const int chunk = (int)std::min<int64_t>(g.n_frames, std::max<int64_t>(1, (lim - 1) / per_frame));
-    return (g.n_frames + chunk - 1) / chunk;
-}
-
-hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, bool publish,
-                         hipStream_t s)
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s)
 {
     // imgproc.cpp:56-65: GUIDELIGHT G-R; BLUE B-R; everything else (RED, NEUTRAL) R-B.  BGR byte order.
-    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, groups, seq, publish, s);
-    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, groups, seq, publish, s);
-    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, groups, seq, publish, s);
+    if (camp == RMCV_CAMP_GUIDELIGHT) return launch_binary_t<1, 2>(g, b, lower_bound, morph, image, groups, s);
+    if (camp == RMCV_CAMP_BLUE) return launch_binary_t<0, 2>(g, b, lower_bound, morph, image, groups, s);
+    return launch_binary_t<2, 0>(g, b, lower_bound, morph, image, groups, s);
 }
 
 // binary (0 / non-zero bytes) -> padded bit plane; used when a caller hands in its own binary image

@@ -38,12 +38,9 @@ namespace rmcv {
 
 static_assert(sizeof(ContoursLds) >= (CT_THREADS_MAX / 64) * sizeof(WaveLds), "the fit rows reuse the contour tables");
 
-static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int waves, uint32_t wait_seq,
-                                    hipStream_t s)
+static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int waves, hipStream_t s)
 {
     SparseSched Q;
-    Q.frame_ready = wait_seq ? b.frame_ready : nullptr;
-    Q.target = (unsigned long long)wait_seq * (unsigned long long)g.h;
     Q.order = b.frame_order;
     const int grid = g.n_frames;
     static const int force_literal = getenv("RMCV_CONTOURS_LITERAL") ? atoi(getenv("RMCV_CONTOURS_LITERAL")) : 0; // dev/test knob
@@ -65,8 +62,7 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
         if (g.dense_defer == 3 && !defer) return hipSuccess; // (nothing was deferred: the first launch finished every frame)
         hipError_t e = g.dense_defer == 3 ? hipSuccess : launch_contours_w4(g, b, lim, X, force | (defer ? 4 : 0), Q, grid, s);
         if (e != hipSuccess || !defer || g.dense_defer == 2) return e;
-        SparseSched Q2 = Q;
-        Q2.frame_ready = nullptr; // the first launch has consumed the planes already
+        const SparseSched& Q2 = Q;
         static const bool second_w4 = getenv("RMCV_DEFER_W4") && atoi(getenv("RMCV_DEFER_W4")); // dev knob: the second launch with 4 wavefronts per frame too
         if (second_w4) return launch_contours_w4(g, b, lim, X, 2 | 8, Q2, grid, s);
         return launch(k_contours_w8, dim3(grid), dim3(512), lds_bytes(g.h), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
@@ -80,16 +76,15 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
                        b.mid_slot_cap, Q, lds_rows_cap(g.h));
 }
 
-hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, uint32_t wait_seq, hipStream_t s)
+hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s)
 {
     SparseTail X;
     memset(&X, 0, sizeof(X));
-    return launch_contours_x(g, b, lim, X, 8, wait_seq, s);
+    return launch_contours_x(g, b, lim, X, 8, s);
 }
 
 // findContours + filter_lightblobs (+ filter_armours) of every frame in ONE launch
-hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, bool identity, int waves, uint32_t wait_seq,
-                         hipStream_t s)
+hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, bool identity, int waves, hipStream_t s)
 {
     SparseTail X;
     memset(&X, 0, sizeof(X));
@@ -115,7 +110,7 @@ hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const 
     T.length_ratio_max = p.length_ratio_max;
     T.ov = g.overloads;
     if (identity && pairs) X.C = classify_args(g, b);
-    return launch_contours_x(g, b, lim, X, waves, wait_seq, s);
+    return launch_contours_x(g, b, lim, X, waves, s);
 }
 
 // see ExportArgs (rmcv_internal.h): the lists and header words, by `nthreads` threads of which this is number `gtid`

@@ -66,18 +66,8 @@ struct rmcv_ctx {
     struct ArParams { float angle_diff_max, shear_max, length_ratio_max; int enemy; } last_ar{};
     bool last_lb_valid = false, last_ar_valid = false; // what the previous frame's calls asked for
     bool ahead_lb = false, ahead_ar = false;           // this frame's extract_color has run them: headers + windows are in pinned memory
-    // Frame-level hand-over (k_binary -> the per-frame sparse kernel): the sparse kernel of a batch runs BESIDE the batch's own pixel
-    // kernel, on a side stream, and takes each frame when its last strip has been written.
-    int handover = 0;             // RMCV_OPT_HANDOVER (off by default: measured equal to the plain order on the pipelined bench and
-                                  // slower for a lone batch -- DESIGN.md section 5b)
-    hipStream_t side = nullptr;   // the library's own second stream (full runs handed ONE stream are forked onto it and joined)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pre_binary = nullptr;
-    bool pre_binary_valid = false; // ev_pre_binary marks the point in front of the last pixel kernel
-    bool binary_enqueued = false;  // a pixel kernel has been enqueued on this geometry
-    uint32_t binary_seq = 0;      // k_binary launches since the geometry was bound (frame_ready words: launch L is through with a frame at L * h)
-    uint32_t pub_id = 0;          // PUBLISHING k_binary launches of this context: the label the `started` word carries.  Only
-                                  // launches that write the word advance it, and the stream waits with >= -- a launch that does
-                                  // not publish (rmcv_extract_color, RMCV_K1_NOPUB) can neither be waited for nor overwrite a label
+    hipStream_t side = nullptr;   // the library's own second stream: the byte image's download runs on it beside the sparse kernels
+    hipEvent_t ev_fork = nullptr;
     int mid_frames = 0;           // frame slots Bufs::mid holds (ensure_mid)
     bool mid_failed = false;      // ... could not be allocated: the mid tier is absent for this context
     int sparse_waves = 8;         // RMCV_OPT_SPARSE_WAVES
@@ -175,10 +165,7 @@ void rmcv_ctx_destroy(rmcv_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    if (c->ev_join) hipEventDestroy(c->ev_join);
-    if (c->ev_pre_binary) hipEventDestroy(c->ev_pre_binary);
     for (void* p : c->allocs) hipFree(p);
-    if (c->bufs.started) hipFree(c->bufs.started);
     if (c->own_frames) hipFree(c->own_frames);
     for (auto& r : c->registered) hipHostUnregister(const_cast<void*>(r.p));
     for (void* h : {(void*)c->h_frame, (void*)c->h_hdr, (void*)c->h_pts, (void*)c->h_offs, (void*)c->h_blobs,
@@ -217,17 +204,8 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pre_binary, hipEventDisableTiming);
     if (e == hipSuccess) {
-        // NORMAL priority, on purpose.  The sparse kernel's workgroups may spin for frames of a pixel kernel that has not been
-        // dispatched yet; on a high-priority queue, workgroups of theirs that are still PENDING (a batch of more frames than CUs)
-        // keep the dispatcher from placing lower-priority workgroups -- the pixel kernel's -- and the two wait for each other until
-        // the spin times out (seen once, with 300 frames: tests/test_gpu_round2.py::test_armour_list_compaction...).
-        static const int side_prio = getenv("RMCV_SIDE_PRIO") ? atoi(getenv("RMCV_SIDE_PRIO")) : 0; // dev knob: -1 = high
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = the numerically lowest = the highest priority
-        e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, side_prio < 0 ? hi : 0);
+        e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, 0);
     }
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
@@ -275,18 +253,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.n_armours, F);
     if (e == hipSuccess) e = dalloc(c, &b.status, F);
     if (e == hipSuccess) e = dalloc(c, &b.frame_order, F);
-    if (e == hipSuccess) e = dalloc(c, &b.frame_ready, F);
-    if (e == hipSuccess) { // the "pixel kernel is running" word a stream can wait on; without it there is no frame-level hand-over
-        int can = 0;
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) can = 0;
-        if (can && hipExtMallocWithFlags((void**)&b.started, 8, hipMallocSignalMemory) == hipSuccess) {
-            if (hipMemset(b.started, 0, 8) != hipSuccess) { hipFree(b.started); b.started = nullptr; }
-        } else b.started = nullptr;
-        (void)hipGetLastError();
-        (void)0; // (without the word RMCV_OPT_HANDOVER = 1 is refused)
-    }
     if (e == hipSuccess) {
-        hipMemset(b.frame_ready, 0, F * sizeof(unsigned long long));
         hipMemset(b.strip_ctr, 0, 9 * CTR_STRIDE * sizeof(int));
         hipMemset(b.n_contours, 0, F * 4);
         hipMemset(b.n_points, 0, F * 4);
@@ -460,11 +427,6 @@ static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t
                 }
         }
         { const int rcs = rmcv_batch_sync(c); if (rcs) return rcs; } // a batch of the previous shape may still be reading the old order
-        // the progress words count rows since THIS binding: launch number L of the geometry is complete for a frame at L * h
-        HIPCHK(c, hipMemset(c->bufs.frame_ready, 0, (size_t)c->lim.max_frames * sizeof(unsigned long long)), "frame progress words");
-        c->binary_seq = 0;
-        c->pre_binary_valid = false;
-        c->binary_enqueued = false;
         HIPCHK(c, hipMemcpy(c->bufs.frame_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice), "frame order");
         c->order_n = n_frames;
         c->order_h = h;
@@ -497,32 +459,11 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     const Bufs& b = c->bufs;
     int k = 0;
     resident_none(c);
-    static const bool host_trace = getenv("RMCV_TRACE_HOST") && atoi(getenv("RMCV_TRACE_HOST")); // dev knob: host time of every enqueue below
-    static int host_trace_calls = 0;
-    double ht[12]; int hk = 0;
-    auto HT = [&]() { if (host_trace && hk < 12) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); ht[hk++] = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; } };
-    HT();
-    const bool waits_per_frame = (stages & RMCV_STAGE_HANDOVER) != 0; // the caller enqueued this batch's pixel kernel elsewhere
-    stages &= ~RMCV_STAGE_HANDOVER;
     int rc;
     // every argument check comes BEFORE the first enqueue: an error return leaves the streams as they were
-    if (waits_per_frame) {
-        if (!c->binary_enqueued) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER without a preceding RMCV_STAGE_BINARY run");
-        if (stages & RMCV_STAGE_BINARY) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER goes with a run WITHOUT RMCV_STAGE_BINARY");
-    }
     if ((stages & RMCV_STAGE_IDENTITY) && !b.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
     if ((stages & RMCV_STAGE_POSE) && !b.pnp_cfg) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_POSE needs rmcv_pnp_load first");
-    if (c->pub_id >= 0x7FFFFF00u) { // the label is 32 bits wide: start over long before it wraps (months of launches away)
-        if ((rc = rmcv_batch_sync(c))) return rc;
-        if (b.started) HIPCHK(c, hipMemset(b.started, 0, 8), "hand-over: label reset");
-        c->pub_id = 0;
-        c->pre_binary_valid = false;
-        c->binary_enqueued = false;
-    }
-    if (waits_per_frame && c->handover && c->pre_binary_valid) {
-        // everything this context did BEFORE that pixel kernel must be through; the pixel kernel itself need not be
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_pre_binary, 0), "hand-over: wait for what preceded the pixel kernel");
-    } else if ((rc = order_begin(c, s))) return rc;
+    if ((rc = order_begin(c, s))) return rc;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     // Status bits belong to the stage that sets them: k_contours rewrites the whole word; a run that starts at a later stage
     // clears only the bits of the stages it runs, so OVF_CONTOURS / OVF_POINTS / SLOW_PATH of the contour run it builds on survive.
@@ -535,49 +476,14 @@ static int run_stages(rmcv_ctx* c, const rmcv_params* p, int stages, hipStream_t
     // the per-stage events of rmcv_batch_run_timed need per-stage launches (RMCV_FUSE_SPARSE=0: dev knob for A/B runs)
     static const bool fuse_ok = !(getenv("RMCV_FUSE_SPARSE") && atoi(getenv("RMCV_FUSE_SPARSE")) == 0);
     const bool one_sparse = fuse_ok && !timed && !lp && (stages & RMCV_STAGE_CONTOURS) && (stages & RMCV_STAGE_BLOBS);
-    // A full run on ONE stream: the sparse kernel is forked onto the context's side stream, next to the pixel kernel, and joined
-    // back -- each frame's contours, fits and pairing start when the frame's last strip is written instead of the batch's.
-    // (not when the pixel kernel takes several launches -- batches beyond the 32-bit buffer extents --: the word the sparse stream
-    // waits on says that the FIRST of them runs)
-    static const bool nopub = getenv("RMCV_K1_NOPUB") && atoi(getenv("RMCV_K1_NOPUB")); // dev knob: no progress words, hence no hand-over
-    const bool can_hand_over = c->handover && !nopub && b.frame_ready && b.started && binary_launches(g, b) == 1;
-    const bool forked = one_sparse && can_hand_over && (stages & RMCV_STAGE_BINARY) && g.n_frames >= 4;
     if (stages & RMCV_STAGE_BINARY) {
-        c->binary_enqueued = true;
-        c->pre_binary_valid = false;
-        if (can_hand_over) { // (only then: a marker in front of every pixel kernel costs the next launch a few microseconds)
-            HIPCHK(c, hipEventRecord(c->ev_pre_binary, s), "hand-over: mark");
-            c->pre_binary_valid = true;
-        }
-        if (forked) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pre_binary, 0), "hand-over: fork");
-        const bool publish = can_hand_over;
-        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, c->pub_id + 1, publish, s), "k_binary");
-        if (publish) { // (counted once the launch is accepted: the device's words and these counters move together)
-            c->pub_id++;
-            c->binary_seq++;
-        } else c->pre_binary_valid = false; // nothing to hand over frame by frame: a RMCV_STAGE_HANDOVER run waits for the launch as a whole
-        HT();
+        HIPCHK(c, launch_binary(g, b, p->camp, p->lower_bound, p->morph, !(stages & RMCV_STAGE_NO_IMAGE), c->pixel_groups, s), "k_binary");
     }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
-    const bool per_frame = forked || (waits_per_frame && can_hand_over && c->pre_binary_valid);
-    // (RMCV_STAGE_HANDOVER with the hand-over switched off went through order_begin above: it waits for the whole pixel kernel)
-    const uint32_t wait_seq = per_frame ? c->binary_seq : 0;
-    hipStream_t ss = forked ? c->side : s;
-    // the spinning consumer goes on the machine only once its producer is there (k_binary.hip: `started`)
-    static const bool no_waitvalue = getenv("RMCV_NO_WAITVALUE") && atoi(getenv("RMCV_NO_WAITVALUE")); // dev knob (timing experiments only)
-    if (per_frame && !no_waitvalue) HIPCHK(c, hipStreamWaitValue32(ss, b.started, c->pub_id, hipStreamWaitValueGte, 0xFFFFFFFFu), "hand-over: wait for the pixel kernel to start");
     // the icon classifier rides in the per-frame kernel when the armours come from it (BASELINE config 5: no launch of its own)
     const bool identity_fused = one_sparse && (stages & RMCV_STAGE_ARMOURS) && (stages & RMCV_STAGE_IDENTITY);
-    if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, identity_fused, c->sparse_waves, wait_seq, ss), "k_contours (fused)");
-    else if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, wait_seq, s), "k_contours");
-    HT();
-    if (forked) {
-        HIPCHK(c, hipEventRecord(c->ev_join, c->side), "hand-over: join");
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0), "hand-over: join");
-    }
-    HT();
-    if (host_trace && ++host_trace_calls % 8 == 0 && hk >= 4)
-        fprintf(stderr, "[rmcv host] run_stages: to k_binary enqueued %.1f us, to sparse enqueued %.1f us, join %.1f us (forked %d)\n", ht[1] - ht[0], ht[2] - ht[1], ht[3] - ht[2], (int)forked);
+    if (one_sparse) HIPCHK(c, launch_sparse(g, b, c->lim, *p, (stages & RMCV_STAGE_ARMOURS) != 0, identity_fused, c->sparse_waves, s), "k_contours (fused)");
+    else if (stages & RMCV_STAGE_CONTOURS) HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[k++], s), "event");
     const bool fused = (stages & RMCV_STAGE_BLOBS) && (stages & RMCV_STAGE_ARMOURS); // one launch for both
     if (one_sparse) {
@@ -597,7 +503,7 @@ static int check_params(rmcv_ctx* c, const rmcv_params* p, int stages)
     if (!c) return RMCV_ERR_BAD_ARG;
     if (!p) return fail(c, RMCV_ERR_BAD_ARG, "null params");
     if (p->morph < RMCV_MORPH_NONE || p->morph > RMCV_MORPH_CLOSE) return fail(c, RMCV_ERR_BAD_ARG, "bad morph");
-    if (stages <= 0 || stages > (RMCV_STAGE_ALL | RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE | RMCV_STAGE_NO_IMAGE | RMCV_STAGE_HANDOVER)) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
+    if (stages <= 0 || stages > (RMCV_STAGE_ALL | RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE | RMCV_STAGE_NO_IMAGE)) return fail(c, RMCV_ERR_BAD_ARG, "bad stage mask");
     if (c->geom.n_frames <= 0 || !c->bufs.frames) {
         if (stages & RMCV_STAGE_BINARY) return fail(c, RMCV_ERR_BAD_ARG, "no frames bound");
     }
@@ -676,11 +582,6 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
     }
     if (option == RMCV_OPT_FRAME_UPLOAD && value >= 0 && value <= 2) {
         c->frame_upload = value;
-        return RMCV_OK;
-    }
-    if (option == RMCV_OPT_HANDOVER && (value == 0 || value == 1)) {
-        if (value && !c->bufs.started) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_OPT_HANDOVER needs hipStreamWaitValue32 on signal memory, which this device / runtime lacks");
-        c->handover = value;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_PIXEL_HALO_NT && (value == 0 || value == 1)) {
@@ -831,7 +732,6 @@ int rmcv_batch_get_contours(rmcv_ctx* c, int frame, rmcv_point* pts_out, int pts
     HIPCHK(c, hipMemcpy(&total, c->pack_offs + nc, 4, hipMemcpyDeviceToHost), "D2H");
     if (n_contours) *n_contours = nc;
     if (n_points) *n_points = total;
-    if (st & RMCV_FRAME_TIMEOUT) return fail(c, RMCV_ERR_HIP, "frame-level hand-over timed out: the pixel kernel of this batch never delivered its planes");
     if (st & (RMCV_FRAME_OVF_CONTOURS | RMCV_FRAME_OVF_POINTS)) return fail(c, RMCV_ERR_CAPACITY, "context limits exceeded (max_contours/max_points)");
     if (nc > contours_cap || total > pts_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
     if (offs_out) HIPCHK(c, hipMemcpy(offs_out, c->pack_offs, (size_t)(nc + 1) * 4, hipMemcpyDeviceToHost), "D2H offs");
@@ -877,8 +777,6 @@ int rmcv_batch_get_armours(rmcv_ctx* c, rmcv_armour* armours_out, int cap, int32
     }
     if (frame_offs) frame_offs[nf] = (int32_t)total;
     if (n_total) *n_total = (int32_t)total;
-    for (int f = 0; f < nf; f++)
-        if (st[f] & RMCV_FRAME_TIMEOUT) return fail(c, RMCV_ERR_HIP, "frame-level hand-over timed out: the pixel kernel of this batch never delivered its planes");
     if (ovf) return fail(c, RMCV_ERR_CAPACITY, "context limits exceeded on at least one frame (see status)");
     if (total > cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
     if (armours_out && total) {
@@ -1177,9 +1075,7 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     const Geom& g = c->geom;
     const Bufs& b = c->bufs;
     hipStream_t s = c->stream;
-    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, 0, false, s), "k_binary");
-    c->pre_binary_valid = false; // this launch published nothing: a later RMCV_STAGE_HANDOVER run has no pixel kernel to follow frame by frame
-    c->binary_enqueued = false;
+    HIPCHK(c, launch_binary(g, b, camp, lower_bound, morph, binary_out != nullptr, c->pixel_groups, s), "k_binary");
     if (binary_out) HIPCHK(c, hipEventRecord(c->ev_fork, s), "image download: mark");
     // running ahead with both parameter sets known: the frame's whole sparse part is ONE kernel (the fused per-frame kernel of
     // the batch path: findContours, fits and pairing back to back), not three
@@ -1196,9 +1092,9 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
         p.angle_diff_max = c->last_ar.angle_diff_max;
         p.shear_max = c->last_ar.shear_max;
         p.length_ratio_max = c->last_ar.length_ratio_max;
-        HIPCHK(c, launch_sparse(g, b, c->lim, p, true, false, 8, 0, s), "k_contours (fused)");
+        HIPCHK(c, launch_sparse(g, b, c->lim, p, true, false, 8, s), "k_contours (fused)");
     } else {
-        HIPCHK(c, launch_contours(g, b, c->lim, 0, s), "k_contours");
+        HIPCHK(c, launch_contours(g, b, c->lim, s), "k_contours");
     }
     // Results go home by kernel stores into the pinned buffers (ExportArgs) instead of a row of small copies -- each of those is a
     // hand-over from the compute queue to the copy engine and back, 5-8 us apiece, nine of them when the chain runs ahead

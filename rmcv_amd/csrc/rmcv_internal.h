@@ -85,8 +85,6 @@ struct Bufs {
     int32_t* n_armours;    // [frame]
     int32_t* status;       // [frame] RMCV_FRAME_* bits
     int32_t* frame_order;  // [frame] the frames in k_binary's completion order, interleaved over the XCDs (SparseSched::order)
-    unsigned long long* frame_ready; // [frame] k_binary's per-frame progress: rows finished, summed over the launches since set_geom
-    unsigned* started;     // signal memory: the label of the k_binary launch that has started running (hipStreamWaitValue32 target)
     // icon classifier (BASELINE config 5); allocated by rmcv_svm_load
     float* svm_w;          // [n_df][1200]
     double* svm_rho;       // [n_df]
@@ -104,12 +102,11 @@ struct Bufs {
 // rewrites the word of every frame that carries it)
 #define RMCV_FRAME_DEFERRED_ (1 << 30)
 
-// Frame-level hand-over from k_binary to the per-frame sparse kernel, and the order in which the latter's workgroups take frames.
+// The order in which the sparse kernel's workgroups take frames (Bufs::frame_order): the frames in the order k_binary completes
+// them, interleaved over the XCDs the way workgroups are dealt to them -- a frame's planes are then read on the XCD whose L2 they
+// were written through.
 struct SparseSched {
-    const unsigned long long* frame_ready;  // [frame] rows finished by all k_binary launches since the geometry was bound; null: no
-                                            // hand-over -- the planes are complete before this launch starts (stream order)
-    unsigned long long target;              // the value a frame's word has when the k_binary launch this launch consumes is through with it
-    const int32_t* order;                   // [frame] workgroup b -> frame (Bufs::frame_order); null: identity
+    const int32_t* order; // [frame] workgroup b -> frame; null: identity
 };
 
 static constexpr int MAX_DEVICES = 64; // per-device launch state (hipFuncSetAttribute is per device) is kept in arrays of this size
@@ -135,17 +132,11 @@ inline hipError_t launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds
 // kernel launchers (each enqueues on `s` and returns the launch error)
 hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, const rmcv_legacy_params& lp,
                         int mode, bool with_frames, bool pairs, hipStream_t s);
-// wait_seq != 0: frame-level hand-over -- the launch takes each frame when k_binary launch `wait_seq` has finished its rows
 // identity: the frame's armours are classified by the same kernel (RMCV_STAGE_IDENTITY; needs pairs)
-hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, bool identity, int waves, uint32_t wait_seq,
-                         hipStream_t s);
+hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, bool identity, int waves, hipStream_t s);
 hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
-// publish: the launch adds its finished rows to Bufs::frame_ready, writes plane words and row masks through (sc1) and says under
-// label `seq` when it runs (Bufs::started) -- what the frame-level hand-over needs; without it the stores are plain
-hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, uint32_t seq, bool publish,
-                         hipStream_t s);
-hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, uint32_t wait_seq, hipStream_t s);
-int binary_launches(const Geom& g, const Bufs& b); // launches launch_binary makes for this geometry (> 1: no frame-level hand-over)
+hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s);
+hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_blobs_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);

@@ -90,7 +90,6 @@ void rmcv_default_pipeline_config(rmcv_pipeline_config* c)
     c->sparse_waves = 4;
     c->pixel_groups = 2;
     c->host_results = 1;
-    c->handover = 2;
     c->dense_streams = 4;
 }
 
@@ -131,11 +130,10 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
         d.sparse_waves = cfg->sparse_waves > 0 ? cfg->sparse_waves : (d.depth >= 3 ? 4 : 8);
         d.pixel_groups = cfg->pixel_groups > 0 ? cfg->pixel_groups : (d.depth >= 2 ? 2 : 3);
         if (cfg->host_results > 0) d.host_results = cfg->host_results;
-        if (cfg->handover > 0) d.handover = cfg->handover;
         if (cfg->dense_streams != 0) d.dense_streams = cfg->dense_streams;
     }
-    if (d.dense_streams < 0 || d.sparse_waves != 4 || d.handover == 1 || d.host_results != 1) d.dense_streams = 0; // (the deferral exists for the 4-wavefront kernel; the policy reads the host mirror)
-    if (d.depth > 64 || d.pixel_streams > 16 || d.sparse_streams > 16 || d.dense_streams > 16 || d.host_results > 2 || d.handover > 2) return RMCV_ERR_BAD_ARG;
+    if (d.dense_streams < 0 || d.sparse_waves != 4 || d.host_results != 1) d.dense_streams = 0; // (the deferral exists for the 4-wavefront kernel; the policy reads the host mirror)
+    if (d.depth > 64 || d.pixel_streams > 16 || d.sparse_streams > 16 || d.dense_streams > 16 || d.host_results > 2) return RMCV_ERR_BAD_ARG;
     if (d.pixel_streams > d.depth) d.pixel_streams = d.depth;
     if (d.sparse_streams > d.depth) d.sparse_streams = d.depth;
     if (d.dense_streams > d.depth) d.dense_streams = d.depth;
@@ -151,7 +149,6 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
             pl->ring.push_back(c);
             rc = rmcv_ctx_set_option(c, RMCV_OPT_SPARSE_WAVES, d.sparse_waves);
             if (rc == RMCV_OK) rc = rmcv_ctx_set_option(c, RMCV_OPT_PIXEL_GROUPS, d.pixel_groups);
-            if (rc == RMCV_OK && d.handover == 1) rc = rmcv_ctx_set_option(c, RMCV_OPT_HANDOVER, 1);
         }
     }
     if (rc != RMCV_OK) {
@@ -238,7 +235,6 @@ int rmcv_pipeline_get_info(const rmcv_pipeline* pl, rmcv_pipeline_info* o)
     o->sparse_waves = pl->cfg.sparse_waves;
     o->pixel_groups = pl->cfg.pixel_groups;
     o->host_results = pl->cfg.host_results;
-    o->handover = pl->cfg.handover;
     o->dense_streams = pl->cfg.dense_streams;
     o->max_frames = pl->lim.max_frames;
     const char* q = getenv("GPU_MAX_HW_QUEUES");
@@ -301,7 +297,6 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
 {
     if (!pl || !d_frames || !p) return RMCV_ERR_BAD_ARG;
     if (!(stages & RMCV_STAGE_BINARY)) return pfail(pl, RMCV_ERR_BAD_ARG, "a pipelined batch starts at RMCV_STAGE_BINARY");
-    if (stages & RMCV_STAGE_HANDOVER) return pfail(pl, RMCV_ERR_BAD_ARG, "RMCV_STAGE_HANDOVER is the pipeline's own business (rmcv_pipeline_config::handover)");
     hipSetDevice(pl->device);
     const uint64_t t = pl->next_ticket;
     const size_t k = (size_t)(t % (uint64_t)pl->cfg.depth);
@@ -315,11 +310,8 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     if (used) PCHK(pl, hipStreamWaitEvent(A, pl->ev_done[k], 0), "pipeline: wait for the slot");
     rc = rmcv_batch_run(c, p, pixel, A);
     if (rc) return cfail(pl, c, rc);
-    const bool ho = pl->cfg.handover == 1 && sparse;
-    if (!ho) {
-        PCHK(pl, hipEventRecord(pl->ev_bin[k], A), "pipeline: mark the pixel kernel");
-        PCHK(pl, hipStreamWaitEvent(B, pl->ev_bin[k], 0), "pipeline: chain the sparse stages");
-    }
+    PCHK(pl, hipEventRecord(pl->ev_bin[k], A), "pipeline: mark the pixel kernel");
+    PCHK(pl, hipStreamWaitEvent(B, pl->ev_bin[k], 0), "pipeline: chain the sparse stages");
     // Dense frames (beyond findContours' LDS tables: hundreds of borders, 0.5-1 ms on one workgroup) are left by the per-frame launch
     // to a second launch with 8 wavefronts per frame on a stream of its own, the compaction behind it: the sparse stream B is free
     // for the next batch when the batch's ordinary frames are through (one lit window per batch used to cost the whole loop 20-35 %).
@@ -339,8 +331,6 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     // caller mixes stage masks that finish on different streams; then the old stream is drained first)
     if (used && pl->slot_stream[k] && pl->slot_stream[k] != T) PCHK(pl, hipStreamSynchronize(pl->slot_stream[k]), "pipeline: change of the slot's stream");
     if (sparse) {
-        // frame-level hand-over: the sparse kernel is enqueued BESIDE its own pixel kernel and takes each frame when its last strip is
-        // written (the context orders it behind what preceded that pixel kernel)
         if (split) {
             ctx_defer_phase(c, 2); // the first launch only: frames beyond the LDS tables are marked and left alone
             rc = rmcv_batch_run(c, p, sparse & ~RMCV_STAGE_POSE, B);
@@ -352,7 +342,7 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
             }
             ctx_defer_phase(c, 0);
         } else
-            rc = lp ? rmcv_batch_run_legacy(c, p, lp, sparse | (ho ? RMCV_STAGE_HANDOVER : 0), B) : rmcv_batch_run(c, p, sparse | (ho ? RMCV_STAGE_HANDOVER : 0), B);
+            rc = lp ? rmcv_batch_run_legacy(c, p, lp, sparse, B) : rmcv_batch_run(c, p, sparse, B);
         if (rc) return cfail(pl, c, rc);
     }
     // the record is rewritten: a reader on another stream (the hook's) must be through; readers on B are by stream order
@@ -441,7 +431,6 @@ int rmcv_pipeline_collect(rmcv_pipeline* pl, uint64_t ticket, rmcv_armour* armou
     if (n_total) *n_total = total;
     if (frame_offs) memcpy(frame_offs, offs, (size_t)(nf + 1) * 4);
     pl->collected++;
-    if (st & RMCV_FRAME_TIMEOUT) return pfail(pl, RMCV_ERR_HIP, "frame-level hand-over timed out: the pixel kernel of this batch never delivered its planes");
     if (st & (RMCV_FRAME_OVF_CONTOURS | RMCV_FRAME_OVF_POINTS | RMCV_FRAME_OVF_BLOBS | RMCV_FRAME_OVF_ARMOURS))
         return pfail(pl, RMCV_ERR_CAPACITY, "context limits exceeded on at least one frame of the batch (rmcv_batch_counts on the slot's context names it)");
     if (total > pl->cfg.armour_cap) return pfail(pl, RMCV_ERR_CAPACITY, "the batch has more armours than the pipeline's armour_cap");

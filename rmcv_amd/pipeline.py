@@ -16,13 +16,13 @@ from .api import Context
 
 class Pipeline:
     def __init__(self, device=0, depth=0, pixel_streams=0, sparse_streams=0, armour_cap=0, sparse_waves=0, pixel_groups=0,
-                 host_results=0, handover=0, dense_streams=0, **limits):
+                 host_results=0, dense_streams=0, **limits):
         lim = Limits()
         lib().rmcv_default_limits(C.byref(lim))
         for k, v in limits.items():
             setattr(lim, k, v)
         self.limits = lim
-        cfg = PipelineConfig(depth, pixel_streams, sparse_streams, armour_cap, sparse_waves, pixel_groups, host_results, handover, dense_streams, 0)
+        cfg = PipelineConfig(depth, pixel_streams, sparse_streams, armour_cap, sparse_waves, pixel_groups, host_results, dense_streams)
         h = C.c_void_p()
         rc = lib().rmcv_pipeline_create(int(device), C.byref(lim), C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -3,7 +3,7 @@ documents, full path on a small batch, lists compared with the default's byte fo
 import numpy as np
 import pytest
 
-from rmcv_amd import (CAMP_BLUE, OPT_CONTOUR_TIER, OPT_DENSE_DEFER, OPT_HANDOVER, OPT_PIXEL_GROUPS, OPT_PIXEL_HALO_NT,
+from rmcv_amd import (CAMP_BLUE, OPT_CONTOUR_TIER, OPT_DENSE_DEFER, OPT_PIXEL_GROUPS, OPT_PIXEL_HALO_NT,
                       OPT_SPARSE_WAVES, STAGE_ALL, Context, default_params, synth)
 from rmcv_amd.abi import RmcvError
 
@@ -29,7 +29,7 @@ def test_every_option_leaves_the_results_alone():
     c.sync()
     ref = _lists(c)
     cases = [(OPT_SPARSE_WAVES, 4), (OPT_PIXEL_GROUPS, 1), (OPT_PIXEL_GROUPS, 5), (OPT_PIXEL_HALO_NT, 1),
-             (OPT_DENSE_DEFER, 1), (OPT_HANDOVER, 1), (OPT_CONTOUR_TIER, 2)]
+             (OPT_DENSE_DEFER, 1), (OPT_CONTOUR_TIER, 2)]
     for opt, val in cases:
         c.set_option(opt, val)
         if opt == OPT_DENSE_DEFER:
@@ -38,7 +38,7 @@ def test_every_option_leaves_the_results_alone():
         c.sync()
         got = _lists(c)
         assert all(a == b for a, b in zip(got, ref)), (opt, val)
-    for opt, val in ((8, 0), (9, 3), (10, 1),                                   # round 3's measurement knobs: removed
+    for opt, val in ((6, 1), (8, 0), (9, 3), (10, 1),                           # round 3's hand-over and measurement knobs: removed
                      (OPT_PIXEL_HALO_NT, 2), (OPT_DENSE_DEFER, 2), (99, 0)):
         with pytest.raises(RmcvError):
             c.set_option(opt, val)
