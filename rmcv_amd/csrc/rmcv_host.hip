@@ -510,6 +510,20 @@ static int check_params(rmcv_ctx* c, const rmcv_params* p, int stages)
     return RMCV_OK;
 }
 
+namespace rmcv {
+// everything rmcv_batch_run would refuse for this stage mask, WITHOUT enqueuing anything: the pipeline splits a batch into several
+// runs on different streams and must not find out at the second one that the batch cannot run (a pixel kernel already enqueued,
+// nothing ordered behind it)
+int ctx_check_stages(rmcv_ctx* c, const rmcv_params* p, int stages)
+{
+    const int rc = check_params(c, p, stages);
+    if (rc) return rc;
+    if ((stages & RMCV_STAGE_IDENTITY) && !c->bufs.svm_w) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_IDENTITY needs rmcv_svm_load first");
+    if ((stages & RMCV_STAGE_POSE) && !c->bufs.pnp_cfg) return fail(c, RMCV_ERR_BAD_ARG, "RMCV_STAGE_POSE needs rmcv_pnp_load first");
+    return RMCV_OK;
+}
+} // namespace rmcv
+
 extern "C" {
 
 int rmcv_batch_upload(rmcv_ctx* c, const uint8_t* frames, int n_frames, int w, int h, int stride, int64_t frame_pitch)

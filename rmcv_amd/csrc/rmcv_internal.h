@@ -178,6 +178,8 @@ void ctx_external_order(rmcv_ctx* c, hipEvent_t done);
 // rmcv_batch_compact_armours + the batch's OR-ed status word
 int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s, void* hd_record = nullptr, int host_head = 0);
 const Limits& ctx_limits(const rmcv_ctx* c);
+// what rmcv_batch_run would refuse for (p, stages), checked without enqueuing anything
+int ctx_check_stages(rmcv_ctx* c, const rmcv_params* p, int stages);
 // Geom::dense_defer for the runs that follow: 0 off, 1 both launches on the run's stream (RMCV_OPT_DENSE_DEFER), 2 / 3 the first / second only
 void ctx_defer_phase(rmcv_ctx* c, int phase);
 

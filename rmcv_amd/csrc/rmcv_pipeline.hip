@@ -305,6 +305,8 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     const bool used = pl->slot_ticket[k] != 0;
     int rc = rmcv_batch_set_device_frames(c, d_frames, n_frames, w, h, stride, frame_pitch); // (waits for the slot's work when the geometry changes)
     if (rc) return cfail(pl, c, rc);
+    // a batch is several runs on several streams: everything that could refuse it is checked before the first enqueue
+    if ((rc = ctx_check_stages(c, p, stages))) return cfail(pl, c, rc);
     const int pixel = stages & (RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE), sparse = stages & ~(RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE);
     // the slot's context buffers are free once its previous list is compacted
     if (used) PCHK(pl, hipStreamWaitEvent(A, pl->ev_done[k], 0), "pipeline: wait for the slot");

@@ -110,6 +110,11 @@ def test_pipeline_stage_getters_sizes_and_modes(oracle):
         pl.submit(keep[0][1].data_ptr(), 40, 512, 640, p, STAGE_ALL & ~STAGE_BINARY)     # a pipelined batch starts at the pixel kernel
     with pytest.raises(RmcvError):
         pl.submit(keep[0][1].data_ptr(), 41, 512, 640, p, STAGE_ALL)                      # more frames than the ring's contexts hold
+    with pytest.raises(RmcvError):
+        pl.submit(keep[0][1].data_ptr(), 40, 512, 640, p, STAGE_ALL | STAGE_IDENTITY)    # no SVM loaded: refused BEFORE anything is enqueued ...
+    t = pl.submit(keep[0][1].data_ptr(), 40, 512, 640, p, STAGE_ALL)                      # ... so the slot is as it was
+    arm, offs = pl.collect(t)
+    check_batch(oracle, keep[0][0], arm, offs)
     t = pl.submit(keep[0][1].data_ptr(), 40, 512, 640, p, STAGE_BINARY | STAGE_CONTOURS)  # a partial path is fine (its list is the previous run's)
     pl.wait(t)
     pts, co = pl.context_of(t).contours(3)
