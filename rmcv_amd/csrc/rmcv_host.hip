@@ -212,6 +212,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
         c->geom.device = device;
         c->geom.pixel_halo_nt = getenv("RMCV_K1_HALO_NT") ? atoi(getenv("RMCV_K1_HALO_NT")) : 0;
         c->geom.pixel_rowquad = getenv("RMCV_K1_LINEAR") && atoi(getenv("RMCV_K1_LINEAR")) == 0;
+        c->geom.pixel_ws = getenv("RMCV_K1_WS") ? atoi(getenv("RMCV_K1_WS")) : 0;
         c->geom.dense_defer = getenv("RMCV_DENSE_DEFER") ? atoi(getenv("RMCV_DENSE_DEFER")) : 0; // RMCV_OPT_DENSE_DEFER (env: dev A/B knob)
         c->geom.n_cu = (device < MAX_DEVICES && hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
         if (device >= MAX_DEVICES) e = hipErrorInvalidDevice;
@@ -604,6 +605,10 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
     }
     if (option == 1001 && (value == 0 || value == 1)) { // dev (not in the header): k_binary's row-quad loader even where rows are contiguous,
         c->geom.pixel_rowquad = value;                  // for bench.py's RMCV_BENCH_AB=1001:0:1 (one pipeline, regions alternating)
+        return RMCV_OK;
+    }
+    if (option == 1002 && value >= 0 && value <= 32) { // dev: the wave-specialised pixel kernel for whole batches
+        c->geom.pixel_ws = value;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_OVERLOADS && value >= 0 && value <= 3) {

@@ -20,6 +20,7 @@ struct Geom {
     int n_cu;            // compute units of that device (sizes the persistent grid of k_binary)
     int pixel_halo_nt;   // RMCV_OPT_PIXEL_HALO_NT: the row quads a strip shares with its neighbours are loaded non-temporal too
     int pixel_rowquad;   // dev knob (RMCV_K1_LINEAR=0 in the environment when the context is made): k_binary's row-quad loader even where rows are contiguous
+    int pixel_ws;        // dev knob (RMCV_K1_WS in the environment when the context is made, option 1002): whole batches with contiguous rows go to k_binary_ws
     int dense_defer;     // RMCV_OPT_DENSE_DEFER: frames beyond the LDS tables are left to a second launch with 8 wavefronts per frame
     int overloads;       // RMCV_OPT_OVERLOADS: SURVEY A.6, which functions the reference's unqualified abs / atan2 / sin / cos on floats are
     int contour_tier;    // RMCV_OPT_CONTOUR_TIER: 0 = per frame (LDS tables, else mid tier, else literal scanner), 1 = literal, 2 = mid tier
