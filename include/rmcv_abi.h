@@ -177,7 +177,17 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * are the double functions, the arithmetic around them double.  0 (default): the float overloads everywhere.  Changes results --
  * by design: it follows the reference build it replaces.  INTEGRATION.md has the probe that tells which value a build needs. */
 #define RMCV_OPT_OVERLOADS 13
+/* RMCV_OPT_PIXEL_SHAPE: which kernel is the pixel stage of a WHOLE batch whose rows are contiguous (stride == 3 w, w % 64 == 0).
+ * 0 (default): k_binary -- 256-thread workgroups, 2-3 per CU, each loading, thresholding, closing and storing its strip in turn.
+ * 1: k_binary_ws -- ONE 1024-thread workgroup per CU, 8 wavefronts loading strip k+1 while 8 store strip k: 4-7 % faster alone
+ * (6.1-6.2 TB/s of the bare copy's 6.25), but it fills the CU: the 8-wavefront sparse kernel cannot run beside it, and it gains
+ * nothing while the bit planes of more than ~5 contexts take turns (they fall out of the Infinity Cache).  A pipeline switches it
+ * per batch (rmcv_pipeline_config::hot_contexts).  Same results. */
+#define RMCV_OPT_PIXEL_SHAPE 14
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
+/* launches of k_binary_ws (RMCV_OPT_PIXEL_SHAPE 1) by this process so far: a diagnostic -- an option that is set but whose
+ * conditions a batch does not meet falls back to k_binary silently (tests/test_gpu_pixel_shape.py) */
+int64_t rmcv_pixel_ws_launches(void);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */
 int  rmcv_ctx_check_guards(rmcv_ctx* ctx, int32_t* n_damaged);
@@ -392,7 +402,7 @@ int  rmcv_track_step(rmcv_track* tracking, int32_t* n_tracking, int cap, rmcv_tr
  * call preceded the load; rmcv_pipeline_get_info reports what the variable reads. */
 typedef struct rmcv_pipeline rmcv_pipeline;
 typedef struct {            /* 0 in any field = the default; rmcv_default_pipeline_config fills them in */
-    int32_t depth;          /* batches in flight = contexts in the ring                         (8)  */
+    int32_t depth;          /* batches in flight = slots (records, tickets) = contexts in the ring (8)  */
     int32_t pixel_streams;  /*                                                                  (2)  */
     int32_t sparse_streams; /*                                                                  (4)  */
     int32_t armour_cap;     /* armours a batch's compacted list holds                (8 per frame)   */
@@ -407,6 +417,15 @@ typedef struct {            /* 0 in any field = the default; rmcv_default_pipeli
                              * stream goes on with the next batch instead of waiting for a 0.5-1 ms frame (one lit window per batch:
                              * 1.3 x the plain step time without, 1.01 x with).  Batches without such frames, and batches full of them,
                              * run as if this were off.  -1: off                                                              (4)  */
+    int32_t hot_contexts;   /* WHILE the batches are calm -- no frame of the record that last came back went beyond findContours' LDS
+                             * tables, no classifier / pose stage asked for -- the batches take turns at the first `hot_contexts`
+                             * contexts of the ring (slot, record and ticket window stay `depth` deep) and run the wave-specialised pixel
+                             * kernel (RMCV_OPT_PIXEL_SHAPE 1).  What a batch writes with ordinary stores and reads right back -- the
+                             * 46 MB bit plane first of all -- then stays in the 256 MB Infinity Cache instead of going to HBM and
+                             * back: 3-8 % on the plain stream.  A context's next batch waits for its last one's list, so dense
+                             * batches (0.5-1 ms of sparse work) would stall the pixel stream: those run one context per slot, as
+                             * with -1.  Needs host_results = 1.  -1: off                                                     (4)  */
+    int32_t _reserved;
 } rmcv_pipeline_config;
 typedef struct {
     int32_t depth, pixel_streams, sparse_streams, armour_cap, sparse_waves, pixel_groups, host_results, dense_streams;
@@ -418,16 +437,22 @@ typedef struct {
     int64_t armours_offset;    /* = the layout of rmcv_amd/dist.py, the payload of rmcv_gather */
     uint64_t submitted, collected;
     uint64_t dense_split;      /* batches whose dense frames were given a launch and a stream of their own (see dense_streams) */
+    uint64_t hot_batches;      /* batches that ran in one of the hot contexts (see hot_contexts) */
+    int32_t hot_contexts, _pad2;
 } rmcv_pipeline_info;
 void rmcv_default_pipeline_config(rmcv_pipeline_config* c);
 int  rmcv_pipeline_create(int device, const rmcv_limits* limits /* nullable */, const rmcv_pipeline_config* cfg /* nullable */, rmcv_pipeline** out);
 void rmcv_pipeline_destroy(rmcv_pipeline* pl);   /* drains first */
 const char* rmcv_pipeline_last_error(const rmcv_pipeline* pl);
 int  rmcv_pipeline_get_info(const rmcv_pipeline* pl, rmcv_pipeline_info* out);
-/* the context of ring slot `slot` (0 .. depth-1), for set-up that is per context: rmcv_svm_load (RMCV_STAGE_IDENTITY),
- * rmcv_pnp_load (RMCV_STAGE_POSE), rmcv_ctx_set_option; and for the per-stage getters on a ticket that has been waited for
- * (ticket t lives in slot t % depth until ticket t + depth is submitted).  Owned by the pipeline. */
+/* the context of ring slot `slot` (0 .. depth-1), for set-up that is per context -- rmcv_svm_load (RMCV_STAGE_IDENTITY),
+ * rmcv_pnp_load (RMCV_STAGE_POSE), rmcv_ctx_set_option: do it for EVERY slot.  Owned by the pipeline. */
 rmcv_ctx* rmcv_pipeline_context(rmcv_pipeline* pl, int slot);
+/* the context a ticket's batch ran in, for the per-stage getters (binary image, contours, blobs, counts) on a ticket that has been
+ * waited for.  The ticket's RECORD (rmcv_pipeline_collect / _record) lives until ticket + depth is submitted; its context's buffers
+ * only until the context's next batch, which can be as early as ticket + hot_contexts (rmcv_pipeline_config): read them before
+ * submitting that many more.  NULL for a ticket that is not live. */
+rmcv_ctx* rmcv_pipeline_context_of(rmcv_pipeline* pl, uint64_t ticket);
 /* enqueue one batch of n_frames frames that are resident in HBM (layout as rmcv_batch_set_device_frames); stages must include
  * RMCV_STAGE_BINARY.  Asynchronous; *ticket (0, 1, 2, ...) names the batch.  The slot's previous batch (ticket - depth) is
  * overwritten: collect it first. */

@@ -38,6 +38,8 @@ OPT_CONTOUR_TIER = 5
 OPT_DENSE_DEFER = 7
 OPT_PIXEL_HALO_NT = 11
 OPT_OVERLOADS = 13
+OPT_PIXEL_SHAPE = 14
+OPT_PIXEL_SHAPE = 14
 STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE, STAGE_NO_IMAGE = 1, 2, 4, 8, 15, 16, 32, 64
 SVM_FEATURES = 1200
 FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_SLOW_PATH, FRAME_MID_PATH = 1, 2, 4, 8, 16, 64
@@ -51,7 +53,7 @@ EXPORTS = [
     "rmcv_svm_load", "rmcv_classify_armours", "rmcv_batch_get_identities", "rmcv_batch_get_icons",
     "rmcv_default_pnp_config", "rmcv_pnp_load", "rmcv_locate_armours", "rmcv_batch_set_base2gripper", "rmcv_batch_get_poses",
     "rmcv_max_iou", "rmcv_identity_max", "rmcv_comm_unique_id", "rmcv_comm_create", "rmcv_comm_destroy", "rmcv_comm_info", "rmcv_comm_last_error", "rmcv_gather",
-    "rmcv_default_pipeline_config", "rmcv_pipeline_create", "rmcv_pipeline_destroy", "rmcv_pipeline_last_error", "rmcv_pipeline_get_info", "rmcv_pipeline_context",
+    "rmcv_default_pipeline_config", "rmcv_pipeline_create", "rmcv_pipeline_destroy", "rmcv_pipeline_last_error", "rmcv_pipeline_get_info", "rmcv_pipeline_context", "rmcv_pipeline_context_of", "rmcv_pixel_ws_launches",
     "rmcv_pipeline_submit", "rmcv_pipeline_submit_legacy", "rmcv_pipeline_wait", "rmcv_pipeline_collect", "rmcv_pipeline_drain", "rmcv_pipeline_record",
     "rmcv_pipeline_set_hook", "rmcv_pipeline_set_gather", "rmcv_pipeline_gathered", "rmcv_device_alloc", "rmcv_device_free", "rmcv_device_upload", "rmcv_device_download",
     "rmcv_track_init", "rmcv_track_reset", "rmcv_track_update", "rmcv_track_predict", "rmcv_track_step", "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
@@ -87,7 +89,8 @@ class Limits(C.Structure):
 class PipelineConfig(C.Structure):
     """rmcv_pipeline_config (0 in a field = the default)"""
     _fields_ = [("depth", C.c_int32), ("pixel_streams", C.c_int32), ("sparse_streams", C.c_int32), ("armour_cap", C.c_int32),
-                ("sparse_waves", C.c_int32), ("pixel_groups", C.c_int32), ("host_results", C.c_int32), ("dense_streams", C.c_int32)]
+                ("sparse_waves", C.c_int32), ("pixel_groups", C.c_int32), ("host_results", C.c_int32), ("dense_streams", C.c_int32),
+                ("hot_contexts", C.c_int32), ("_reserved", C.c_int32)]
 
 
 class PipelineInfo(C.Structure):
@@ -96,7 +99,7 @@ class PipelineInfo(C.Structure):
                 ("sparse_waves", C.c_int32), ("pixel_groups", C.c_int32), ("host_results", C.c_int32), ("dense_streams", C.c_int32),
                 ("max_frames", C.c_int32), ("hw_queues_env", C.c_int32), ("hw_queues_wanted", C.c_int32), ("_pad", C.c_int32),
                 ("record_bytes", C.c_int64), ("armours_offset", C.c_int64), ("submitted", C.c_uint64), ("collected", C.c_uint64),
-                ("dense_split", C.c_uint64)]
+                ("dense_split", C.c_uint64), ("hot_batches", C.c_uint64), ("hot_contexts", C.c_int32), ("_pad2", C.c_int32)]
 
 
 # rmcv_pipeline_hook: int (*)(void* user, uint64_t ticket, void* d_record, int64_t record_bytes, void* hip_stream, void** done_event)
@@ -128,6 +131,10 @@ def load(path):
     L.rmcv_pipeline_destroy.argtypes = [C.c_void_p]
     L.rmcv_pipeline_context.restype = C.c_void_p
     L.rmcv_pipeline_context.argtypes = [C.c_void_p, C.c_int]
+    L.rmcv_pixel_ws_launches.restype = C.c_int64
+    L.rmcv_pixel_ws_launches.argtypes = []
+    L.rmcv_pipeline_context_of.restype = C.c_void_p
+    L.rmcv_pipeline_context_of.argtypes = [C.c_void_p, C.c_uint64]
     # the call of the timed region: fixed argument types, so that ctypes converts without looking at the Python objects' types
     L.rmcv_pipeline_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
     L.rmcv_pipeline_submit_legacy.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

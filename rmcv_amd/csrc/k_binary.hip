@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #include "rmcv_internal.h"
@@ -459,6 +460,9 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
                 if (ok) word = R[__umul24(s_ + halo, ww) + k];
                 const uint32_t po = ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB;
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, RMCV_K1_PLAIN_PLAUX); // (plain: the sparse kernel of the same batch finds the words in L2)
+                // the two pad words behind the row's last word (always zero), so that the plane's cache lines are written whole: see k_binary_ws.inc
+                const u32x4v z = {0u, 0u, 0u, 0u};
+                __builtin_amdgcn_raw_buffer_store_b128(z, r_plane, ok && k == ww - 1 ? po + 8u : OOB, 0, RMCV_K1_PLAIN_PLAUX);
                 k += k_step;
                 s_ += s_step;
                 if (k >= ww) { k -= ww; s_++; }
@@ -531,6 +535,9 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
 
 #include "k_binary_ws.inc"
 
+static std::atomic<int64_t> g_ws_launches{0};
+int64_t pixel_ws_launches() { return g_ws_launches.load(std::memory_order_relaxed); }
+
 template <int CA, int CB>
 static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound, int morph, bool image, int groups,
                                   hipStream_t s)
@@ -584,46 +591,21 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
             if (ea != hipSuccess) return ea;
             lds_set[g.device][inst] = planes;
         }
-        // whole batches with contiguous rows: the wave-specialised kernel, one large workgroup per CU (k_binary_ws.inc)
-        if (g.pixel_ws && linear && !all_pass && taper_head == 0) {
+        // whole batches with contiguous rows, when the caller asks for it (RMCV_OPT_PIXEL_SHAPE; a pipeline does for its calm batches):
+        // the wave-specialised kernel, ONE 1024-thread workgroup per CU -- 8 loader wavefronts with 3 items in flight each, 8 storers
+        constexpr int WS_NL = 8, WS_NS = 8, WS_RING = 3, WS_AUX = 2 /* nt */;
+        const size_t planes_ws = ((size_t)2 * (SR + 4) + SR) * g.ww * sizeof(uint64_t);
+        if (g.pixel_ws && linear && !all_pass && taper_head == 0 && planes_ws <= 60 * 1024) {
             K1Args ka;
             ka.frames = frames; ka.frame_pitch = g.frame_pitch; ka.stride = g.stride; ka.n_frames = nf; ka.w = g.w; ka.h = g.h; ka.ww = g.ww;
             ka.lb = lb; ka.morph = morph; ka.binary = binary; ka.bits = bits; ka.prow = g.prow; ka.plane_pitch = g.plane_pitch;
-            ka.strips = strips; ka.n_blocks = n_blocks; ka.rowmask = rowmask; ka.strip_ctr = b.strip_ctr; ka.halo_nt = g.pixel_halo_nt;
-            const size_t planes_ws = ((size_t)2 * (SR + 4) + SR) * g.ww * sizeof(uint64_t);
-            auto go = [&](auto kern, int threads, int per_cu) {
-                int grid_ws = ((g.n_cu > 0 ? g.n_cu : 256) * per_cu + 7) & ~7;
-                if (grid_ws > ((n_blocks + 7) & ~7)) grid_ws = (n_blocks + 7) & ~7;
-                return launch(kern, dim3(grid_ws), dim3(threads), planes_ws, s, ka);
-            };
-            if (planes_ws <= 60 * 1024) {
-                hipError_t e;
-                switch (g.pixel_ws) { // (dev: shapes for the A/B; 1 is the one in use)
-                default: e = go(k_binary_ws<CA, CB, 8, 8, 2>, 1024, 1); break;
-                case 2: e = go(k_binary_ws<CA, CB, 8, 8, 3>, 1024, 1); break;
-                case 3: e = go(k_binary_ws<CA, CB, 8, 8, 4>, 1024, 1); break;
-                case 4: e = go(k_binary_ws<CA, CB, 12, 4, 2>, 1024, 1); break;
-                case 5: e = go(k_binary_ws<CA, CB, 8, 4, 2>, 768, 1); break;
-                case 6: e = go(k_binary_ws<CA, CB, 4, 4, 4>, 512, 2); break;
-                case 7: e = go(k_binary_ws<CA, CB, 6, 2, 3>, 512, 2); break;
-                case 8: e = go(k_binary_ws<CA, CB, 10, 4, 2>, 896, 1); break;
-                case 9: e = go(k_binary_wsr<CA, CB, 12, 4, 2>, 1024, 1); break;
-                case 10: e = go(k_binary_wsr<CA, CB, 12, 4, 3>, 1024, 1); break;
-                case 11: e = go(k_binary_wsr<CA, CB, 8, 8, 3>, 1024, 1); break;
-                case 12: e = go(k_binary_wsr<CA, CB, 8, 4, 3>, 768, 1); break;
-                case 13: e = go(k_binary_wsr<CA, CB, 10, 4, 3>, 896, 1); break;
-                case 14: e = go(k_binary_wsr<CA, CB, 8, 4, 4>, 768, 1); break;
-                case 15: e = go(k_binary_wsr<CA, CB, 8, 4, 2>, 768, 1); break;
-                case 16: e = go(k_binary_wsr<CA, CB, 8, 8, 2>, 1024, 1); break;
-                case 17: e = go(k_binary_wsr<CA, CB, 12, 4, 4>, 1024, 1); break;
-                case 18: e = go(k_binary_wsr<CA, CB, 8, 8, 4>, 1024, 1); break;
-                case 19: e = go(k_binary_wsr<CA, CB, 12, 4, 3, 0>, 1024, 1); break;
-                case 20: e = go(k_binary_wsr<CA, CB, 8, 8, 3, 0>, 1024, 1); break;
-                case 21: e = go(k_binary_wsr<CA, CB, 8, 8, 5>, 1024, 1); break;
-                }
-                if (e != hipSuccess) return e;
-                continue;
-            }
+            ka.strips = strips; ka.n_blocks = n_blocks; ka.rowmask = rowmask; ka.strip_ctr = b.strip_ctr;
+            int grid_ws = ((g.n_cu > 0 ? g.n_cu : 256) + 7) & ~7;
+            if (grid_ws > ((n_blocks + 7) & ~7)) grid_ws = (n_blocks + 7) & ~7;
+            g_ws_launches.fetch_add(1, std::memory_order_relaxed);
+            const hipError_t e = launch(k_binary_ws<CA, CB, WS_NL, WS_NS, WS_RING, WS_AUX>, dim3(grid_ws), dim3((WS_NL + WS_NS) * 64), planes_ws, s, ka);
+            if (e != hipSuccess) return e;
+            continue;
         }
 #define RMCV_K1_LAUNCH(F)                                                                                                             \
     launch(k_binary<CA, CB, F>, dim3(grid), dim3(256), planes, s, frames, g.frame_pitch, g.stride, nf, g.w, g.h, g.ww, lb, all_pass, \

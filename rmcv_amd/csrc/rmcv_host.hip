@@ -33,6 +33,8 @@ struct rmcv_ctx {
     int order_n = -1, order_h = -1; // (n_frames, h) the frame order on the device was computed for
     hipEvent_t ev_order = nullptr; // recorded behind the work enqueued last: a call on ANOTHER stream first waits for it
     bool order_pending = false;
+    uint64_t* own_bits = nullptr;  // the context's own foreground plane and row masks (bufs.bits / bufs.rowmask may point at another context's:
+    uint32_t* own_rowmask = nullptr; // rmcv_internal.h: ctx_use_planes)
     bool external_order = false;  // a pipeline owns the ordering of this context's launches (rmcv_internal.h: ctx_external_order)
     hipEvent_t ext_done = nullptr; // ... and records this event behind the last of them
     // ---- per-frame drop-in path (rmcv_extract_color -> rmcv_filter_lightblobs -> rmcv_filter_armours, executable/main.cpp:172-176)
@@ -127,6 +129,7 @@ static hipError_t dalloc_named(rmcv_ctx* c, T** p, size_t count, const char* nam
 extern "C" {
 
 int rmcv_abi_version(void) { return RMCV_ABI_VERSION; }
+int64_t rmcv_pixel_ws_launches(void) { return pixel_ws_launches(); }
 
 void rmcv_default_params(rmcv_params* p)
 { // the literals of executable/main.cpp:172-176
@@ -212,7 +215,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
         c->geom.device = device;
         c->geom.pixel_halo_nt = getenv("RMCV_K1_HALO_NT") ? atoi(getenv("RMCV_K1_HALO_NT")) : 0;
         c->geom.pixel_rowquad = getenv("RMCV_K1_LINEAR") && atoi(getenv("RMCV_K1_LINEAR")) == 0;
-        c->geom.pixel_ws = getenv("RMCV_K1_WS") ? atoi(getenv("RMCV_K1_WS")) : 0;
+        c->geom.pixel_ws = 0;
         c->geom.dense_defer = getenv("RMCV_DENSE_DEFER") ? atoi(getenv("RMCV_DENSE_DEFER")) : 0; // RMCV_OPT_DENSE_DEFER (env: dev A/B knob)
         c->geom.n_cu = (device < MAX_DEVICES && hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
         if (device >= MAX_DEVICES) e = hipErrorInvalidDevice;
@@ -223,6 +226,8 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
     if (e == hipSuccess) e = dalloc(c, &b.binary, F * d.max_width * d.max_height);
     if (e == hipSuccess) e = dalloc(c, &b.bits, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.rowmask, F * d.max_height);
+    c->own_bits = b.bits;
+    c->own_rowmask = b.rowmask;
     if (e == hipSuccess) e = dalloc(c, &b.strip_ctr, 9 * CTR_STRIDE);
     if (e == hipSuccess) e = dalloc(c, &b.lab, F * plane);
     if (e == hipSuccess) e = dalloc(c, &b.neg, F * plane);
@@ -281,6 +286,13 @@ void ctx_external_order(rmcv_ctx* c, hipEvent_t done)
     c->ext_done = done;
 }
 const Limits& ctx_limits(const rmcv_ctx* c) { return c->lim; }
+void ctx_pixel_shape(rmcv_ctx* c, int shape) { c->geom.pixel_ws = shape ? 1 : 0; }
+void ctx_planes(rmcv_ctx* c, uint64_t** bits, uint32_t** rowmask) { *bits = c->own_bits; *rowmask = c->own_rowmask; }
+void ctx_use_planes(rmcv_ctx* c, uint64_t* bits, uint32_t* rowmask)
+{
+    c->bufs.bits = bits ? bits : c->own_bits;
+    c->bufs.rowmask = rowmask ? rowmask : c->own_rowmask;
+}
 void ctx_defer_phase(rmcv_ctx* c, int phase) { c->geom.dense_defer = phase; }
 int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s, void* hd_record, int host_head)
 {
@@ -386,7 +398,7 @@ static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t
     g.plane_pitch = (int64_t)(h + 2) * g.prow;
     if (c->geom_w != w || c->geom_h != h) {
         const size_t plane = (size_t)(c->lim.max_height + 2) * ((c->lim.max_width + 63) / 64 + 2);
-        HIPCHK(c, hipMemsetAsync(c->bufs.bits, 0, (size_t)c->lim.max_frames * plane * 8, c->stream), "memset planes");
+        HIPCHK(c, hipMemsetAsync(c->own_bits, 0, (size_t)c->lim.max_frames * plane * 8, c->stream), "memset planes");
         HIPCHK(c, hipMemsetAsync(c->bufs.lab, 0, (size_t)c->lim.max_frames * plane * 8, c->stream), "memset planes");
         HIPCHK(c, hipMemsetAsync(c->bufs.neg, 0, (size_t)c->lim.max_frames * plane * 8, c->stream), "memset planes");
         HIPCHK(c, hipStreamSynchronize(c->stream), "memset planes");
@@ -607,7 +619,7 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         c->geom.pixel_rowquad = value;                  // for bench.py's RMCV_BENCH_AB=1001:0:1 (one pipeline, regions alternating)
         return RMCV_OK;
     }
-    if (option == 1002 && value >= 0 && value <= 32) { // dev: the wave-specialised pixel kernel for whole batches
+    if (option == RMCV_OPT_PIXEL_SHAPE && (value == 0 || value == 1)) {
         c->geom.pixel_ws = value;
         return RMCV_OK;
     }

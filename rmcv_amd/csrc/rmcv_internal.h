@@ -20,7 +20,7 @@ struct Geom {
     int n_cu;            // compute units of that device (sizes the persistent grid of k_binary)
     int pixel_halo_nt;   // RMCV_OPT_PIXEL_HALO_NT: the row quads a strip shares with its neighbours are loaded non-temporal too
     int pixel_rowquad;   // dev knob (RMCV_K1_LINEAR=0 in the environment when the context is made): k_binary's row-quad loader even where rows are contiguous
-    int pixel_ws;        // dev knob (RMCV_K1_WS in the environment when the context is made, option 1002): whole batches with contiguous rows go to k_binary_ws
+    int pixel_ws;        // RMCV_OPT_PIXEL_SHAPE: whole batches with contiguous rows go to k_binary_ws (one 1024-thread workgroup per CU)
     int dense_defer;     // RMCV_OPT_DENSE_DEFER: frames beyond the LDS tables are left to a second launch with 8 wavefronts per frame
     int overloads;       // RMCV_OPT_OVERLOADS: SURVEY A.6, which functions the reference's unqualified abs / atan2 / sin / cos on floats are
     int contour_tier;    // RMCV_OPT_CONTOUR_TIER: 0 = per frame (LDS tables, else mid tier, else literal scanner), 1 = literal, 2 = mid tier
@@ -130,6 +130,7 @@ inline hipError_t launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds
     return launch_tuple(kernel, grid, block, lds, s, vals, std::index_sequence_for<P...>{});
 }
 
+int64_t pixel_ws_launches(); // launches of k_binary_ws by this process (rmcv_pixel_ws_launches)
 // kernel launchers (each enqueues on `s` and returns the launch error)
 hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, const rmcv_legacy_params& lp,
                         int mode, bool with_frames, bool pairs, hipStream_t s);
@@ -179,6 +180,13 @@ void ctx_external_order(rmcv_ctx* c, hipEvent_t done);
 // rmcv_batch_compact_armours + the batch's OR-ed status word
 int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s, void* hd_record = nullptr, int host_head = 0);
 const Limits& ctx_limits(const rmcv_ctx* c);
+// The foreground plane + row masks a context's pixel kernel writes and its sparse kernel reads: its own, or -- for the batches to come --
+// another context's of the same limits (a pipeline keeps FEWER planes in rotation than contexts: rmcv_pipeline.hip).  The caller orders
+// the users of a plane; a context zeroes only its OWN plane when the frame geometry changes.
+void ctx_planes(rmcv_ctx* c, uint64_t** bits, uint32_t** rowmask);
+// 1: whole batches with contiguous rows go to the wave-specialised pixel kernel (k_binary_ws.inc), 0: k_binary
+void ctx_pixel_shape(rmcv_ctx* c, int shape);
+void ctx_use_planes(rmcv_ctx* c, uint64_t* bits, uint32_t* rowmask);
 // what rmcv_batch_run would refuse for (p, stages), checked without enqueuing anything
 int ctx_check_stages(rmcv_ctx* c, const rmcv_params* p, int stages);
 // Geom::dense_defer for the runs that follow: 0 off, 1 both launches on the run's stream (RMCV_OPT_DENSE_DEFER), 2 / 3 the first / second only

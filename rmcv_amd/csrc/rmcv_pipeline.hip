@@ -43,6 +43,20 @@ struct rmcv_pipeline {
     std::vector<int> slot_frames;
     std::vector<hipStream_t> slot_stream; // the stream the slot's record was finished on
     uint64_t next_ticket = 0, collected = 0;
+    // Contexts in rotation.  What a batch writes with ordinary stores and reads back right away -- the pixel kernel's bit plane
+    // (46 MB per batch at 1280x1024), the sparse kernel's planes, points and tables -- LIVES in the 256 MB Infinity Cache while few
+    // enough contexts take turns: with 4 the bit planes are never written to HBM at all; with 8 every one of their cache lines is a
+    // miss and the pixel kernel runs 3-15 % slower (profiles/r04f_*).  So while the batches are CALM (no frame of the record that last
+    // came back went beyond findContours' LDS tables, and no classifier / pose stage is asked for) the batches use the first `hot`
+    // contexts in turn -- the slot (record, events, streams, ticket window) is still one of `depth` -- and the wave-specialised pixel
+    // kernel, which wants its CU to itself.  A context's next batch waits for its last one's list (ev_done of that slot): `hot` batches
+    // back instead of `depth`, slack enough for sparse frames, a stall of the pixel stream for a batch of dense ones (0.5-1 ms of
+    // sparse work) -- those run as before: every slot its own context, k_binary, the ring's full depth as slack.
+    int hot = 0;                        // contexts in rotation while calm (0: a slot always uses its own)
+    bool calm = false;
+    uint64_t hot_seq = 0, hot_batches = 0;
+    std::vector<int> ctx_last;          // per context: the slot of its last batch (-1: none)
+    std::vector<int> slot_ctx;          // per slot: the context of its batch
     bool split_now = false;            // the batches of the moment have a FEW dense frames: give those a launch and a stream of their own
     uint64_t split_batches = 0;        // batches submitted that way
     rmcv_pipeline_hook hook = nullptr;
@@ -91,6 +105,7 @@ void rmcv_default_pipeline_config(rmcv_pipeline_config* c)
     c->pixel_groups = 2;
     c->host_results = 1;
     c->dense_streams = 4;
+    c->hot_contexts = 4;   // measured (round 4, process against process on five boxes): 4 < 5 << 3, 6; 0.236-0.243 against 0.244-0.268 ms per step
 }
 
 void rmcv_pipeline_destroy(rmcv_pipeline* pl)
@@ -131,12 +146,16 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
         d.pixel_groups = cfg->pixel_groups > 0 ? cfg->pixel_groups : (d.depth >= 2 ? 2 : 3);
         if (cfg->host_results > 0) d.host_results = cfg->host_results;
         if (cfg->dense_streams != 0) d.dense_streams = cfg->dense_streams;
+        if (cfg->hot_contexts != 0) d.hot_contexts = cfg->hot_contexts;
     }
     if (d.dense_streams < 0 || d.sparse_waves != 4 || d.host_results != 1) d.dense_streams = 0; // (the deferral exists for the 4-wavefront kernel; the policy reads the host mirror)
     if (d.depth > 64 || d.pixel_streams > 16 || d.sparse_streams > 16 || d.dense_streams > 16 || d.host_results > 2) return RMCV_ERR_BAD_ARG;
     if (d.pixel_streams > d.depth) d.pixel_streams = d.depth;
     if (d.sparse_streams > d.depth) d.sparse_streams = d.depth;
     if (d.dense_streams > d.depth) d.dense_streams = d.depth;
+    // (what came back is read from the records' host mirror; fewer than 3 in rotation stall even sparse batches; the 4-wavefront sparse
+    // kernel is the one that fits beside the wave-specialised pixel kernel)
+    if (d.hot_contexts < 3 || d.hot_contexts >= d.depth || d.host_results != 1 || d.sparse_waves != 4) d.hot_contexts = 0;
     rmcv_pipeline* pl = new (std::nothrow) rmcv_pipeline();
     if (!pl) return RMCV_ERR_NOMEM;
     pl->device = device;
@@ -212,6 +231,9 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
         if (e == hipSuccess) ctx_external_order(pl->ring[(size_t)k], b);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_gather, hipEventDisableTiming);
+    pl->ctx_last.assign((size_t)d.depth, -1);
+    pl->slot_ctx.assign((size_t)d.depth, 0);
+    pl->hot = d.hot_contexts;
     if (e != hipSuccess) {
         fprintf(stderr, "rmcv_pipeline_create: %s\n", hipGetErrorString(e));
         (void)hipGetLastError();
@@ -245,6 +267,8 @@ int rmcv_pipeline_get_info(const rmcv_pipeline* pl, rmcv_pipeline_info* o)
     o->submitted = pl->next_ticket;
     o->collected = pl->collected;
     o->dense_split = pl->split_batches;
+    o->hot_batches = pl->hot_batches;
+    o->hot_contexts = pl->hot;
     return RMCV_OK;
 }
 
@@ -252,6 +276,14 @@ rmcv_ctx* rmcv_pipeline_context(rmcv_pipeline* pl, int slot)
 {
     if (!pl || slot < 0 || slot >= pl->cfg.depth) return nullptr;
     return pl->ring[(size_t)slot];
+}
+
+static int slot_of(rmcv_pipeline* pl, uint64_t ticket);
+rmcv_ctx* rmcv_pipeline_context_of(rmcv_pipeline* pl, uint64_t ticket)
+{
+    if (!pl) return nullptr;
+    const int k = slot_of(pl, ticket);
+    return k < 0 ? nullptr : pl->ring[(size_t)pl->slot_ctx[(size_t)k]];
 }
 
 int rmcv_pipeline_set_hook(rmcv_pipeline* pl, rmcv_pipeline_hook fn, void* user)
@@ -300,16 +332,35 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     hipSetDevice(pl->device);
     const uint64_t t = pl->next_ticket;
     const size_t k = (size_t)(t % (uint64_t)pl->cfg.depth);
-    rmcv_ctx* c = pl->ring[k];
-    hipStream_t A = pl->pix[(size_t)(t % (uint64_t)pl->cfg.pixel_streams)], B = pl->sp[k % (size_t)pl->cfg.sparse_streams];
     const bool used = pl->slot_ticket[k] != 0;
-    int rc = rmcv_batch_set_device_frames(c, d_frames, n_frames, w, h, stride, frame_pitch); // (waits for the slot's work when the geometry changes)
+    if (pl->hot) { // the newest record that has come back: did any of its frames go beyond the LDS tables?
+        for (uint64_t d = 1; d <= (uint64_t)pl->cfg.depth && d <= t; d++) {
+            const size_t s_ = (size_t)((t - d) % (uint64_t)pl->cfg.depth);
+            if (pl->slot_ticket[s_] != t - d + 1 || !pl->h_rec[s_]) break;
+            if (hipEventQuery(pl->ev_done[s_]) != hipSuccess) continue;
+            pl->calm = reinterpret_cast<const int32_t*>(pl->h_rec[s_])[pl->lim.max_frames + 2] == 0;
+            break;
+        }
+        (void)hipGetLastError(); // (hipErrorNotReady is not an error)
+    }
+    const bool fast = pl->hot && pl->calm && !lp && !(stages & (RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE));
+    const size_t j = fast ? (size_t)(pl->hot_seq++ % (uint64_t)pl->hot) : k;
+    if (fast) pl->hot_batches++;
+    rmcv_ctx* c = pl->ring[j];
+    hipStream_t A = pl->pix[(size_t)(t % (uint64_t)pl->cfg.pixel_streams)], B = pl->sp[k % (size_t)pl->cfg.sparse_streams];
+    int rc;
+    rc = rmcv_batch_set_device_frames(c, d_frames, n_frames, w, h, stride, frame_pitch); // (waits for the slot's work when the geometry changes)
     if (rc) return cfail(pl, c, rc);
     // a batch is several runs on several streams: everything that could refuse it is checked before the first enqueue
     if ((rc = ctx_check_stages(c, p, stages))) return cfail(pl, c, rc);
     const int pixel = stages & (RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE), sparse = stages & ~(RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE);
     // the slot's context buffers are free once its previous list is compacted
     if (used) PCHK(pl, hipStreamWaitEvent(A, pl->ev_done[k], 0), "pipeline: wait for the slot");
+    if (pl->ctx_last[j] >= 0 && pl->ctx_last[j] != (int)k) PCHK(pl, hipStreamWaitEvent(A, pl->ev_done[(size_t)pl->ctx_last[j]], 0), "pipeline: wait for the context");
+    pl->ctx_last[j] = (int)k;
+    pl->slot_ctx[k] = (int)j;
+    ctx_external_order(c, pl->ev_done[k]);
+    ctx_pixel_shape(c, fast ? 1 : 0);
     rc = rmcv_batch_run(c, p, pixel, A);
     if (rc) return cfail(pl, c, rc);
     PCHK(pl, hipEventRecord(pl->ev_bin[k], A), "pipeline: mark the pixel kernel");

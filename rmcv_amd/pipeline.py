@@ -16,13 +16,13 @@ from .api import Context
 
 class Pipeline:
     def __init__(self, device=0, depth=0, pixel_streams=0, sparse_streams=0, armour_cap=0, sparse_waves=0, pixel_groups=0,
-                 host_results=0, dense_streams=0, **limits):
+                 host_results=0, dense_streams=0, hot_contexts=0, **limits):
         lim = Limits()
         lib().rmcv_default_limits(C.byref(lim))
         for k, v in limits.items():
             setattr(lim, k, v)
         self.limits = lim
-        cfg = PipelineConfig(depth, pixel_streams, sparse_streams, armour_cap, sparse_waves, pixel_groups, host_results, dense_streams)
+        cfg = PipelineConfig(depth, pixel_streams, sparse_streams, armour_cap, sparse_waves, pixel_groups, host_results, dense_streams, hot_contexts, 0)
         h = C.c_void_p()
         rc = lib().rmcv_pipeline_create(int(device), C.byref(lim), C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -100,7 +100,13 @@ class Pipeline:
 
     def context_of(self, ticket):
         """the Context view of the slot a (waited-for) ticket lives in: per-stage getters (binary, contours, blobs, counts)"""
-        return self.contexts[ticket % self.depth]
+        h = self._lib.rmcv_pipeline_context_of(self._h, int(ticket))
+        if not h:
+            raise RmcvError(abi.ERR_BAD_ARG, "ticket %d is not live" % ticket)
+        for c in self.contexts:
+            if c._h.value == h:
+                return c
+        raise RmcvError(abi.ERR_BAD_ARG, "unknown context")
 
     def record(self, ticket):
         """(device pointer of the ticket's record, hipStream_t it is produced on) as ints"""

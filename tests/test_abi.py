@@ -96,10 +96,10 @@ def test_pipeline_entry_points_without_a_gpu():
     import torch
     from rmcv_amd import abi
     L = abi.lib()
-    assert C.sizeof(abi.PipelineConfig) == 32 and C.sizeof(abi.PipelineInfo) == 88
+    assert C.sizeof(abi.PipelineConfig) == 40 and C.sizeof(abi.PipelineInfo) == 104
     cfg = abi.PipelineConfig()
     L.rmcv_default_pipeline_config(C.byref(cfg))
-    assert (cfg.depth, cfg.pixel_streams, cfg.sparse_streams, cfg.sparse_waves, cfg.pixel_groups, cfg.host_results, cfg.dense_streams) == (8, 2, 4, 4, 2, 1, 4)
+    assert (cfg.depth, cfg.pixel_streams, cfg.sparse_streams, cfg.sparse_waves, cfg.pixel_groups, cfg.host_results, cfg.dense_streams, cfg.hot_contexts) == (8, 2, 4, 4, 2, 1, 4, 4)
     h = C.c_void_p()
     assert L.rmcv_pipeline_create(0, None, None, None) == abi.ERR_BAD_ARG
     t = C.c_uint64(0)

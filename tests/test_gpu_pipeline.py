@@ -77,6 +77,11 @@ def test_24_distinct_batches_through_a_depth_8_pipeline(oracle, one_dense, dense
     # where there are some
     split = pl.get_info().dense_split
     assert (split >= nb - 2 * 8) if (one_dense and dense_streams >= 0) else split == 0
+    # calm batches (no frame beyond the LDS tables in what came back) take turns at four contexts and run the wave-specialised pixel
+    # kernel -- from the second ring cycle on; a stream with a dense frame in every batch never does
+    hot = pl.get_info().hot_batches
+    assert pl.get_info().hot_contexts == 4
+    assert (hot >= nb - 2 * 8) if not one_dense else hot == 0
     pl.close()
 
 
@@ -302,3 +307,43 @@ def test_pipeline_gathers_single_rank(oracle):
         pl.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_calm_and_dense_batches_in_turn(oracle):
+    """a stream that changes character -- plain batches, then batches full of dense frames, then plain again: the pipeline moves between
+    four contexts in rotation (+ the wave-specialised pixel kernel) and one context per slot; every list equals the oracle's, and a
+    waited-for ticket's context holds THAT batch's stages"""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, w, h = 64, 1280, 1024
+    pl = Pipeline(device=0, max_frames=n, max_width=w, max_height=h, max_contours=4096)
+    assert pl.info.depth == 8 and pl.info.hot_contexts == 4
+    p = default_params()
+    kinds = [0] * 12 + [14] * 5 + [1] * 14 + [14] * 3 + [0] * 10
+    ws0 = abi.lib().rmcv_pixel_ws_launches()
+    host, devf, got = [], [], {}
+    for i, kind in enumerate(kinds):
+        fr = synth.batch(770000 + 31 * i, n, w, h, CAMP_BLUE, kind if kind != 14 else 0, threads=16)
+        if kind == 14:
+            fr[::5] = synth.batch(880000 + i, len(fr[::5]), w, h, CAMP_BLUE, 14, threads=16)
+        host.append(fr)
+        devf.append(torch.from_numpy(fr).to(dev))
+        t = pl.submit(devf[i].data_ptr(), n, h, w, p, STAGE_ALL)
+        if i % 7 == 3:                                                # now and then: wait and look at the batch's own context
+            pl.wait(t)
+            c = pl.context_of(t)
+            r = oracle.detect_frame(fr[n // 2])
+            pts, co = c.contours(n // 2)
+            assert np.array_equal(co, r["offs"]) and np.array_equal(pts, r["pts"])
+            assert np.array_equal(c.binary(n // 2), r["binary"])
+        if i >= 7:
+            got[i - 7] = pl.collect(i - 7)
+    pl.drain()
+    for i in range(len(kinds) - 7, len(kinds)):
+        got[i] = pl.collect(i)
+    for i in range(len(kinds)):
+        check_batch(oracle, host[i], *got[i])
+    info = pl.get_info()
+    assert 10 <= info.hot_batches <= len(kinds) - 1 - 6               # most ran hot; the first one and the dense ones (but for the first of a run) did not
+    assert abi.lib().rmcv_pixel_ws_launches() - ws0 == info.hot_batches
+    pl.close()

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <chrono>
 #include <vector>
@@ -93,11 +94,13 @@ __global__ __launch_bounds__((NL + NS) * 64) void k31_pipe(const u32x4* __restri
         __syncthreads();
     }
 }
-int main()
+int main(int argc, char** argv)
 {
     const size_t out_bytes = 256ull * 1280 * 1024, in_bytes = 3 * out_bytes, n = out_bytes / 16;
-    const int MAXS = 4;
-    u32x4 *in[MAXS], *out[MAXS];
+    const int MAXS = argc > 1 ? atoi(argv[1]) : 4; // buffer pairs the launches rotate over
+    const bool quick = argc > 2;
+    u32x4 *in[16], *out[16];
+    printf("%d buffer pairs (%.1f GB)\n", MAXS, MAXS * (in_bytes + out_bytes) / 1e9);
     for (int s = 0; s < MAXS; s++) {
         hipMalloc(&in[s], in_bytes + (1 << 20));
         hipMalloc(&out[s], out_bytes + (1 << 20));
@@ -163,6 +166,12 @@ int main()
     run("3:1 chunks U4", 1, 256, 512, 1, 2560, 0);
     run("3:1 chunks U4", 1, 256, 1024, 1, 2560, 0);
     run("3:1 chunks U4", 1, 512, 512, 1, 2560, 0);
+    if (quick) {
+        run("pipe 8 loaders + 8 storers U2", 1, 256, 1024, 2, 2560, 0);
+        run("pipe 8 loaders + 8 storers U2", 1, 256, 1024, 2, 2560, 8);
+        run("pipe 8 loaders + 8 storers U2", 2, 256, 1024, 2, 2560, 8);
+        return 0;
+    }
     for (int pause : {0, 8, 16}) {
         run("pipe 8 loaders + 8 storers U2", 1, 256, 1024, 2, 2560, pause);
         run("pipe 12 loaders + 4 storers U2", 1, 256, 1024, 3, 2560, pause);
