@@ -88,6 +88,8 @@ def parse_args(argv=None):
     ap.add_argument("--dense-streams", type=int, default=0,
                     help="streams for the second, 8-wavefront launch that takes a batch's frames beyond findContours' LDS tables "
                          "(rmcv_pipeline_config::dense_streams; 0: the library's default, 2; -1: no such launch)")
+    ap.add_argument("--hot-contexts", type=int, default=0,
+                    help="rmcv_pipeline_config::hot_contexts: contexts the calm batches take turns at (0 = the library's default of 4, -1 = off)")
     ap.add_argument("--device-results", action="store_true",
                     help="leave the armour lists in HBM (rmcv_pipeline_config::host_results = 2) instead of copying every step's to pinned host memory")
     ap.add_argument("--gather", choices=("auto", "torch", "abi"), default="auto",
@@ -177,7 +179,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, OPT_PIXEL_GROUPS, OPT_SPARSE_WAVES, STAGE_ALL, STAGE_BINARY,
+    from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, OPT_PIXEL_GROUPS, OPT_PIXEL_SHAPE, OPT_SPARSE_WAVES, STAGE_ALL, STAGE_BINARY,
                           STAGE_IDENTITY, STAGE_NO_IMAGE, STAGE_POSE, Context, LegacyParams, Pipeline, default_params, synth)
     from rmcv_amd import dist as rdist
 
@@ -225,7 +227,7 @@ def main():
         pl = Pipeline(device=local_rank, depth=depth, pixel_streams=pix, sparse_streams=sp, armour_cap=n * 8,
                       sparse_waves=int(knobs.get("RMCV_SPARSE_WAVES", 0)), pixel_groups=int(knobs.get("RMCV_PIXEL_GROUPS", 0)),
                       host_results=host_results or (2 if args.device_results else 1),
-                      dense_streams=dense or args.dense_streams,
+                      dense_streams=dense or args.dense_streams, hot_contexts=args.hot_contexts,
                       max_frames=n, max_width=w, max_height=h, max_contours=mc)
         for c in pl.contexts:
             if with_svm:
@@ -264,11 +266,17 @@ def main():
         hook = rdist.TorchGatherHook(info.record_bytes, ns, dev)
         pl.set_hook(hook)
 
+    # the kernel that moves the algorithmic 4 B/px in the steps: k_binary_ws in the contexts that take turns while the batches are calm
+    # (rmcv_pipeline_config::hot_contexts), k_binary where that is off or does not apply (a classifier / pose stage, the legacy blob stage)
+    hot_mode = info.hot_contexts > 0 and legacy is None and not (stages & (STAGE_IDENTITY | STAGE_POSE))
+    roof_kernel = "k_binary_ws" if hot_mode else "k_binary"
+    roof_ctxs = pl.contexts[:info.hot_contexts] if hot_mode else pl.contexts
+
     if args.roofline_only:
-        ctxs = pl.contexts
-        for k, c in enumerate(ctxs):
-            c.bind_device_frames(frames_k[k % n_sets].data_ptr(), n, H, W)
+        ctxs = roof_ctxs
+        for c in ctxs:
             c.set_option(OPT_PIXEL_GROUPS, 3)
+            c.set_option(OPT_PIXEL_SHAPE, 1 if hot_mode else 0)
         stream = torch.cuda.Stream(device=dev)
         sh, R, each = stream.cuda_stream, 20, []
         for rep in range(4):                                         # the first repeat is the warm-up (clocks, code objects)
@@ -277,15 +285,19 @@ def main():
             with torch.cuda.stream(stream):
                 e0.record(stream)
                 for i in range(R):
-                    ctxs[(rep * R + i) % len(ctxs)].run(params, STAGE_BINARY, sh)
+                    c = ctxs[(rep * R + i) % len(ctxs)]
+                    c.bind_device_frames(frames_k[(rep * R + i) % n_sets].data_ptr(), n, H, W)
+                    c.run(params, STAGE_BINARY, sh)
                 e1.record(stream)
             torch.cuda.synchronize()
             each.append(e0.elapsed_time(e1) / R)
         ms = sorted(each[1:])[1]
-        print(json.dumps({"roofline_only": True, "kernel": "k_binary", "workgroups_per_cu": 3, "launches": 4 * R, "avg_launch_ms_each_repeat": [round(x, 4) for x in each],
+        print(json.dumps({"roofline_only": True, "kernel": roof_kernel, "workgroups_per_cu": 1 if hot_mode else 3, "contexts_rotated": len(ctxs), "frame_sets_rotated": n_sets,
+                          "launches": 4 * R, "avg_launch_ms_each_repeat": [round(x, 4) for x in each],
                           "avg_launch_ms": round(ms, 4), "achieved_GBps": round(n * BYTES_PER_FRAME / (ms * 1e-3) / 1e9, 1),
                           "frac": round(n * BYTES_PER_FRAME / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME,
-                          "note": "cold: every launch on another context's frames and buffers, one stream, HIP events around each 20 launches"}), flush=True)
+                          "note": "cold: every launch reads another frame set; its context's buffers were last written %d launches ago (the contexts the "
+                                  "steps' batches take turns at); one stream, HIP events around each 20 launches" % len(ctxs)}), flush=True)
         pl.close()
         return
 
@@ -317,17 +329,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    hot_each = []                                              # batches of each region that ran in a hot context
+
     def regions(steps, repeats):
         """`repeats` regions of exactly `steps` steps between barrier + synchronize pairs -> (wall seconds each, host enqueue seconds each)"""
         rep, enq = [], []
         for _ in range(repeats):
             barrier()
+            h0 = cur["pl"].get_info().hot_batches
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
             enq.append(time.perf_counter() - t0)       # host time to enqueue the region's steps (the GPU may still be running them)
             barrier()
             rep.append(agree_max(time.perf_counter() - t0))
+            hot_each.append(int(cur["pl"].get_info().hot_batches - h0))
         return rep, enq
 
     def median(x):
@@ -352,7 +368,9 @@ def main():
         barrier()
     # the timed region: EXACTLY --steps steps between two (barrier + synchronize), MAX over ranks; repeated --repeats times,
     # value = the median repeat (median and min over the passes)
+    del hot_each[:]
     rep_dt, enq_dt = regions(args.steps, max(1, args.repeats))
+    hot_timed = list(hot_each)
     dt = median(rep_dt)
     ms_per_step = dt / args.steps * 1e3
     value = world * n * args.steps / dt
@@ -518,22 +536,34 @@ def main():
     # event/launch latency amortised: the figure is the kernel's duration, the quantity rocprofv3 --kernel-trace reports)
     R = 20
 
-    def k_binary_alone(groups, rotate=True):
+    rot_r = [0]
+
+    def k_binary_alone(groups, rotate=True, shape=0):
+        """R launches back to back; cold: each reads another frame set, in the contexts the steps' batches take turns at"""
         for c in ctxs:
             c.set_option(OPT_PIXEL_GROUPS, groups)
+            c.set_option(OPT_PIXEL_SHAPE, shape)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         with torch.cuda.stream(stream):
             ctxs[0].run(params, STAGE_BINARY, sh)
             e0.record(stream)
             for _ in range(R):
-                (nxt() if rotate else ctxs[0]).run(params, STAGE_BINARY, sh)
+                if rotate:
+                    rot_r[0] += 1
+                    c = roof_ctxs[rot_r[0] % len(roof_ctxs)]
+                    c.bind_device_frames(frames_k[rot_r[0] % n_sets].data_ptr(), n, H, W)
+                else:
+                    c = ctxs[0]
+                c.run(params, STAGE_BINARY, sh)
             e1.record(stream)
         torch.cuda.synchronize()
+        for c in ctxs:
+            c.set_option(OPT_PIXEL_SHAPE, 0)
         return e0.elapsed_time(e1) / R
-    k1_ms = k_binary_alone(3)                                       # the library's default of 3 workgroups per CU (a lone batch)
-    k1_steps_ms = k_binary_alone(groups_in_steps) if groups_in_steps != 3 else k1_ms
-    k1_warm_ms = k_binary_alone(3, rotate=False)
+    k1_ms = k_binary_alone(3, shape=1 if hot_mode else 0)          # the steps' kernel (k_binary: the library's default of 3 workgroups per CU)
+    k1_steps_ms = k_binary_alone(groups_in_steps) if (groups_in_steps != 3 or hot_mode) else k1_ms   # k_binary as the steps' other batches launch it
+    k1_warm_ms = k_binary_alone(3, rotate=False, shape=1 if hot_mode else 0)
     # the pixel kernels ALONE in the schedule the steps launch them in (the steps' streams, workgroups per CU and frame sets, no sparse
     # stage): what the overlap of consecutive launches is worth -- each hides the other's ramp and tail
     settings(waves_in_steps, groups_in_steps)
@@ -570,6 +600,7 @@ def main():
         "metric": "frames/sec (%dx%d BGR) armour detect" % (W, H), "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "timed_region": {"repeats": len(rep_dt), "ms_per_step_each": [round(d / args.steps * 1e3, 4) for d in rep_dt],
+                         "batches_in_hot_contexts_each": hot_timed,
                          "ms_per_step_median": round(ms_per_step, 4), "ms_per_step_min": round(srt[0] / args.steps * 1e3, 4),
                          "value_at_min": round(world * n * args.steps / srt[0], 1), "warmup_steps_requested": args.warmup, "warmup_steps_by_time": warm_steps,
                          "host_enqueue_ms_per_step": round(median(enq_dt) / args.steps * 1e3, 4),
@@ -585,6 +616,7 @@ def main():
                    "frames_per_gpu": n, "stream_variant": args.variant, "one_dense_frame_per_batch": args.one_dense, "parallelism": "frame-shard x%d" % world,
                    "host_api": "rmcv_pipeline_submit (librmcv_hip.so): one call per step",
                    "batches_in_flight": info.depth, "pixel_streams": info.pixel_streams, "sparse_streams": info.sparse_streams, "dense_streams": info.dense_streams,
+                   "hot_contexts": info.hot_contexts, "batches_in_hot_contexts": int(pl.get_info().hot_batches), "pixel_kernel_of_calm_batches": roof_kernel,
                    "frame_sets": n_sets, "gpu_max_hw_queues": info.hw_queues_env, "pixel_groups_per_cu": groups_in_steps,
                    "sparse_waves_per_frame": waves_in_steps, "results_to_host_every_step": info.host_results == 1,
                    "stages": stages, "dev_knobs": knobs or None,
@@ -601,18 +633,18 @@ def main():
                      "note": "per-stage launches (rmcv_batch_run_timed); the steps run contours+blobs+armours as one fused "
                              "per-frame kernel: fused_sparse",
                      "fused_sparse": None if fused_ms is None else round(fused_ms, 4)},
-        "roofline": {"kernel": "k_binary", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": roof_kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "in_schedule_frac": None if k1_pipe_ms is None else frac(k1_pipe_ms),
                      "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME, "avg_launch_ms": round(k1_ms, 4),
-                     "launches_timed": R, "workgroups_per_cu": 3, "contexts_rotated": len(ctxs),
-                     "note": "frac: one launch at a time, cold (every launch on another context's frames and buffers); in_schedule_frac: the same "
+                     "launches_timed": R, "workgroups_per_cu": 1 if hot_mode else 3, "contexts_rotated": len(roof_ctxs), "frame_sets_rotated": n_sets,
+                     "note": "frac: one launch at a time, cold (every launch reads another frame set, in the contexts the steps' batches take turns at); in_schedule_frac: the same "
                              "kernel as the steps launch it -- two launches overlapping on two streams, each hiding the other's ramp and tail",
                      "same_frames_every_launch": {"avg_launch_ms": round(k1_warm_ms, 4), "frac": frac(k1_warm_ms),
                                                   "note": "NOT the roofline figure: 20 launches over the SAME gigabyte of frames, part of which the 256 MB "
                                                           "Infinity Cache still holds from the launch before"},
-                     "as_launched_by_the_steps": {"workgroups_per_cu": groups_in_steps, "avg_launch_ms": round(k1_steps_ms, 4), "frac": frac(k1_steps_ms),
-                                                  "note": "alone, back to back; in the steps two such launches overlap (4 workgroups per CU resident)"},
+                     "k_binary_as_the_other_batches_launch_it": {"workgroups_per_cu": groups_in_steps, "avg_launch_ms": round(k1_steps_ms, 4), "frac": frac(k1_steps_ms),
+                                                  "note": "k_binary alone, back to back (batches with dense frames, a classifier or pose stage: two such launches overlap, 4 workgroups per CU resident)"},
                      "pixel_kernels_only_in_the_steps_schedule": None if k1_pipe_ms is None else {
                          "ms_per_launch": round(k1_pipe_ms, 4), "frac": frac(k1_pipe_ms),
                          "note": "%d steps of the pipeline with the stage mask cut down to RMCV_STAGE_BINARY, wall clock between two drains" % (4 * R)}},
