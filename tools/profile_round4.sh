@@ -1,7 +1,7 @@
 # usage: bash tools/profile_round4.sh <tag> [c3|c5]   (on the GPU box through gpurun; writes gpurun_out/prof_<tag>/)
 # Round-4 evidence for one workload.  Every rocprofv3 call has the program directly after `--`; PMC passes carry --kernel-trace only.
-#   roofline   kernel stats of `bench.py --roofline-only`: warm-up + 80 cold launches of k_binary at 3 workgroups per CU and nothing else
-#              -- the trace's AverageNs of k_binary is ONE kind of launch and is what bench.py's roofline.avg_launch_ms must agree with
+#   roofline   kernel stats of `bench.py --roofline-only`: warm-up + 80 cold launches of the steps' pixel kernel (k_binary_ws in the hot
+#              contexts for C3, k_binary at 3 workgroups per CU for C5) and nothing else -- the trace's AverageNs of it is ONE kind of launch and is what bench.py's roofline.avg_launch_ms must agree with
 #              (round 3's "serial" command mixed warm and cold launches in one average: VERDICT r3 weak 10c)
 #   default    kernel stats of the driver's command (pipelined: two k_binary launches overlap, so each takes about twice its share)
 #   pmc_*      HBM traffic of k_binary (FETCH_SIZE / WRITE_SIZE in separate passes on the roofline command; FETCH_SIZE calibrated on
@@ -11,7 +11,7 @@ if [ "$wl" = c5 ]; then W=1920; H=1200; else W=1280; H=1024; fi
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; mkdir -p $out
 RO="--workload $wl --roofline-only"
-Q="--workload $wl --cpu-frames 0 --no-extras --repeats 1 --warmup-seconds 0 --streams 1 --steps 3 --warmup 1"
+Q="--workload $wl --cpu-frames 0 --no-extras --repeats 1 --warmup-seconds 0 --steps 12 --warmup 10"   # (the default ring: after the first cycle the calm batches run k_binary_ws in the hot contexts)
 python3 bench.py $RO > $out/roofline_plain.json 2> $out/roofline_plain.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/roofline -- python3 bench.py $RO > $out/roofline_traced.json 2> $out/roofline.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/default -- python3 bench.py --workload $wl --steps 20 --warmup 5 --cpu-frames 0 --no-extras > $out/bench_default.json 2> $out/default.err
@@ -38,19 +38,21 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
         if "rmcv" in k:
             res.setdefault(k, {}).update(cs)
 json.dump(res, open(out + "/counters_per_kernel.json", "w"), indent=1, sort_keys=True)
-kb = [v for k, v in res.items() if "k_binary" in k]
+kbk = [k for k, v in res.items() if "k_binary" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v]   # (the kernel of the roofline command)
+kb = [res[k] for k in kbk]
 cal = [v for k, v in table("pmc_cal").items() if "k_binary" in k]
 if kb and "FETCH_SIZE" in kb[0] and "WRITE_SIZE" in kb[0]:
     known = 256 * W * H * 3
     factor = known / (cal[0]["FETCH_SIZE"] * 1024) if cal and cal[0].get("FETCH_SIZE") else None
-    rec = {"kernel": "k_binary", "frames": 256, "width": W, "height": H, "FETCH_SIZE_KiB_raw": kb[0]["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": kb[0]["WRITE_SIZE"],
+    kname = kbk[0]
+    rec = {"kernel": kname.replace("void rmcv::", ""), "frames": 256, "width": W, "height": H, "FETCH_SIZE_KiB_raw": kb[0]["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": kb[0]["WRITE_SIZE"],
            "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950 under-count of wide coalesced reads, MI355X_MICROARCH.md HBM), write bytes = WRITE_SIZE x 1024",
            "calibration": {"what": "the same kernel with morph = none reads every input byte exactly once (no halo rows): known bytes / (FETCH_SIZE x 1024) for its 12-B-per-lane wave-coalesced loads",
                            "known_read_bytes": known, "FETCH_SIZE_KiB_raw": cal[0]["FETCH_SIZE"] if cal else None, "factor": factor},
            "algorithmic_bytes_per_launch": 256 * W * H * 4,
            "hbm_bytes_per_launch": int((2 * kb[0]["FETCH_SIZE"] + kb[0]["WRITE_SIZE"]) * 1024),
            "hbm_bytes_per_launch_calibrated": int((factor * kb[0]["FETCH_SIZE"] + kb[0]["WRITE_SIZE"]) * 1024) if factor else None,
-           "command": "bench.py --roofline-only (cold launches, 3 workgroups per CU)"}
+           "command": "bench.py --roofline-only (cold launches of the steps' pixel kernel)"}
     json.dump(rec, open(out + "/k_binary_traffic.json", "w"), indent=1)
     print(rec)
 for d in ("roofline", "default"):
