@@ -20,7 +20,7 @@ Prints ONE JSON line on rank 0: the contract fields plus
                 sample of the same frames (rank 0, N=1 only)
   c5, density_sweep   short sub-records for BASELINE config 5 and for denser scenes (skipped by --no-extras)
 
-Dev tool (--dev): RMCV_BENCH_AB="<option>:<a>:<b>" | "sched:<depth,pix,sparse>:<...>" | "stages:<mask>:<mask>" | "lib:<another build>"
+Dev tool (--dev): RMCV_BENCH_AB="<option>:<a>:<b>" | "hot:<a>:<b>" | "sched:<depth,pix,sparse>:<...>" | "stages:<mask>:<mask>" | "lib:<another build>"
 alternates two settings between regions of ONE process (two processes of one command differ by +-3 % on one box; regions inside a
 process by 0.1 %).
 """
@@ -419,7 +419,7 @@ def main():
         f_ = knobs["RMCV_BENCH_AB"].split(":")
         kind = f_[0]
         pairs_ = 12
-        pls, stg, opt_ = {0: pl, 1: pl}, {0: stages, 1: stages}, None
+        pls, stg, opt_, hot_ = {0: pl, 1: pl}, {0: stages, 1: stages}, None, None
         # A is always the run's own pipeline, B a second one (at most two rings, i.e. 12 streams, exist at a time)
         if kind == "lib":        # "lib:<path>": THIS build against another build of librmcv_hip.so (tools/build_variant*.sh)
             from rmcv_amd import abi as abi_
@@ -444,6 +444,9 @@ def main():
         elif kind == "hostres":  # "hostres:<b>": rmcv_pipeline_config::host_results (1: lists copied to pinned memory every step, 2: left in HBM)
             pls[1] = make_pipeline(ns, args.pixel_streams, args.sparse_streams, host_results=int(f_[1]))
             label, pairs_ = "host_results %d vs %s" % (info.host_results, f_[1]), int(f_[2]) if len(f_) > 2 else 12
+        elif kind == "hot":      # "hot:<a>:<b>": rmcv_pipeline_config::hot_contexts, switched on the run's own pipeline (0 = off)
+            hot_ = {0: int(f_[1]), 1: int(f_[2])}
+            label, pairs_ = "hot_contexts %s vs %s" % (f_[1], f_[2]), int(f_[3]) if len(f_) > 3 else 12
         elif kind == "stages":   # "stages:<mask>:<mask>": what each stage COSTS the step (1 = pixel kernel only, 3 = + findContours, ...)
             stg = {0: int(f_[1]) | (stages & ~15), 1: int(f_[2]) | (stages & ~15)}
             label, pairs_ = "stage masks %s vs %s" % (f_[1], f_[2]), int(f_[3]) if len(f_) > 3 else 12
@@ -458,12 +461,16 @@ def main():
                 if opt_ is not None:
                     for c in pl.contexts:
                         c.set_option(opt_, vals[v_])
+                if hot_ is not None:
+                    pl.set_hot_contexts(hot_[v_])
                 for _ in range(2 * ns):
                     step()
                 (d_,), _ = regions(reg_, 1)
                 res_[v_].append(d_ / reg_ * 1e3)
         barrier()
         cur["pl"], cur["stages"] = pl, stages
+        if hot_ is not None:
+            pl.set_hot_contexts(info.hot_contexts)
         if opt_ is not None:
             for c in pl.contexts:
                 c.set_option(opt_, vals[0])
@@ -570,10 +577,13 @@ def main():
     k1_pipe_ms = None
     if ns > 1:
         cur["stages"] = stages & (STAGE_BINARY | STAGE_NO_IMAGE)
+        if not hot_mode:
+            pl.set_hot_contexts(0)                                # (the pixel kernel the steps run, not the one a pixel-only mask would get)
         for _ in range(ns):
             step()
         (d_,), _ = regions(4 * R, 1)
         k1_pipe_ms = d_ / (4 * R) * 1e3
+        pl.set_hot_contexts(info.hot_contexts)
         cur["stages"] = STAGE_ALL | (stages & ~15)              # (leave full lists behind in every slot)
         for _ in range(ns):
             step()

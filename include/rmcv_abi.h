@@ -453,6 +453,8 @@ rmcv_ctx* rmcv_pipeline_context(rmcv_pipeline* pl, int slot);
  * only until the context's next batch, which can be as early as ticket + hot_contexts (rmcv_pipeline_config): read them before
  * submitting that many more.  NULL for a ticket that is not live. */
 rmcv_ctx* rmcv_pipeline_context_of(rmcv_pipeline* pl, uint64_t ticket);
+/* rmcv_pipeline_config::hot_contexts from the next submit on (3 .. depth - 1; 0 or -1: off).  Batches in flight are not touched. */
+int  rmcv_pipeline_set_hot_contexts(rmcv_pipeline* pl, int n);
 /* enqueue one batch of n_frames frames that are resident in HBM (layout as rmcv_batch_set_device_frames); stages must include
  * RMCV_STAGE_BINARY.  Asynchronous; *ticket (0, 1, 2, ...) names the batch.  The slot's previous batch (ticket - depth) is
  * overwritten: collect it first. */

@@ -53,7 +53,7 @@ EXPORTS = [
     "rmcv_svm_load", "rmcv_classify_armours", "rmcv_batch_get_identities", "rmcv_batch_get_icons",
     "rmcv_default_pnp_config", "rmcv_pnp_load", "rmcv_locate_armours", "rmcv_batch_set_base2gripper", "rmcv_batch_get_poses",
     "rmcv_max_iou", "rmcv_identity_max", "rmcv_comm_unique_id", "rmcv_comm_create", "rmcv_comm_destroy", "rmcv_comm_info", "rmcv_comm_last_error", "rmcv_gather",
-    "rmcv_default_pipeline_config", "rmcv_pipeline_create", "rmcv_pipeline_destroy", "rmcv_pipeline_last_error", "rmcv_pipeline_get_info", "rmcv_pipeline_context", "rmcv_pipeline_context_of", "rmcv_pixel_ws_launches",
+    "rmcv_default_pipeline_config", "rmcv_pipeline_create", "rmcv_pipeline_destroy", "rmcv_pipeline_last_error", "rmcv_pipeline_get_info", "rmcv_pipeline_context", "rmcv_pipeline_context_of", "rmcv_pipeline_set_hot_contexts", "rmcv_pixel_ws_launches",
     "rmcv_pipeline_submit", "rmcv_pipeline_submit_legacy", "rmcv_pipeline_wait", "rmcv_pipeline_collect", "rmcv_pipeline_drain", "rmcv_pipeline_record",
     "rmcv_pipeline_set_hook", "rmcv_pipeline_set_gather", "rmcv_pipeline_gathered", "rmcv_device_alloc", "rmcv_device_free", "rmcv_device_upload", "rmcv_device_download",
     "rmcv_track_init", "rmcv_track_reset", "rmcv_track_update", "rmcv_track_predict", "rmcv_track_step", "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
@@ -131,6 +131,8 @@ def load(path):
     L.rmcv_pipeline_destroy.argtypes = [C.c_void_p]
     L.rmcv_pipeline_context.restype = C.c_void_p
     L.rmcv_pipeline_context.argtypes = [C.c_void_p, C.c_int]
+    L.rmcv_pipeline_set_hot_contexts.restype = C.c_int
+    L.rmcv_pipeline_set_hot_contexts.argtypes = [C.c_void_p, C.c_int]
     L.rmcv_pixel_ws_launches.restype = C.c_int64
     L.rmcv_pixel_ws_launches.argtypes = []
     L.rmcv_pipeline_context_of.restype = C.c_void_p

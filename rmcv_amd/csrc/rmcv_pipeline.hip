@@ -278,6 +278,16 @@ rmcv_ctx* rmcv_pipeline_context(rmcv_pipeline* pl, int slot)
     return pl->ring[(size_t)slot];
 }
 
+int rmcv_pipeline_set_hot_contexts(rmcv_pipeline* pl, int n)
+{
+    if (!pl) return RMCV_ERR_BAD_ARG;
+    if (n <= 0) { pl->hot = 0; return RMCV_OK; }
+    if (n < 3 || n >= pl->cfg.depth) return pfail(pl, RMCV_ERR_BAD_ARG, "hot_contexts: 3 .. depth - 1, or 0 / -1 for off");
+    if (pl->cfg.host_results != 1 || pl->cfg.sparse_waves != 4) return pfail(pl, RMCV_ERR_BAD_ARG, "hot_contexts needs host_results = 1 and sparse_waves = 4");
+    pl->hot = n;
+    return RMCV_OK;
+}
+
 static int slot_of(rmcv_pipeline* pl, uint64_t ticket);
 rmcv_ctx* rmcv_pipeline_context_of(rmcv_pipeline* pl, uint64_t ticket)
 {

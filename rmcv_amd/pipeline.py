@@ -95,6 +95,10 @@ class Pipeline:
         n = self._n[int(ticket) % self.depth]
         return out[:tot.value].copy(), offs[:n + 1].copy()
 
+    def set_hot_contexts(self, n):
+        """rmcv_pipeline_config::hot_contexts from the next submit on (0: off)"""
+        self._chk(self._lib.rmcv_pipeline_set_hot_contexts(self._h, int(n)))
+
     def drain(self):
         self._chk(self._lib.rmcv_pipeline_drain(self._h))
 
