@@ -450,6 +450,14 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
         const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(binary, 0, binary ? (int)((int64_t)n_frames * w * h) : 0, RSRC3);
         const __amdgpu_buffer_rsrc_t r_plane = __builtin_amdgcn_make_buffer_rsrc(bits, 0, (int)((int64_t)n_frames * plane_pitch * 8), RSRC3);
         const uint32_t plane_base = (uint32_t)((int64_t)f * plane_pitch);
+        // ... and the two pad words behind every row's last word (always zero), so that the plane's cache lines are written whole (see
+        // k_binary_ws.inc: with a 16-byte hole in every line the plane costs 3-15 % of the kernel once it falls out of the Infinity Cache)
+        if (tid < sr && y0 + tid < h) {
+            const u32x2v z = {0u, 0u};
+            const uint32_t pp = (plane_base + __umul24(y0 + tid + 1, prow) + 1u + (uint32_t)ww) * 8u;
+            __builtin_amdgcn_raw_buffer_store_b64(z, r_plane, pp, 0, RMCV_K1_PLAIN_PLAUX);
+            __builtin_amdgcn_raw_buffer_store_b64(z, r_plane, pp + 8u, 0, RMCV_K1_PLAIN_PLAUX);
+        }
         { // the strip's words -> the frame's bit plane (8 contiguous bytes per lane)
             const int nw = sr * ww;
             int s_ = s_first, k = k_first;
@@ -460,9 +468,6 @@ __global__ __launch_bounds__(256, RMCV_K1_MINBLOCKS) void k_binary(const uint8_t
                 if (ok) word = R[__umul24(s_ + halo, ww) + k];
                 const uint32_t po = ok ? (plane_base + __umul24(y + 1, prow) + 1u + (uint32_t)k) * 8u : OOB;
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, word), r_plane, po, 0, RMCV_K1_PLAIN_PLAUX); // (plain: the sparse kernel of the same batch finds the words in L2)
-                // the two pad words behind the row's last word (always zero), so that the plane's cache lines are written whole: see k_binary_ws.inc
-                const u32x4v z = {0u, 0u, 0u, 0u};
-                __builtin_amdgcn_raw_buffer_store_b128(z, r_plane, ok && k == ww - 1 ? po + 8u : OOB, 0, RMCV_K1_PLAIN_PLAUX);
                 k += k_step;
                 s_ += s_step;
                 if (k >= ww) { k -= ww; s_++; }
