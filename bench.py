@@ -566,7 +566,7 @@ def main():
             e1.record(stream)
         torch.cuda.synchronize()
         for c in ctxs:
-            c.set_option(OPT_PIXEL_SHAPE, 0)
+            c.set_option(OPT_PIXEL_SHAPE, 1)                      # (the contexts' default)
         return e0.elapsed_time(e1) / R
     k1_ms = k_binary_alone(3, shape=1 if hot_mode else 0)          # the steps' kernel (k_binary: the library's default of 3 workgroups per CU)
     k1_steps_ms = k_binary_alone(groups_in_steps) if (groups_in_steps != 3 or hot_mode) else k1_ms   # k_binary as the steps' other batches launch it

@@ -177,12 +177,14 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * are the double functions, the arithmetic around them double.  0 (default): the float overloads everywhere.  Changes results --
  * by design: it follows the reference build it replaces.  INTEGRATION.md has the probe that tells which value a build needs. */
 #define RMCV_OPT_OVERLOADS 13
-/* RMCV_OPT_PIXEL_SHAPE: which kernel is the pixel stage of a WHOLE batch whose rows are contiguous (stride == 3 w, w % 64 == 0).
- * 0 (default): k_binary -- 256-thread workgroups, 2-3 per CU, each loading, thresholding, closing and storing its strip in turn.
- * 1: k_binary_ws -- ONE 1024-thread workgroup per CU, 8 wavefronts loading strip k+1 while 8 store strip k: 4-7 % faster alone
- * (6.1-6.2 TB/s of the bare copy's 6.25), but it fills the CU: the 8-wavefront sparse kernel cannot run beside it, and it gains
- * nothing while the bit planes of more than ~5 contexts take turns (they fall out of the Infinity Cache).  A pipeline switches it
- * per batch (rmcv_pipeline_config::hot_contexts).  Same results. */
+/* RMCV_OPT_PIXEL_SHAPE: which kernel is the pixel stage of a WHOLE batch whose rows are contiguous (stride == 3 w, w % 64 == 0, more
+ * strips than half the CUs, lb > 0; anything else is k_binary's whatever this says).
+ * 1 (default): k_binary_ws -- ONE 1024-thread workgroup per CU, 8 wavefronts loading strip k+1 while 8 store strip k: alone 8 % faster
+ * than k_binary (0.227 against 0.247 ms per 256 x 1280x1024, 5.9 TB/s of the bare copy's 6.25).  It fills the CU: a second launch
+ * of it waits for the first, and the 8-wavefront sparse kernel cannot run beside it.
+ * 0: k_binary -- 256-thread workgroups, 2-3 per CU, each loading, thresholding, closing and storing its strip in turn; launches of
+ * consecutive batches and the sparse kernels share every CU.  A pipeline chooses per batch (rmcv_pipeline_config::hot_contexts)
+ * and overrides this.  Same results. */
 #define RMCV_OPT_PIXEL_SHAPE 14
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 /* launches of k_binary_ws (RMCV_OPT_PIXEL_SHAPE 1) by this process so far: a diagnostic -- an option that is set but whose

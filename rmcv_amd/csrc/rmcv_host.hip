@@ -215,7 +215,7 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
         c->geom.device = device;
         c->geom.pixel_halo_nt = getenv("RMCV_K1_HALO_NT") ? atoi(getenv("RMCV_K1_HALO_NT")) : 0;
         c->geom.pixel_rowquad = getenv("RMCV_K1_LINEAR") && atoi(getenv("RMCV_K1_LINEAR")) == 0;
-        c->geom.pixel_ws = 0;
+        c->geom.pixel_ws = 1; // RMCV_OPT_PIXEL_SHAPE: whole batches with contiguous rows -> k_binary_ws
         c->geom.dense_defer = getenv("RMCV_DENSE_DEFER") ? atoi(getenv("RMCV_DENSE_DEFER")) : 0; // RMCV_OPT_DENSE_DEFER (env: dev A/B knob)
         c->geom.n_cu = (device < MAX_DEVICES && hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
         if (device >= MAX_DEVICES) e = hipErrorInvalidDevice;
