@@ -396,6 +396,10 @@ static int set_geom(rmcv_ctx* c, int n_frames, int w, int h, int stride, int64_t
     g.ww = (w + 63) / 64;
     g.prow = g.ww + 2;
     g.plane_pitch = (int64_t)(h + 2) * g.prow;
+    // the planes are re-zeroed and the frame order rewritten under the kernels' feet otherwise: a pipeline's batches run on the
+    // pipeline's streams, and the context's last one may still be in flight (its event sits behind it)
+    if ((c->geom_w != w || c->geom_h != h || c->order_n != n_frames || c->order_h != h) && c->external_order && c->ext_done)
+        HIPCHK(c, hipEventSynchronize(c->ext_done), "sync before a change of geometry (pipeline slot)");
     if (c->geom_w != w || c->geom_h != h) {
         const size_t plane = (size_t)(c->lim.max_height + 2) * ((c->lim.max_width + 63) / 64 + 2);
         HIPCHK(c, hipMemsetAsync(c->own_bits, 0, (size_t)c->lim.max_frames * plane * 8, c->stream), "memset planes");

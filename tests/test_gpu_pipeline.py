@@ -347,3 +347,32 @@ def test_calm_and_dense_batches_in_turn(oracle):
     assert 10 <= info.hot_batches <= len(kinds) - 1 - 6               # most ran hot; the first one and the dense ones (but for the first of a run) did not
     assert abi.lib().rmcv_pixel_ws_launches() - ws0 == info.hot_batches
     pl.close()
+
+
+def test_geometry_changes_with_batches_in_flight(oracle):
+    """frame sizes and batch sizes change from one submit to the next while eight batches are in flight and the calm ones share four
+    contexts: a context re-zeroes its planes and rewrites its frame order only when its own last batch is through"""
+    import torch
+    dev = torch.device("cuda", 0)
+    pl = Pipeline(device=0, max_frames=96, max_width=1920, max_height=1200)
+    assert pl.info.depth == 8 and pl.info.hot_contexts == 4
+    p = default_params()
+    geoms = [(96, 1280, 1024), (40, 1920, 1200), (96, 640, 512), (17, 1280, 720), (96, 1280, 1024), (64, 1920, 1080)]
+    host, devf, got = [], [], {}
+    for i in range(30):
+        n, w, h = geoms[(i * 7) % len(geoms)] if i % 3 else geoms[i % len(geoms)]
+        fr = synth.batch(660000 + 13 * i, n, w, h, CAMP_BLUE, i % 2, threads=16)
+        host.append(fr)
+        devf.append(torch.from_numpy(fr).to(dev))
+    for i in range(30):
+        n, h, w, _ = host[i].shape
+        pl.submit(devf[i].data_ptr(), n, h, w, p, STAGE_ALL)
+        if i >= 7:
+            got[i - 7] = pl.collect(i - 7)
+    pl.drain()
+    for i in range(23, 30):
+        got[i] = pl.collect(i)
+    for i in range(30):
+        check_batch(oracle, host[i], *got[i])
+    assert pl.get_info().hot_batches > 0
+    pl.close()
