@@ -597,8 +597,8 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
             lds_set[g.device][inst] = planes;
         }
         // whole batches with contiguous rows, when the caller asks for it (RMCV_OPT_PIXEL_SHAPE; a pipeline does for its calm batches):
-        // the wave-specialised kernel, ONE 1024-thread workgroup per CU -- 8 loader wavefronts with 3 items in flight each, 8 storers
-        constexpr int WS_NL = 8, WS_NS = 8, WS_RING = 3, WS_AUX = 2 /* nt */;
+        // the wave-specialised kernel, ONE 1024-thread workgroup per CU -- 8 loader wavefronts with 2 items (8 loads) in flight each, 8 storers
+        constexpr int WS_NL = 8, WS_NS = 8, WS_RING = 2, WS_AUX = 2 /* nt */;
         const size_t planes_ws = ((size_t)2 * (SR + 4) + SR) * g.ww * sizeof(uint64_t);
         if (g.pixel_ws && linear && !all_pass && taper_head == 0 && planes_ws <= 60 * 1024) {
             K1Args ka;
@@ -610,6 +610,8 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
             g_ws_launches.fetch_add(1, std::memory_order_relaxed);
             // (issue priority 3 for loaders and storers, the sparse kernel's own: in-process A/B against 0 / (2,1) / (3,0) / (1,1):
             // 0.991 / 1.008 / 1.017 / 1.006 of the step)
+            // (in the pipeline, in-process A/B against this shape: ring of 3 items 1.005, of 4 1.005; 12 loaders + 4 storers 1.087, 10 + 4
+            // 1.017, 8 + 4 1.024; loads without the nt hint 1.062)
             const hipError_t e = launch(k_binary_ws<CA, CB, WS_NL, WS_NS, WS_RING, WS_AUX, 3, 3>, dim3(grid_ws), dim3((WS_NL + WS_NS) * 64), planes_ws, s, ka);
             if (e != hipSuccess) return e;
             continue;
