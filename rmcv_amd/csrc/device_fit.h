@@ -463,12 +463,12 @@ __device__ inline void eigen_nonsymmetric3(const double M[3][3], double eval[3],
 // immediate, a select against a constant mask), no subscript arithmetic.  Operations and their order are unchanged, and so is the
 // time (14-17 us of a general fit's 33 for K = 5, measured before and after): the sweep is a chain of dependent divisions and
 // square roots -- ~6 sweeps x 10 rotations x 5 of them --, not of subscripts.  Kept for the two VGPRs it gives back.
-// Round 4, RMCV_JACOBI_PLAIN (the 4-wavefront sparse kernel's translation unit defines it): the sweeps run on PLAIN (wave-uniform,
-// replicated) registers, the lane-resident arrays are read once and written once: 15 -> 10.5 us for K = 5 (what is left is the
-// divisions and square roots), the fused sparse kernel 0.121 -> 0.105 ms per batch alone -- at 180 instead of 165 VGPRs.  Affordable
-// where ONE wavefront per SIMD sits beside the pixel kernel (4 x 72 or 4 x 80 + 184 <= 512); NOT for the 8-wavefront kernel, whose
-// two per SIMD then no longer fit beside two of k_binary's (2 x 184 + 2 x 80 > 512): a batch with one dense frame went from
-// 0.27 to 0.31 ms per step with it.
+// Round 4, -DRMCV_JACOBI_PLAIN (off): the sweeps on PLAIN (wave-uniform, replicated) registers, the lane-resident arrays read once
+// and written once: 15 -> 10.5 us for K = 5 (what is left is the divisions and square roots), the fused sparse kernel 0.121 -> 0.105
+// ms per batch ALONE -- at 180 instead of 165 VGPRs.  Measured where it would count and not kept: in the 4-wavefront kernel the
+// pipelined step is unchanged (alternating pipelines of one process, against an identical pair: 0.993-0.995), in the 8-wavefront
+// kernel two wavefronts per SIMD no longer fit beside two of k_binary's (2 x 184 + 2 x 80 > 512) and a batch with one dense frame
+// goes from 0.27 to 0.31 ms per step; what remains is 3 % of a lone batch.
 template <int K>
 __device__ __forceinline__ void jacobi_sym(LaneVec& A_, LaneVec& lam, LaneVec& V_)
 {

@@ -1,6 +1,5 @@
 // k_contours_w4.hip -- the per-frame sparse kernel (k_contours_kernel.inc) with 4 wavefronts per frame: the throughput setting
 // (RMCV_OPT_SPARSE_WAVES = 4).  Its own translation unit, see k_contours.hip.
-#define RMCV_JACOBI_PLAIN 1 // device_fit.h: the Jacobi sweeps on plain registers (one wavefront per SIMD: 180 VGPRs fit)
 #include "contours_device.h"
 
 namespace rmcv {
