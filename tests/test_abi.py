@@ -107,6 +107,8 @@ def test_pipeline_entry_points_without_a_gpu():
     assert L.rmcv_pipeline_collect(None, 0, None, 0, None, None) == abi.ERR_BAD_ARG
     assert L.rmcv_pipeline_drain(None) == abi.ERR_BAD_ARG and L.rmcv_pipeline_wait(None, 0) == abi.ERR_BAD_ARG
     assert L.rmcv_pipeline_context(None, 0) is None
+    assert L.rmcv_pipeline_context_of(None, 0) is None and L.rmcv_pipeline_set_hot_contexts(None, 4) == abi.ERR_BAD_ARG
+    assert L.rmcv_pixel_ws_launches() == 0
     assert L.rmcv_device_alloc(0, 0, C.byref(h)) == abi.ERR_BAD_ARG
     libc = C.CDLL(None)                                             # (os.environ is Python's snapshot: ask the C environment)
     libc.getenv.restype = C.c_char_p

@@ -376,3 +376,38 @@ def test_geometry_changes_with_batches_in_flight(oracle):
         check_batch(oracle, host[i], *got[i])
     assert pl.get_info().hot_batches > 0
     pl.close()
+
+
+def test_hot_contexts_config_and_switch():
+    """rmcv_pipeline_config::hot_contexts: the default, off, out of range, what it needs; rmcv_pipeline_set_hot_contexts at run time"""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, w, h = 32, 640, 512
+    pl = Pipeline(device=0, max_frames=n, max_width=w, max_height=h)
+    assert pl.info.hot_contexts == 4
+    with pytest.raises(RmcvError):
+        pl.set_hot_contexts(2)                                        # fewer than 3 stall even sparse batches
+    with pytest.raises(RmcvError):
+        pl.set_hot_contexts(8)                                        # the ring has 8 contexts: 3 .. 7
+    pl.set_hot_contexts(5)
+    assert pl.get_info().hot_contexts == 5
+    pl.set_hot_contexts(0)
+    assert pl.get_info().hot_contexts == 0
+    fr = synth.batch(99, n, w, h, CAMP_BLUE, 0, threads=16)
+    d = torch.from_numpy(fr).to(dev)
+    p = default_params()
+    for i in range(12):
+        pl.submit(d.data_ptr(), n, h, w, p, STAGE_ALL)
+        pl.wait(i)
+    assert pl.get_info().hot_batches == 0                             # off: a context per slot
+    pl.set_hot_contexts(4)
+    for i in range(12, 24):
+        pl.submit(d.data_ptr(), n, h, w, p, STAGE_ALL)
+        pl.wait(i)
+    assert pl.get_info().hot_batches == 12
+    pl.close()
+    for kw, want in ((dict(hot_contexts=-1), 0), (dict(hot_contexts=6), 6), (dict(hot_contexts=9), 0), (dict(depth=3), 0), (dict(host_results=2), 0),
+                     (dict(sparse_waves=8), 0)):
+        q = Pipeline(device=0, max_frames=n, max_width=w, max_height=h, **kw)
+        assert q.info.hot_contexts == want, kw
+        q.close()
