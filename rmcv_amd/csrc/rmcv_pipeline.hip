@@ -57,6 +57,8 @@ struct rmcv_pipeline {
     uint64_t hot_seq = 0, hot_batches = 0;
     std::vector<int> ctx_last;          // per context: the slot of its last batch (-1: none)
     std::vector<int> slot_ctx;          // per slot: the context of its batch
+    std::vector<hipEvent_t> ev_free;    // per slot: behind the LAST READER of its batch's pixel outputs (the sparse stage; before the compaction)
+    bool early_free = true;             // (dev knob RMCV_EARLY_FREE=0: a context's next batch waits for the whole list, as ev_done)
     bool split_now = false;            // the batches of the moment have a FEW dense frames: give those a launch and a stream of their own
     uint64_t split_batches = 0;        // batches submitted that way
     rmcv_pipeline_hook hook = nullptr;
@@ -120,6 +122,7 @@ void rmcv_pipeline_destroy(rmcv_pipeline* pl)
     for (auto e : pl->ev_done) if (e) hipEventDestroy(e);
     for (auto e : pl->ev_host) if (e) hipEventDestroy(e);
     for (auto e : pl->ev_sp) if (e) hipEventDestroy(e);
+    for (auto e : pl->ev_free) if (e) hipEventDestroy(e);
     if (pl->ev_gather) hipEventDestroy(pl->ev_gather);
     for (auto p : pl->d_rec) if (p) hipFree(p);
     for (auto p : pl->d_recv) if (p) hipFree(p);
@@ -206,6 +209,9 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
         hipEvent_t a = nullptr, b = nullptr, h = nullptr, sp_ = nullptr;
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sp_, hipEventDisableTiming);
         pl->ev_sp.push_back(sp_);
+        hipEvent_t fr_ = nullptr;
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&fr_, hipEventDisableTiming);
+        pl->ev_free.push_back(fr_);
         uint8_t *dr = nullptr, *hr = nullptr;
         e = hipEventCreateWithFlags(&a, dev_flags);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b, dev_flags); // (the host reads the record's mirror behind ev_done: it must stay a system-scope event)
@@ -234,6 +240,7 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     pl->ctx_last.assign((size_t)d.depth, -1);
     pl->slot_ctx.assign((size_t)d.depth, 0);
     pl->hot = d.hot_contexts;
+    pl->early_free = !(getenv("RMCV_EARLY_FREE") && atoi(getenv("RMCV_EARLY_FREE")) == 0);
     if (e != hipSuccess) {
         fprintf(stderr, "rmcv_pipeline_create: %s\n", hipGetErrorString(e));
         (void)hipGetLastError();
@@ -366,7 +373,16 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     const int pixel = stages & (RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE), sparse = stages & ~(RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE);
     // the slot's context buffers are free once its previous list is compacted
     if (used) PCHK(pl, hipStreamWaitEvent(A, pl->ev_done[k], 0), "pipeline: wait for the slot");
-    if (pl->ctx_last[j] >= 0 && pl->ctx_last[j] != (int)k) PCHK(pl, hipStreamWaitEvent(A, pl->ev_done[(size_t)pl->ctx_last[j]], 0), "pipeline: wait for the context");
+    // The context's last batch (another slot's, when the hot contexts take turns): the pixel kernel rewrites byte image, bit plane and row
+    // masks, whose last reader is that batch's sparse stage -- its compaction reads the armour slots only, and those are rewritten by THIS
+    // batch's sparse stage, which follows the compaction in stream order when both run on the same sparse stream.  So the pixel kernel
+    // waits for ev_free (behind the sparse stage), not ev_done (behind the compaction: 35-95 us later beside the streaming kernels --
+    // with four contexts in rotation the whole slack is ~80 us).
+    if (pl->ctx_last[j] >= 0 && pl->ctx_last[j] != (int)k) {
+        const size_t last = (size_t)pl->ctx_last[j];
+        const bool early = pl->early_free && pl->slot_stream[last] == B;
+        PCHK(pl, hipStreamWaitEvent(A, early ? pl->ev_free[last] : pl->ev_done[last], 0), "pipeline: wait for the context");
+    }
     pl->ctx_last[j] = (int)k;
     pl->slot_ctx[k] = (int)j;
     ctx_external_order(c, pl->ev_done[k]);
@@ -408,6 +424,7 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
             rc = lp ? rmcv_batch_run_legacy(c, p, lp, sparse, B) : rmcv_batch_run(c, p, sparse, B);
         if (rc) return cfail(pl, c, rc);
     }
+    PCHK(pl, hipEventRecord(pl->ev_free[k], T), "pipeline: mark the pixel outputs' last reader");
     // the record is rewritten: a reader on another stream (the hook's) must be through; readers on B are by stream order
     if (pl->ev_hook[k]) {
         PCHK(pl, hipStreamWaitEvent(T, (hipEvent_t)pl->ev_hook[k], 0), "pipeline: wait for the record's reader");
