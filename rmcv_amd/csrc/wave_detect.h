@@ -53,6 +53,55 @@ __device__ __forceinline__ double seq_sum_terms(int n, int lane, WaveLds& L, F t
     return s;
 }
 
+// two such sums in one walk (two independent chains: the walk is bound by the chain's latency, not by its additions)
+template <typename F0, typename F1>
+__device__ __forceinline__ void seq_sum_terms2(int n, int lane, F0 term0, F1 term1, double* s0_, double* s1_)
+{
+    double s0 = 0, s1 = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const double t0 = i < n ? term0(i) : 0.0, t1 = i < n ? term1(i) : 0.0;
+        const int m = n - base < 64 ? n - base : 64;
+        if (m == 64) {
+#pragma unroll
+            for (int j = 0; j < 64; j++) { s0 += lane_get(t0, j); s1 += lane_get(t1, j); }
+        } else {
+            for (int j = 0; j < m; j++) { s0 += lane_get(t0, j); s1 += lane_get(t1, j); }
+        }
+    }
+    *s0_ = s0;
+    *s1_ = s1;
+}
+
+// Two sets of NS (<= 32) product sums over the SAME points in one walk: the wavefront's halves take 32 points at a time -- lanes 0..31
+// prepare row set 0 of their point, lanes 32..63 row set 1 of the same point -- and lane e of each half walks its half's 32 rows, in
+// point order, for its entry: every chain is the sequence of additions seq_sum_products makes, two attempts for the time of one.
+// Returns the entry of set (lane >> 5) for lane (lane & 31) < ns.
+template <int NR, typename F>
+__device__ __forceinline__ double seq_sum_products_two(int n, int lane, WaveLds& L, int ns, int la, int lb, F make_row /* (i, set, r) */)
+{
+    double acc = 0;
+    const int half = lane >> 5, l5 = lane & 31;
+    for (int base = 0; base < n; base += 32) {
+        const int i = base + l5;
+        if (i < n) {
+            double r[NR];
+            make_row(i, half, r);
+#pragma unroll
+            for (int k = 0; k < NR; k++) L.rows[lane][k] = r[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int m = n - base < 32 ? n - base : 32;
+        if (l5 < ns) {
+            const int r0 = half * 32;
+#pragma unroll 8
+            for (int j = 0; j < m; j++) acc += L.rows[r0 + j][la] * L.rows[r0 + j][lb];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return acc;
+}
+
 // NR = row length, NS = number of sums; lane e < NS accumulates rows[j][la] * (lb < 0 ? konst : rows[j][lb])
 template <int NR, typename F>
 __device__ __forceinline__ double seq_sum_products(int n, int lane, WaveLds& L, int ns, int la, int lb, double konst, F make_row)
@@ -186,41 +235,54 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
                                 rmcv_rrect* box, long long* prof = nullptr)
 {
     FSTAMP(0);
+    bool g_have = false; // the general fit's scale sum, accumulated beside the direct fit's
+    double g_s = 0;
     // ------------------------------------------------ direct (Fitzgibbon / Halir-Flusser)
     {
         const double cx = (double)sumx / n, cy = (double)sumy / n;
-        const double s = seq_sum_terms(n, lane, L, [&](int i) {
-            return dabs((float)pts[i].x - cx) + dabs((float)pts[i].y - cy);
-        });
+        // (the general fit's scale sum rides along: a bar -- the contour this path is made for -- fails the direct fit and needs it)
+        g_have = sumx < (1ll << 24) && sumy < (1ll << 24);
+        const float gcx = (float)sumx / (float)n, gcy = (float)sumy / (float)n;
+        double s;
+        if (g_have) {
+            seq_sum_terms2(n, lane,
+                           [&](int i) { return dabs((float)pts[i].x - cx) + dabs((float)pts[i].y - cy); },
+                           [&](int i) { const float px = (float)pts[i].x - gcx, py = (float)pts[i].y - gcy; return dabs((double)px) + dabs((double)py); },
+                           &s, &g_s);
+        } else {
+            s = seq_sum_terms(n, lane, L, [&](int i) { return dabs((float)pts[i].x - cx) + dabs((float)pts[i].y - cy); });
+        }
         const double scale = 100.0 / (s > FLT_EPSILON ? s : (double)FLT_EPSILON);
         FSTAMP(1);
         int la = 0, lb = 0;
-        tri_index(lane < 21 ? lane : 0, 6, &la, &lb);
+        tri_index((lane & 31) < 21 ? (lane & 31) : 0, 6, &la, &lb);
         double DM[6][6], TM[3][3], M[3][3], Ts = 0;
-        float eps = 0;
+        // Both attempts' scatter sums in ONE walk (the second attempt's jitter depends on s and n only): lanes 0..20 hold the plain
+        // points' entries, lanes 32..52 the jittered points'.  The second set is looked at only if the first determinant is too small.
+        const float eps1 = (float)(s / (n * 2) * 1e-2);
+        const double acc = seq_sum_products_two<6>(n, lane, L, 21, la, lb, [&](int i, int set, double* r) {
+            float ox, oy;
+            get_ofs(i, set ? eps1 : 0.0f, &ox, &oy);
+            const double px = (((float)pts[i].x + ox) - cx) * scale, py = (((float)pts[i].y + oy) - cy) * scale;
+            r[0] = px * px; r[1] = px * py; r[2] = py * py; r[3] = px; r[4] = py; r[5] = 1.0;
+        });
+        const double inv_n = 1.0 / n;
+        if ((lane & 31) < 21) (lane < 32 ? L.dm : L.terms)[lane & 31] = acc * inv_n;
+        __builtin_amdgcn_wave_barrier();
         int iter;
         for (iter = 0; iter < 2; iter++) {
-            const double acc = seq_sum_products<6>(n, lane, L, 21, la, lb, 0.0, [&](int i, double* r) {
-                float ox, oy;
-                get_ofs(i, eps, &ox, &oy);
-                const double px = (((float)pts[i].x + ox) - cx) * scale, py = (((float)pts[i].y + oy) - cy) * scale;
-                r[0] = px * px; r[1] = px * py; r[2] = py * py; r[3] = px; r[4] = py; r[5] = 1.0;
-            });
-            const double inv_n = 1.0 / n;
-            if (lane < 21) L.dm[lane] = acc * inv_n;
-            __builtin_amdgcn_wave_barrier();
+            const double* src = iter ? L.terms : L.dm;
             {
                 int e = 0;
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
-                    for (int b = a; b < 6; b++, e++) DM[a][b] = DM[b][a] = L.dm[e];
+                    for (int b = a; b < 6; b++, e++) DM[a][b] = DM[b][a] = src[e];
             }
-            __builtin_amdgcn_wave_barrier();
             const double det = direct_reduce(DM, TM, &Ts, M);
             if (dabs(det) > 1.0e-10) break;
-            eps = (float)(s / (n * 2) * 1e-2);
         }
+        __builtin_amdgcn_wave_barrier();
         FSTAMP(2);
         if (iter < 2) {
             direct_finish(M, TM, Ts, scale, cx, cy, box, lane);
@@ -242,7 +304,7 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
         }
         cx /= (float)n;
         cy /= (float)n;
-        const double s = seq_sum_terms(n, lane, L, [&](int i) {
+        const double s = g_have ? g_s : seq_sum_terms(n, lane, L, [&](int i) {
             const float px = (float)pts[i].x - cx, py = (float)pts[i].y - cy;
             return dabs((double)px) + dabs((double)py);
         });
