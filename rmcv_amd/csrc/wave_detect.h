@@ -269,9 +269,11 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
         const double inv_n = 1.0 / n;
         if ((lane & 31) < 21) (lane < 32 ? L.dm : L.terms)[lane & 31] = acc * inv_n;
         __builtin_amdgcn_wave_barrier();
+        // ... and both reductions at once: the lanes of the lower half reduce the plain attempt's matrix, those of the upper half the
+        // jittered one's (the same instruction stream on two sets of values); the first attempt whose determinant passes is broadcast
         int iter;
-        for (iter = 0; iter < 2; iter++) {
-            const double* src = iter ? L.terms : L.dm;
+        {
+            const double* src = lane < 32 ? L.dm : L.terms;
             {
                 int e = 0;
 #pragma unroll
@@ -280,7 +282,17 @@ __device__ inline int fit_ellipse_wave(const rmcv_point* __restrict__ pts, int n
                     for (int b = a; b < 6; b++, e++) DM[a][b] = DM[b][a] = src[e];
             }
             const double det = direct_reduce(DM, TM, &Ts, M);
-            if (dabs(det) > 1.0e-10) break;
+            const double det0 = lane_get(det, 0), det1 = lane_get(det, 32);
+            iter = dabs(det0) > 1.0e-10 ? 0 : (dabs(det1) > 1.0e-10 ? 1 : 2);
+            const int sel = iter == 1 ? 32 : 0;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    TM[a][b] = lane_get(TM[a][b], sel);
+                    M[a][b] = lane_get(M[a][b], sel);
+                }
+            Ts = lane_get(Ts, sel);
         }
         __builtin_amdgcn_wave_barrier();
         FSTAMP(2);
