@@ -49,7 +49,7 @@ WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200),   # BASELINE.json configs[2
              "legacy": (1280, 1024)}                     # FindLightBlobs (minAreaRect boxes, camp vote) in place of filter_lightblobs
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 # environment knobs that change what the timed region runs: refused unless --dev, echoed in config.dev_knobs either way
-DEV_KNOBS = ("RMCV_BENCH_STAGES", "RMCV_BENCH_AB", "RMCV_W4_ONE_PER_CU", "RMCV_EARLY_FREE", "RMCV_SPARSE_WAVES", "RMCV_PIXEL_GROUPS", "RMCV_K1_BPC", "RMCV_FUSE_SPARSE", "RMCV_CONTOURS_LITERAL",
+DEV_KNOBS = ("RMCV_BENCH_STAGES", "RMCV_BENCH_AB", "RMCV_W4_ONE_PER_CU", "RMCV_EARLY_FREE", "RMCV_CHAIN_COLD", "RMCV_SPARSE_WAVES", "RMCV_PIXEL_GROUPS", "RMCV_K1_BPC", "RMCV_FUSE_SPARSE", "RMCV_CONTOURS_LITERAL",
              "RMCV_K1_HALO_NT", "RMCV_K1_LINEAR", "RMCV_DENSE_DEFER", "RMCV_LIB_PATH", "RMCV_NO_MID")
 VARIANTS = {"plain": 0, "stress": 1, "dense1": 11, "dense2": 12, "dense3": 13, "dense4": 14, "dense": 14}
 

@@ -58,6 +58,8 @@ struct rmcv_pipeline {
     std::vector<int> ctx_last;          // per context: the slot of its last batch (-1: none)
     std::vector<int> slot_ctx;          // per slot: the context of its batch
     std::vector<hipEvent_t> ev_free;    // per slot: behind the LAST READER of its batch's pixel outputs (the sparse stage; before the compaction)
+    bool chain_cold = true, was_cold = false; // (dev knob RMCV_CHAIN_COLD=0)
+    int chain_cold_us = 60;             // (dev knob RMCV_CHAIN_COLD=n > 1: the delay in microseconds; 1: wait for the first launch's end instead)
     bool early_free = true;             // (dev knob RMCV_EARLY_FREE=0: a context's next batch waits for the whole list, as ev_done)
     bool split_now = false;            // the batches of the moment have a FEW dense frames: give those a launch and a stream of their own
     uint64_t split_batches = 0;        // batches submitted that way
@@ -91,6 +93,13 @@ static int cfail(rmcv_pipeline* pl, rmcv_ctx* c, int rc)
 {
     snprintf(pl->err, sizeof(pl->err), "%s", rmcv_last_error(c));
     return rc;
+}
+
+// holds a stream back for `ns` nanoseconds (one wavefront asleep; the constant-rate counter runs at 100 MHz)
+__global__ void k_delay(unsigned long long ns)
+{
+    const unsigned long long t0 = wall_clock64();
+    while ((wall_clock64() - t0) * 10ull < ns) __builtin_amdgcn_s_sleep(32);
 }
 
 extern "C" {
@@ -240,6 +249,8 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     pl->ctx_last.assign((size_t)d.depth, -1);
     pl->slot_ctx.assign((size_t)d.depth, 0);
     pl->hot = d.hot_contexts;
+    pl->chain_cold = !(getenv("RMCV_CHAIN_COLD") && atoi(getenv("RMCV_CHAIN_COLD")) == 0);
+    if (getenv("RMCV_CHAIN_COLD")) pl->chain_cold_us = atoi(getenv("RMCV_CHAIN_COLD")) > 1 ? atoi(getenv("RMCV_CHAIN_COLD")) : 0;
     pl->early_free = !(getenv("RMCV_EARLY_FREE") && atoi(getenv("RMCV_EARLY_FREE")) == 0);
     if (e != hipSuccess) {
         fprintf(stderr, "rmcv_pipeline_create: %s\n", hipGetErrorString(e));
@@ -386,6 +397,30 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     pl->ctx_last[j] = (int)k;
     pl->slot_ctx[k] = (int)j;
     ctx_external_order(c, pl->ev_done[k]);
+    // A burst's SECOND pixel launch is held back for 60 us (k_delay on its stream).  k_binary_ws is one workgroup per CU: when two
+    // launches reach an empty machine 15 us apart, whether the first has taken every CU by then is a coin toss -- if not, the two split
+    // the CUs, run side by side and END together, and so do the next pairs (each pair's ramp and tail in the open, both sparse kernels
+    // at once) until they drift apart: 0.258 instead of 0.242 ms per step over a 20-batch burst, in 15 % of the bursts
+    // (tools/trace_regions.py, profiles/r04k_burst_start.txt).  Held back, the second launch finds every CU taken and its workgroups
+    // move in as the first one's leave -- the steady state -- at no cost: they would have waited anyway.  (Waiting for the first
+    // launch's END instead puts the event's latency between the two: +1-3 %.)
+    if (fast && pl->chain_cold) {
+        bool cold = t == 0;
+        const size_t s_ = t ? (size_t)((t - 1) % (uint64_t)pl->cfg.depth) : 0;
+        if (t > 0) {
+            cold = pl->slot_ticket[s_] == t && hipEventQuery(pl->ev_done[s_]) == hipSuccess;
+            (void)hipGetLastError();
+        }
+        if (!cold && pl->was_cold && pl->slot_ticket[s_] == t) {
+            if (pl->chain_cold_us > 0) { // hold the second launch back until the first one's workgroups have taken every CU
+                hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, A, (unsigned long long)pl->chain_cold_us * 1000ull);
+                PCHK(pl, hipGetLastError(), "pipeline: k_delay");
+            } else
+                PCHK(pl, hipStreamWaitEvent(A, pl->ev_bin[s_], 0), "pipeline: chain a burst's second launch");
+        }
+        pl->was_cold = cold;
+    } else
+        pl->was_cold = false;
     ctx_pixel_shape(c, fast ? 1 : 0);
     rc = rmcv_batch_run(c, p, pixel, A);
     if (rc) return cfail(pl, c, rc);
