@@ -49,7 +49,7 @@ WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200),   # BASELINE.json configs[2
              "legacy": (1280, 1024)}                     # FindLightBlobs (minAreaRect boxes, camp vote) in place of filter_lightblobs
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 # environment knobs that change what the timed region runs: refused unless --dev, echoed in config.dev_knobs either way
-DEV_KNOBS = ("RMCV_BENCH_STAGES", "RMCV_BENCH_AB", "RMCV_W4_ONE_PER_CU", "RMCV_EARLY_FREE", "RMCV_CHAIN_COLD", "RMCV_SPARSE_WAVES", "RMCV_PIXEL_GROUPS", "RMCV_K1_BPC", "RMCV_FUSE_SPARSE", "RMCV_CONTOURS_LITERAL",
+DEV_KNOBS = ("RMCV_BENCH_STAGES", "RMCV_BENCH_AB", "RMCV_W4_ONE_PER_CU", "RMCV_EARLY_FREE", "RMCV_CHAIN_COLD", "RMCV_LAZY_BACK", "RMCV_SPARSE_WAVES", "RMCV_PIXEL_GROUPS", "RMCV_K1_BPC", "RMCV_FUSE_SPARSE", "RMCV_CONTOURS_LITERAL",
              "RMCV_K1_HALO_NT", "RMCV_K1_LINEAR", "RMCV_DENSE_DEFER", "RMCV_LIB_PATH", "RMCV_NO_MID")
 VARIANTS = {"plain": 0, "stress": 1, "dense1": 11, "dense2": 12, "dense3": 13, "dense4": 14, "dense": 14}
 
@@ -628,7 +628,7 @@ def main():
                    "frames_per_gpu": n, "stream_variant": args.variant, "one_dense_frame_per_batch": args.one_dense, "parallelism": "frame-shard x%d" % world,
                    "host_api": "rmcv_pipeline_submit (librmcv_hip.so): one call per step",
                    "batches_in_flight": info.depth, "pixel_streams": info.pixel_streams, "sparse_streams": info.sparse_streams, "dense_streams": info.dense_streams,
-                   "hot_contexts": info.hot_contexts, "batches_in_hot_contexts": int(pl.get_info().hot_batches), "pixel_kernel_of_calm_batches": roof_kernel,
+                   "hot_contexts": info.hot_contexts, "batches_in_hot_contexts": int(pl.get_info().hot_batches), "batches_finished_with_the_latency_kernel": int(pl.get_info().latency_batches), "pixel_kernel_of_calm_batches": roof_kernel,
                    "frame_sets": n_sets, "gpu_max_hw_queues": info.hw_queues_env, "pixel_groups_per_cu": groups_in_steps,
                    "sparse_waves_per_frame": waves_in_steps, "results_to_host_every_step": info.host_results == 1,
                    "stages": stages, "dev_knobs": knobs or None,

@@ -441,6 +441,8 @@ typedef struct {
     uint64_t dense_split;      /* batches whose dense frames were given a launch and a stream of their own (see dense_streams) */
     uint64_t hot_batches;      /* batches that ran in one of the hot contexts (see hot_contexts) */
     int32_t hot_contexts, _pad2;
+    uint64_t latency_batches;  /* batches whose back half ran with the latency kernel (8 wavefronts per frame): the newest batch when a call waited
+                                * for it -- wait / collect of it, drain -- before another submit (a burst's last batch; one batch at a time) */
 } rmcv_pipeline_info;
 void rmcv_default_pipeline_config(rmcv_pipeline_config* c);
 int  rmcv_pipeline_create(int device, const rmcv_limits* limits /* nullable */, const rmcv_pipeline_config* cfg /* nullable */, rmcv_pipeline** out);
@@ -458,7 +460,11 @@ rmcv_ctx* rmcv_pipeline_context_of(rmcv_pipeline* pl, uint64_t ticket);
 /* rmcv_pipeline_config::hot_contexts from the next submit on (3 .. depth - 1; 0 or -1: off).  Batches in flight are not touched. */
 int  rmcv_pipeline_set_hot_contexts(rmcv_pipeline* pl, int n);
 /* enqueue one batch of n_frames frames that are resident in HBM (layout as rmcv_batch_set_device_frames); stages must include
- * RMCV_STAGE_BINARY.  Asynchronous; *ticket (0, 1, 2, ...) names the batch.  The slot's previous batch (ticket - depth) is
+ * RMCV_STAGE_BINARY.  Asynchronous; *ticket (0, 1, 2, ...) names the batch.  Without a hook, the batch's back half (sparse stage,
+ * compaction) is enqueued by the NEXT call on the pipeline: another submit enqueues it as it always was; rmcv_pipeline_wait / _collect
+ * of this very ticket, or _drain, know that nothing will run beside it and use the latency kernel (8 wavefronts per frame) -- the
+ * last batch of a burst and a host that submits one batch at a time finish 0.03-0.08 ms earlier.  A submitted batch therefore
+ * completes only once the pipeline is called again (any call that names it, the next submit, drain, destroy).  The slot's previous batch (ticket - depth) is
  * overwritten: collect it first. */
 int  rmcv_pipeline_submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch,
                           const rmcv_params* p, int stages, uint64_t* ticket);

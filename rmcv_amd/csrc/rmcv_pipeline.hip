@@ -58,6 +58,24 @@ struct rmcv_pipeline {
     std::vector<int> ctx_last;          // per context: the slot of its last batch (-1: none)
     std::vector<int> slot_ctx;          // per slot: the context of its batch
     std::vector<hipEvent_t> ev_free;    // per slot: behind the LAST READER of its batch's pixel outputs (the sparse stage; before the compaction)
+    // The back half of the NEWEST batch (sparse stage, compaction, events, hook) is enqueued by the next call, not by its own submit:
+    // the next submit enqueues it as before -- nothing is lost, its first kernel waits for the pixel kernel anyway --, but a call that
+    // WAITS for the newest batch (wait / collect of it, drain) finds that no pixel launch will be beside it and runs it with 8
+    // wavefronts per frame: the last batch of a burst, or a host that submits one batch at a time, gets the latency kernel (0.09
+    // against 0.18 ms alone).
+    struct Pending {
+        bool valid = false;
+        uint64_t t = 0;
+        size_t k = 0;
+        rmcv_ctx* c = nullptr;
+        rmcv_params p{};
+        rmcv_legacy_params lp{};
+        bool has_lp = false, used = false;
+        int sparse = 0, n_frames = 0;
+        hipStream_t B = nullptr;
+    } pend;
+    uint64_t latency_batches = 0;
+    bool lazy_back = true;              // (dev knob RMCV_LAZY_BACK=0)
     bool chain_cold = true, was_cold = false; // (dev knob RMCV_CHAIN_COLD=0)
     int chain_cold_us = 60;             // (dev knob RMCV_CHAIN_COLD=n > 1: the delay in microseconds; 1: wait for the first launch's end instead)
     bool early_free = true;             // (dev knob RMCV_EARLY_FREE=0: a context's next batch waits for the whole list, as ev_done)
@@ -73,6 +91,8 @@ struct rmcv_pipeline {
     bool gather_pending = false;
     char err[256] = {0};
 };
+
+static int finish_back(rmcv_pipeline* pl, bool latency);
 
 static int pfail(rmcv_pipeline* pl, int code, const char* what, hipError_t e = hipSuccess)
 {
@@ -123,6 +143,7 @@ void rmcv_pipeline_destroy(rmcv_pipeline* pl)
 {
     if (!pl) return;
     hipSetDevice(pl->device);
+    if (!pl->ring.empty()) (void)finish_back(pl, true);
     for (auto s : pl->pix) if (s) hipStreamSynchronize(s);
     for (auto s : pl->sp) if (s) hipStreamSynchronize(s);
     for (auto s : pl->dn) if (s) hipStreamSynchronize(s);
@@ -249,6 +270,7 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     pl->ctx_last.assign((size_t)d.depth, -1);
     pl->slot_ctx.assign((size_t)d.depth, 0);
     pl->hot = d.hot_contexts;
+    pl->lazy_back = !(getenv("RMCV_LAZY_BACK") && atoi(getenv("RMCV_LAZY_BACK")) == 0);
     pl->chain_cold = !(getenv("RMCV_CHAIN_COLD") && atoi(getenv("RMCV_CHAIN_COLD")) == 0);
     if (getenv("RMCV_CHAIN_COLD")) pl->chain_cold_us = atoi(getenv("RMCV_CHAIN_COLD")) > 1 ? atoi(getenv("RMCV_CHAIN_COLD")) : 0;
     pl->early_free = !(getenv("RMCV_EARLY_FREE") && atoi(getenv("RMCV_EARLY_FREE")) == 0);
@@ -287,6 +309,7 @@ int rmcv_pipeline_get_info(const rmcv_pipeline* pl, rmcv_pipeline_info* o)
     o->dense_split = pl->split_batches;
     o->hot_batches = pl->hot_batches;
     o->hot_contexts = pl->hot;
+    o->latency_batches = pl->latency_batches;
     return RMCV_OK;
 }
 
@@ -310,6 +333,7 @@ static int slot_of(rmcv_pipeline* pl, uint64_t ticket);
 rmcv_ctx* rmcv_pipeline_context_of(rmcv_pipeline* pl, uint64_t ticket)
 {
     if (!pl) return nullptr;
+    if (pl->pend.valid) { hipSetDevice(pl->device); if (finish_back(pl, pl->pend.t == ticket)) return nullptr; }
     const int k = slot_of(pl, ticket);
     return k < 0 ? nullptr : pl->ring[(size_t)pl->slot_ctx[(size_t)k]];
 }
@@ -317,6 +341,7 @@ rmcv_ctx* rmcv_pipeline_context_of(rmcv_pipeline* pl, uint64_t ticket)
 int rmcv_pipeline_set_hook(rmcv_pipeline* pl, rmcv_pipeline_hook fn, void* user)
 {
     if (!pl) return RMCV_ERR_BAD_ARG;
+    if (pl->pend.valid) { hipSetDevice(pl->device); const int rcb = finish_back(pl, false); if (rcb) return rcb; } // (the batch in hand keeps the hook it was submitted under)
     if (pl->comm && fn) return pfail(pl, RMCV_ERR_BAD_ARG, "the pipeline already gathers with rmcv_gather (rmcv_pipeline_set_gather): one hook at a time");
     pl->hook = fn;
     pl->hook_user = user;
@@ -325,6 +350,7 @@ int rmcv_pipeline_set_hook(rmcv_pipeline* pl, rmcv_pipeline_hook fn, void* user)
 
 int rmcv_pipeline_set_gather(rmcv_pipeline* pl, rmcv_comm* comm, int root)
 {
+    if (pl && pl->pend.valid) { hipSetDevice(pl->device); const int rcb = finish_back(pl, false); if (rcb) return rcb; }
     if (!pl) return RMCV_ERR_BAD_ARG;
     if (pl->hook && comm) return pfail(pl, RMCV_ERR_BAD_ARG, "the pipeline already has a hook (rmcv_pipeline_set_hook): one at a time");
     int rc = rmcv_pipeline_drain(pl);
@@ -352,12 +378,100 @@ int rmcv_pipeline_set_gather(rmcv_pipeline* pl, rmcv_comm* comm, int root)
     return RMCV_OK;
 }
 
+// the back half of the newest batch (see rmcv_pipeline::Pending); latency: nothing will be launched beside it
+static int finish_back(rmcv_pipeline* pl, bool latency)
+{
+    if (!pl->pend.valid) return RMCV_OK;
+    pl->pend.valid = false;
+    const uint64_t t = pl->pend.t;
+    const size_t k = pl->pend.k;
+    rmcv_ctx* c = pl->pend.c;
+    const rmcv_params* p = &pl->pend.p;
+    const rmcv_legacy_params* lp = pl->pend.has_lp ? &pl->pend.lp : nullptr;
+    const bool used = pl->pend.used;
+    const int sparse = pl->pend.sparse, n_frames = pl->pend.n_frames;
+    hipStream_t B = pl->pend.B;
+    int rc = RMCV_OK;
+    const bool w8 = latency && pl->cfg.sparse_waves == 4 && !lp;
+    if (w8) {
+        rmcv_ctx_set_option(c, RMCV_OPT_SPARSE_WAVES, 8);
+        pl->latency_batches++;
+    }
+    struct Restore { rmcv_ctx* c; bool on; ~Restore() { if (on) rmcv_ctx_set_option(c, RMCV_OPT_SPARSE_WAVES, 4); } } restore{c, w8};
+    // Dense frames (beyond findContours' LDS tables: hundreds of borders, 0.5-1 ms on one workgroup) are left by the per-frame launch
+    // to a second launch with 8 wavefronts per frame on a stream of its own, the compaction behind it: the sparse stream B is free
+    // for the next batch when the batch's ordinary frames are through (one lit window per batch used to cost the whole loop 20-35 %).
+    // When: while the batch that last left this slot had SOME such frames but not many (its count sits in the record's host mirror:
+    // a camera's lit window stays for many batches).  A batch without any pays nothing (the second launch costs the plain stream
+    // 1-3 %: 256 workgroups of 8 wavefronts and 80 KB of LDS to be placed just to find their frame is not marked); a batch full of
+    // them is better off with every frame finished where it is (measured: 0.312 against 0.360 ms per step at 233 dense frames of 256).
+    if (used && !pl->dn.empty() && hipEventQuery(pl->ev_done[k]) == hipSuccess) {
+        const int32_t dense = reinterpret_cast<const int32_t*>(pl->h_rec[k])[pl->lim.max_frames + 2];
+        pl->split_now = dense > 0 && dense * 8 <= pl->slot_frames[k];
+    }
+    (void)hipGetLastError(); // (hipErrorNotReady is not an error)
+    const bool split = !w8 && pl->split_now && !pl->dn.empty() && !lp && (sparse & RMCV_STAGE_CONTOURS) && (sparse & RMCV_STAGE_BLOBS);
+    if (split) pl->split_batches++;
+    hipStream_t T = split ? pl->dn[k % pl->dn.size()] : B; // the stream the batch's list is finished on
+    // (a record's rewrite is ordered behind its readers by stream order: the slot meets the same stream every time -- unless the
+    // caller mixes stage masks that finish on different streams; then the old stream is drained first)
+    if (used && pl->slot_stream[k] && pl->slot_stream[k] != T) PCHK(pl, hipStreamSynchronize(pl->slot_stream[k]), "pipeline: change of the slot's stream");
+    if (sparse) {
+        if (split) {
+            ctx_defer_phase(c, 2); // the first launch only: frames beyond the LDS tables are marked and left alone
+            rc = rmcv_batch_run(c, p, sparse & ~RMCV_STAGE_POSE, B);
+            if (rc == RMCV_OK) {
+                PCHK(pl, hipEventRecord(pl->ev_sp[k], B), "pipeline: mark the first sparse launch");
+                PCHK(pl, hipStreamWaitEvent(T, pl->ev_sp[k], 0), "pipeline: chain the dense frames");
+                ctx_defer_phase(c, 3); // the second launch only (+ the pose stage, which needs every frame's armours)
+                rc = rmcv_batch_run(c, p, sparse, T);
+            }
+            ctx_defer_phase(c, 0);
+        } else
+            rc = lp ? rmcv_batch_run_legacy(c, p, lp, sparse, B) : rmcv_batch_run(c, p, sparse, B);
+        if (rc) return cfail(pl, c, rc);
+    }
+    PCHK(pl, hipEventRecord(pl->ev_free[k], T), "pipeline: mark the pixel outputs' last reader");
+    // the record is rewritten: a reader on another stream (the hook's) must be through; readers on B are by stream order
+    if (pl->ev_hook[k]) {
+        PCHK(pl, hipStreamWaitEvent(T, (hipEvent_t)pl->ev_hook[k], 0), "pipeline: wait for the record's reader");
+        pl->ev_hook[k] = nullptr;
+    }
+    int32_t* offs = reinterpret_cast<int32_t*>(pl->d_rec[k]);
+    // host_results: the compaction kernel stores the record a second time, straight into the slot's pinned host mirror (posted
+    // writes over PCIe, only the armours there are); the slot's event -- a default event: system-scope release -- makes them visible
+    rc = ctx_compact(c, pl->d_rec[k] + pl->head_bytes, pl->cfg.armour_cap, offs, offs + pl->lim.max_frames + 1, T, pl->hd_rec[k], (int)pl->head_bytes);
+    if (rc) return cfail(pl, c, rc);
+    // the context's buffers are free from here on: the next pixel kernel of this slot does not wait for the hook
+    PCHK(pl, hipEventRecord(pl->ev_done[k], T), "pipeline: mark the slot");
+    pl->slot_ticket[k] = t + 1;
+    pl->slot_frames[k] = n_frames;
+    pl->slot_stream[k] = T;
+    if (pl->comm) {
+        // one communicator: its operations must execute in one order on every rank; they are issued in ticket order on alternating
+        // streams, so each gather first waits (an event, on the GPU) for the one before
+        if (pl->gather_pending) PCHK(pl, hipStreamWaitEvent(T, pl->ev_gather, 0), "pipeline: order the gathers");
+        rc = rmcv_gather(pl->comm, pl->d_rec[k], pl->record_bytes, pl->rank == pl->root ? pl->d_recv[k] : nullptr, pl->root, T);
+        if (rc) return pfail(pl, rc, rmcv_comm_last_error(pl->comm));
+        PCHK(pl, hipEventRecord(pl->ev_gather, T), "pipeline: mark the gather");
+        pl->gather_pending = true;
+        PCHK(pl, hipEventRecord(pl->ev_host[k], T), "pipeline: mark the gather"); // wait / collect cover the gather too
+    } else if (pl->hook) {
+        void* done = nullptr;
+        rc = pl->hook(pl->hook_user, t, pl->d_rec[k], pl->record_bytes, T, &done);
+        if (rc) return pfail(pl, rc, "the pipeline hook failed");
+        pl->ev_hook[k] = done;
+    }
+    return RMCV_OK;
+}
+
 static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch, const rmcv_params* p,
                   const rmcv_legacy_params* lp, int stages, uint64_t* ticket)
 {
     if (!pl || !d_frames || !p) return RMCV_ERR_BAD_ARG;
     if (!(stages & RMCV_STAGE_BINARY)) return pfail(pl, RMCV_ERR_BAD_ARG, "a pipelined batch starts at RMCV_STAGE_BINARY");
     hipSetDevice(pl->device);
+    { const int rcb = finish_back(pl, false); if (rcb) return rcb; } // the batch before this one: a pixel launch follows it
     const uint64_t t = pl->next_ticket;
     const size_t k = (size_t)(t % (uint64_t)pl->cfg.depth);
     const bool used = pl->slot_ticket[k] != 0;
@@ -426,72 +540,21 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     if (rc) return cfail(pl, c, rc);
     PCHK(pl, hipEventRecord(pl->ev_bin[k], A), "pipeline: mark the pixel kernel");
     PCHK(pl, hipStreamWaitEvent(B, pl->ev_bin[k], 0), "pipeline: chain the sparse stages");
-    // Dense frames (beyond findContours' LDS tables: hundreds of borders, 0.5-1 ms on one workgroup) are left by the per-frame launch
-    // to a second launch with 8 wavefronts per frame on a stream of its own, the compaction behind it: the sparse stream B is free
-    // for the next batch when the batch's ordinary frames are through (one lit window per batch used to cost the whole loop 20-35 %).
-    // When: while the batch that last left this slot had SOME such frames but not many (its count sits in the record's host mirror:
-    // a camera's lit window stays for many batches).  A batch without any pays nothing (the second launch costs the plain stream
-    // 1-3 %: 256 workgroups of 8 wavefronts and 80 KB of LDS to be placed just to find their frame is not marked); a batch full of
-    // them is better off with every frame finished where it is (measured: 0.312 against 0.360 ms per step at 233 dense frames of 256).
-    if (used && !pl->dn.empty() && hipEventQuery(pl->ev_done[k]) == hipSuccess) {
-        const int32_t dense = reinterpret_cast<const int32_t*>(pl->h_rec[k])[pl->lim.max_frames + 2];
-        pl->split_now = dense > 0 && dense * 8 <= pl->slot_frames[k];
-    }
-    (void)hipGetLastError(); // (hipErrorNotReady is not an error)
-    const bool split = pl->split_now && !pl->dn.empty() && !lp && (sparse & RMCV_STAGE_CONTOURS) && (sparse & RMCV_STAGE_BLOBS);
-    if (split) pl->split_batches++;
-    hipStream_t T = split ? pl->dn[k % pl->dn.size()] : B; // the stream the batch's list is finished on
-    // (a record's rewrite is ordered behind its readers by stream order: the slot meets the same stream every time -- unless the
-    // caller mixes stage masks that finish on different streams; then the old stream is drained first)
-    if (used && pl->slot_stream[k] && pl->slot_stream[k] != T) PCHK(pl, hipStreamSynchronize(pl->slot_stream[k]), "pipeline: change of the slot's stream");
-    if (sparse) {
-        if (split) {
-            ctx_defer_phase(c, 2); // the first launch only: frames beyond the LDS tables are marked and left alone
-            rc = rmcv_batch_run(c, p, sparse & ~RMCV_STAGE_POSE, B);
-            if (rc == RMCV_OK) {
-                PCHK(pl, hipEventRecord(pl->ev_sp[k], B), "pipeline: mark the first sparse launch");
-                PCHK(pl, hipStreamWaitEvent(T, pl->ev_sp[k], 0), "pipeline: chain the dense frames");
-                ctx_defer_phase(c, 3); // the second launch only (+ the pose stage, which needs every frame's armours)
-                rc = rmcv_batch_run(c, p, sparse, T);
-            }
-            ctx_defer_phase(c, 0);
-        } else
-            rc = lp ? rmcv_batch_run_legacy(c, p, lp, sparse, B) : rmcv_batch_run(c, p, sparse, B);
-        if (rc) return cfail(pl, c, rc);
-    }
-    PCHK(pl, hipEventRecord(pl->ev_free[k], T), "pipeline: mark the pixel outputs' last reader");
-    // the record is rewritten: a reader on another stream (the hook's) must be through; readers on B are by stream order
-    if (pl->ev_hook[k]) {
-        PCHK(pl, hipStreamWaitEvent(T, (hipEvent_t)pl->ev_hook[k], 0), "pipeline: wait for the record's reader");
-        pl->ev_hook[k] = nullptr;
-    }
-    int32_t* offs = reinterpret_cast<int32_t*>(pl->d_rec[k]);
-    // host_results: the compaction kernel stores the record a second time, straight into the slot's pinned host mirror (posted
-    // writes over PCIe, only the armours there are); the slot's event -- a default event: system-scope release -- makes them visible
-    rc = ctx_compact(c, pl->d_rec[k] + pl->head_bytes, pl->cfg.armour_cap, offs, offs + pl->lim.max_frames + 1, T, pl->hd_rec[k], (int)pl->head_bytes);
-    if (rc) return cfail(pl, c, rc);
-    // the context's buffers are free from here on: the next pixel kernel of this slot does not wait for the hook
-    PCHK(pl, hipEventRecord(pl->ev_done[k], T), "pipeline: mark the slot");
-    pl->slot_ticket[k] = t + 1;
-    pl->slot_frames[k] = n_frames;
-    pl->slot_stream[k] = T;
     pl->next_ticket = t + 1;
     if (ticket) *ticket = t;
-    if (pl->comm) {
-        // one communicator: its operations must execute in one order on every rank; they are issued in ticket order on alternating
-        // streams, so each gather first waits (an event, on the GPU) for the one before
-        if (pl->gather_pending) PCHK(pl, hipStreamWaitEvent(T, pl->ev_gather, 0), "pipeline: order the gathers");
-        rc = rmcv_gather(pl->comm, pl->d_rec[k], pl->record_bytes, pl->rank == pl->root ? pl->d_recv[k] : nullptr, pl->root, T);
-        if (rc) return pfail(pl, rc, rmcv_comm_last_error(pl->comm));
-        PCHK(pl, hipEventRecord(pl->ev_gather, T), "pipeline: mark the gather");
-        pl->gather_pending = true;
-        PCHK(pl, hipEventRecord(pl->ev_host[k], T), "pipeline: mark the gather"); // wait / collect cover the gather too
-    } else if (pl->hook) {
-        void* done = nullptr;
-        rc = pl->hook(pl->hook_user, t, pl->d_rec[k], pl->record_bytes, T, &done);
-        if (rc) return pfail(pl, rc, "the pipeline hook failed");
-        pl->ev_hook[k] = done;
-    }
+    pl->pend.valid = true;
+    pl->pend.t = t;
+    pl->pend.k = k;
+    pl->pend.c = c;
+    pl->pend.p = *p;
+    pl->pend.has_lp = lp != nullptr;
+    if (lp) pl->pend.lp = *lp;
+    pl->pend.used = used;
+    pl->pend.sparse = sparse;
+    pl->pend.n_frames = n_frames;
+    pl->pend.B = B;
+    // (a hook or the gather hands the record to a consumer the pipeline does not see waiting: its batches are finished here and now)
+    if (!pl->lazy_back || pl->hook || pl->comm) return finish_back(pl, false);
     return RMCV_OK;
 }
 
@@ -519,6 +582,11 @@ static int slot_of(rmcv_pipeline* pl, uint64_t ticket)
 int rmcv_pipeline_wait(rmcv_pipeline* pl, uint64_t ticket)
 {
     if (!pl) return RMCV_ERR_BAD_ARG;
+    if (pl->pend.valid) { // (the newest batch's back half: with the latency kernel if it is the one waited for)
+        hipSetDevice(pl->device);
+        const int rcb = finish_back(pl, pl->pend.t == ticket);
+        if (rcb) return rcb;
+    }
     const int k = slot_of(pl, ticket);
     if (k < 0) return pfail(pl, RMCV_ERR_BAD_ARG, "no such ticket in flight (never issued, or its slot has been reused)");
     hipSetDevice(pl->device);
@@ -561,6 +629,7 @@ int rmcv_pipeline_drain(rmcv_pipeline* pl)
 {
     if (!pl) return RMCV_ERR_BAD_ARG;
     hipSetDevice(pl->device);
+    { const int rcb = finish_back(pl, true); if (rcb) return rcb; }
     for (auto s : pl->pix) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
     for (auto s : pl->sp) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
     for (auto s : pl->dn) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
@@ -575,6 +644,7 @@ int rmcv_pipeline_drain(rmcv_pipeline* pl)
 int rmcv_pipeline_record(rmcv_pipeline* pl, uint64_t ticket, void** d_record, void** hip_stream)
 {
     if (!pl) return RMCV_ERR_BAD_ARG;
+    if (pl->pend.valid) { hipSetDevice(pl->device); const int rcb = finish_back(pl, pl->pend.t == ticket); if (rcb) return rcb; }
     const int k = slot_of(pl, ticket);
     if (k < 0) return pfail(pl, RMCV_ERR_BAD_ARG, "no such ticket in flight (never issued, or its slot has been reused)");
     if (d_record) *d_record = pl->d_rec[(size_t)k];
@@ -584,6 +654,7 @@ int rmcv_pipeline_record(rmcv_pipeline* pl, uint64_t ticket, void** d_record, vo
 
 int rmcv_pipeline_gathered(rmcv_pipeline* pl, uint64_t ticket, void** d_recv, int64_t* bytes)
 {
+    if (pl && pl->pend.valid) { hipSetDevice(pl->device); const int rcb = finish_back(pl, pl->pend.t == ticket); if (rcb) return rcb; }
     if (!pl || !pl->comm) return RMCV_ERR_BAD_ARG;
     const int k = slot_of(pl, ticket);
     if (k < 0) return pfail(pl, RMCV_ERR_BAD_ARG, "no such ticket in flight (never issued, or its slot has been reused)");

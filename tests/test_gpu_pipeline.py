@@ -411,3 +411,37 @@ def test_hot_contexts_config_and_switch():
         q = Pipeline(device=0, max_frames=n, max_width=w, max_height=h, **kw)
         assert q.info.hot_contexts == want, kw
         q.close()
+
+
+def test_the_newest_batch_is_finished_by_the_call_that_waits_for_it(oracle):
+    """the back half of the newest batch is enqueued by the next call: by the next submit as ever, by a wait / collect of that very
+    ticket or a drain with the latency kernel (rmcv_pipeline_info::latency_batches); results are the same either way"""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, w, h = 48, 1280, 1024
+    pl = Pipeline(device=0, max_frames=n, max_width=w, max_height=h)
+    p = default_params()
+    fr = [synth.batch(5150 + i, n, w, h, CAMP_BLUE, i % 2, threads=16) for i in range(6)]
+    d = [torch.from_numpy(f).to(dev) for f in fr]
+    t0 = pl.submit(d[0].data_ptr(), n, h, w, p, STAGE_ALL)
+    t1 = pl.submit(d[1].data_ptr(), n, h, w, p, STAGE_ALL)              # finishes t0 the ordinary way
+    assert pl.get_info().latency_batches == 0
+    check_batch(oracle, fr[0], *pl.collect(t0))                        # an older ticket: t1's back half goes out the ordinary way too
+    assert pl.get_info().latency_batches == 0
+    check_batch(oracle, fr[1], *pl.collect(t1))
+    t2 = pl.submit(d[2].data_ptr(), n, h, w, p, STAGE_ALL)
+    check_batch(oracle, fr[2], *pl.collect(t2))                        # the newest ticket itself: the latency kernel
+    assert pl.get_info().latency_batches == 1
+    t3 = pl.submit(d[3].data_ptr(), n, h, w, p, STAGE_ALL)
+    pl.drain()
+    assert pl.get_info().latency_batches == 2
+    check_batch(oracle, fr[3], *pl.collect(t3))
+    t4 = pl.submit(d[4].data_ptr(), n, h, w, p, STAGE_ALL)
+    c = pl.context_of(t4)                                              # names the newest ticket: finishes it (latency kernel), does not wait
+    pl.wait(t4)
+    r = oracle.detect_frame(fr[4][7])
+    pts, co = c.contours(7)
+    assert np.array_equal(co, r["offs"]) and np.array_equal(pts, r["pts"])
+    assert pl.get_info().latency_batches == 3
+    t5 = pl.submit(d[5].data_ptr(), n, h, w, p, STAGE_ALL)
+    pl.close()                                                         # a pipeline destroyed with a batch in hand finishes it first
