@@ -1,3 +1,5 @@
+"""dev tool: one 256-frame batch at a time through the pipeline (submit; wait) -- the latency a host sees.  RMCV_LAZY_BACK=0: the back half enqueued
+by submit itself (4 wavefronts per frame) instead of by the wait (8)."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
