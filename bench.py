@@ -89,7 +89,7 @@ def parse_args(argv=None):
                     help="streams for the second, 8-wavefront launch that takes a batch's frames beyond findContours' LDS tables "
                          "(rmcv_pipeline_config::dense_streams; 0: the library's default, 2; -1: no such launch)")
     ap.add_argument("--hot-contexts", type=int, default=0,
-                    help="rmcv_pipeline_config::hot_contexts: contexts the calm batches take turns at (0 = the library's default of 4, -1 = off)")
+                    help="rmcv_pipeline_config::hot_contexts: contexts the calm batches take turns at (0 = the library's default: derived from the bit planes' size, 4 for C3, 3 for C5; -1 = off)")
     ap.add_argument("--device-results", action="store_true",
                     help="leave the armour lists in HBM (rmcv_pipeline_config::host_results = 2) instead of copying every step's to pinned host memory")
     ap.add_argument("--gather", choices=("auto", "torch", "abi"), default="auto",
@@ -267,8 +267,8 @@ def main():
         pl.set_hook(hook)
 
     # the kernel that moves the algorithmic 4 B/px in the steps: k_binary_ws in the contexts that take turns while the batches are calm
-    # (rmcv_pipeline_config::hot_contexts), k_binary where that is off or does not apply (a classifier / pose stage, the legacy blob stage)
-    hot_mode = info.hot_contexts > 0 and legacy is None and not (stages & (STAGE_IDENTITY | STAGE_POSE))
+    # (rmcv_pipeline_config::hot_contexts), k_binary where that is off or does not apply (a pose stage, the legacy blob stage)
+    hot_mode = info.hot_contexts > 0 and legacy is None and not (stages & STAGE_POSE)
     roof_kernel = "k_binary_ws" if hot_mode else "k_binary"
     roof_ctxs = pl.contexts[:info.hot_contexts] if hot_mode else pl.contexts
 
@@ -301,14 +301,19 @@ def main():
         pl.close()
         return
 
-    cur = {"pl": pl, "stages": stages, "sets": frames_k, "w": W, "h": H}
+    cur = {"pl": pl, "stages": stages, "sets": frames_k, "w": W, "h": H, "max_submit": 0.0}
     step_no = [0]
 
     def step():
         """ONE call into the library: the next batch, on the next frame set"""
         fr = cur["sets"][step_no[0] % len(cur["sets"])]
         step_no[0] += 1
-        return cur["pl"].submit(fr.data_ptr(), n, cur["h"], cur["w"], params, cur["stages"], legacy=legacy)
+        t_s = time.perf_counter()
+        t_ = cur["pl"].submit(fr.data_ptr(), n, cur["h"], cur["w"], params, cur["stages"], legacy=legacy)
+        t_s = time.perf_counter() - t_s
+        if t_s > cur["max_submit"]:
+            cur["max_submit"] = t_s                            # the longest single submit call (host time): a submit never blocks
+        return t_
 
     def barrier():
         # the pipeline and every gather are drained BEFORE the process group's own collectives (barrier, all_reduce) are enqueued:
@@ -330,6 +335,7 @@ def main():
         return float(t.item())
 
     hot_each = []                                              # batches of each region that ran in a hot context
+    submit_max_each = []                                       # the longest single submit call of each region (host seconds)
 
     def regions(steps, repeats):
         """`repeats` regions of exactly `steps` steps between barrier + synchronize pairs -> (wall seconds each, host enqueue seconds each)"""
@@ -337,6 +343,7 @@ def main():
         for _ in range(repeats):
             barrier()
             h0 = cur["pl"].get_info().hot_batches
+            cur["max_submit"] = 0.0
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
@@ -344,6 +351,7 @@ def main():
             barrier()
             rep.append(agree_max(time.perf_counter() - t0))
             hot_each.append(int(cur["pl"].get_info().hot_batches - h0))
+            submit_max_each.append(cur["max_submit"])
         return rep, enq
 
     def median(x):
@@ -369,8 +377,10 @@ def main():
     # the timed region: EXACTLY --steps steps between two (barrier + synchronize), MAX over ranks; repeated --repeats times,
     # value = the median repeat (median and min over the passes)
     del hot_each[:]
+    del submit_max_each[:]
     rep_dt, enq_dt = regions(args.steps, max(1, args.repeats))
     hot_timed = list(hot_each)
+    submit_max_timed = list(submit_max_each)
     if hot_mode and 2 * sum(hot_timed) < len(hot_timed) * args.steps:   # (a stream with dense frames is never calm: its steps run k_binary)
         hot_mode, roof_kernel, roof_ctxs = False, "k_binary", pl.contexts
     dt = median(rep_dt)
@@ -379,7 +389,28 @@ def main():
     # beside the metric: ONE long region (25 x --steps steps): a timed region starts with an empty pipeline and ends by draining it,
     # which a 20-step region pays in full and a camera feed never does.  Reported, never `value`.
     steady = None
+    collect_variant = None
     if not args.no_extras:
+        # beside the metric: the same regions with every list READ by the host inside the loop -- rmcv_pipeline_collect of ticket
+        # t - depth + 1 right behind submit t, as the header's example loop does (the metric's region only submits; its lists go to
+        # pinned host memory every step but nobody reads them until the region is over)
+        def step_collect():
+            t_ = step()
+            if t_ + 1 >= base_t + ns:
+                cur["pl"].collect(t_ - ns + 1)
+        reps_c = []
+        for _ in range(3):
+            barrier()
+            base_t = cur["pl"].get_info().submitted
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_collect()
+            barrier()
+            reps_c.append(agree_max(time.perf_counter() - t0))
+        dc = median(reps_c)
+        collect_variant = {"ms_per_step": round(dc / args.steps * 1e3, 4), "frames_per_s": round(world * n * args.steps / dc, 1),
+                           "ms_per_step_each": [round(x / args.steps * 1e3, 4) for x in reps_c],
+                           "note": "the timed region's loop with rmcv_pipeline_collect(t - depth + 1) behind every submit: the host reads every list as it goes; not the metric"}
         long_steps = 25 * args.steps
         (dts,), _ = regions(long_steps, 1)
         steady = {"steps": long_steps, "ms_per_step": round(dts / long_steps * 1e3, 4), "frames_per_s": round(world * n * long_steps / dts, 1),
@@ -616,8 +647,13 @@ def main():
                          "ms_per_step_median": round(ms_per_step, 4), "ms_per_step_min": round(srt[0] / args.steps * 1e3, 4),
                          "value_at_min": round(world * n * args.steps / srt[0], 1), "warmup_steps_requested": args.warmup, "warmup_steps_by_time": warm_steps,
                          "host_enqueue_ms_per_step": round(median(enq_dt) / args.steps * 1e3, 4),
-                         "note": "each repeat = exactly `steps` calls of rmcv_pipeline_submit between barrier+synchronize pairs; value/ms_per_step = the median repeat"},
-        "steady_state": steady,
+                         "max_submit_host_ms_each": [round(x * 1e3, 4) for x in submit_max_timed],
+                         "host_blocking_calls": int(pl.get_info().host_blocking_calls),
+                         "note": "each repeat = exactly `steps` calls of rmcv_pipeline_submit between barrier+synchronize pairs; value/ms_per_step = the median repeat. "
+                                 "A region starts on an empty machine and ends with a drain: its second pixel launch is held back (k_delay, <= 60 us) so that the first takes "
+                                 "every CU, and its last batch's sparse stage runs with the latency kernel (the drain knows nothing follows) -- both are the library's "
+                                 "behaviour for any burst, not the bench's; steady_state and steps_with_collect show the same loop without / beside them"},
+        "steady_state": steady, "steps_with_collect": collect_variant,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%s: batch=%d/GPU %dx%d BGR, blue lb=80, close3x3 + findContours + lightblob fit + armour "
                                "pairing%s%s" % (args.workload.upper(), n, W, H,
@@ -702,17 +738,28 @@ def main():
                       ("plain + one dense4 frame per batch", 0, True)]
         barrier()
         pl_d = make_pipeline(ns, args.pixel_streams, args.sparse_streams, mc=4096)
-        sweep, region = [], max(60, 3 * args.steps)
+        sweep, region = [], max(40, 2 * args.steps)
         for label, var, one in levels:
             sets_, _ = (frames_k[:4], None) if (var == 0 and not one) else frame_sets(4, W, H, var, one)
             cur["pl"], cur["sets"] = pl_d, sets_
+            # warm-up in two goes with a drain between: the pipeline's policies (hot contexts, the dense frames' second launch) follow the
+            # records that have COME BACK -- after the drain the second go runs under the level's own policy, so the timed regions start
+            # in the level's steady state (round 4's sweep timed the policy's switch-over with the first steps of its one region)
             for _ in range(2 * ns):
                 step()
-            (dsw,), _ = regions(region, 1)
-            dsw /= region
-            cnt_ = pl_d.context_of(pl_d.get_info().submitted - 1).counts()
+            barrier()
+            for _ in range(ns):
+                step()
+            n_sub0 = len(submit_max_each)
+            rep_sw, _ = regions(region, 3)
+            each_sw = [x / region for x in rep_sw]
+            dsw = median(each_sw)
+            info_d = pl_d.get_info()
+            cnt_ = pl_d.context_of(info_d.submitted - 1).counts()
             st_ = cnt_["status"]
-            sweep.append({"stream": label, "ms_per_step": round(dsw * 1e3, 4), "frames_per_s": round(n / dsw, 1),
+            sweep.append({"stream": label, "ms_per_step": round(dsw * 1e3, 4), "ms_per_step_each": [round(x * 1e3, 4) for x in each_sw],
+                          "max_submit_host_ms": round(max(submit_max_each[n_sub0:]) * 1e3, 4), "host_blocking_calls": int(info_d.host_blocking_calls),
+                          "frames_per_s": round(n / dsw, 1),
                           "contours_per_frame": round(float(cnt_["n_contours"].mean()), 1),
                           "points_per_frame": round(float(cnt_["n_points"].mean()), 1),
                           "frames_mid_tier": int(np.count_nonzero(st_ & 64)), "frames_slow_path": int(np.count_nonzero(st_ & 16)),
@@ -725,7 +772,8 @@ def main():
         for lv in sweep:
             lv["x_plain"] = round(lv["ms_per_step"] / base_, 3)
         out["density_sweep"] = {"steps_per_region": region, "levels": sweep, "seconds": round(time.perf_counter() - t_sw, 1),
-                                "note": "steady-state regions of the steps' own loop (%d batches in flight over %d sparse streams, 4 frame sets per level); "
+                                "note": "three steady-state regions per level of the steps' own loop (%d batches in flight over %d sparse streams, 4 frame sets per "
+                                        "level), the median; max_submit_host_ms = the longest single rmcv_pipeline_submit call of the level's regions; "
                                         "x_plain = against this sweep's own plain level; not the metric" % (info.depth, info.sparse_streams)}
 
     if extras and args.workload == "c3" and args.variant == 0 and not args.pose and not args.one_dense:
@@ -812,11 +860,17 @@ def main():
                 subprocess.run([cc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "frame_chain.c"), "-o", exe,
                                 "-L", libdir, "-lrmcv_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, timeout=120)
                 cp = subprocess.run([exe, str(W), str(H)], capture_output=True, text=True, timeout=120)
-                ch = {}
+                ch, last_ = {}, None
                 for ln in cp.stdout.splitlines():
                     w_ = ln.split()
                     if len(w_) > 6 and w_[1] == "median":
-                        ch[w_[0]] = {"median_ms": float(w_[2]), "min_ms": float(w_[4]), "p90_ms": float(w_[6])}
+                        last_ = w_[0]
+                        ch[last_] = {"median_ms": float(w_[2]), "min_ms": float(w_[4]), "p90_ms": float(w_[6])}
+                    elif last_ and ln.strip().startswith("extract_color on the host"):
+                        import re
+                        # where rmcv_extract_color's host time goes (rmcv_ctx_frame_timing): median (p90) microseconds per step
+                        ch[last_]["extract_color_host_us"] = {k.strip(): [float(a), float(b_)] for k, a, b_ in
+                                                              re.findall(r"  ([a-zA-Z+ 2]+?) ([0-9.]+) \(([0-9.]+)\)", ln.split(":", 1)[1])}
                 if ch:
                     sf["c_host"] = dict(ch, note="tools/frame_chain.c: the three C-ABI calls from C, 300 chains per mode")
         except Exception as e:  # noqa: BLE001 -- a side measurement: report, never fail the bench line

@@ -36,6 +36,8 @@ extern "C" {
 #define RMCV_ERR_HIP (-4)       /* a HIP runtime call failed: see rmcv_last_error        */
 #define RMCV_ERR_NO_DEVICE (-5) /* no gfx950 device: this library has no CPU path        */
 #define RMCV_ERR_RCCL (-6)      /* librccl could not be loaded, or an RCCL call failed: see rmcv_comm_last_error */
+#define RMCV_ERR_TIMEOUT (-7)   /* work on the GPU did not finish within the deadline (RMCV_OPT_WAIT_TIMEOUT_MS /
+                                 * rmcv_pipeline_set_wait_timeout); the message names the kernel or copy enqueued last */
 
 /* rm::camp -- include/core.h:20-23 */
 #define RMCV_CAMP_RED 0
@@ -186,6 +188,20 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * consecutive batches and the sparse kernels share every CU.  A pipeline chooses per batch (rmcv_pipeline_config::hot_contexts)
  * and overrides this.  Same results. */
 #define RMCV_OPT_PIXEL_SHAPE 14
+/* RMCV_OPT_WAIT_TIMEOUT_MS: the deadline of every wait a call of this context makes for its work on the GPU, in milliseconds
+ * (default 5000; 0: none).  The reference's process loop is real-time and latest-wins (executable/main.cpp:157, 169, 197): a drop-in
+ * must not park its caller for good behind a kernel that never finishes.  No entry point calls hipStreamSynchronize /
+ * hipEventSynchronize: waits poll the stream (spinning for the first 2 ms -- the runtime's own wait parks the thread after ~0.1 ms,
+ * and its wake-up costs the per-frame chain another 0.1 ms --, then yielding, then sleeping 0.2 ms at a time) and give up at the
+ * deadline with RMCV_ERR_TIMEOUT; rmcv_last_error then names the kernel or copy enqueued last.  After RMCV_ERR_TIMEOUT the work is
+ * STILL IN FLIGHT: the buffers handed to the call (frame, binary_out) stay borrowed until a later call on the context succeeds
+ * (every call first waits, with the same deadline, for what is in flight) or the context is destroyed; rmcv_ctx_destroy waits
+ * once more and, if the work has still not finished, leaks the context's device memory instead of freeing it under a kernel. */
+#define RMCV_OPT_WAIT_TIMEOUT_MS 15
+/* RMCV_OPT_TEST_DELAY_US: the next rmcv_extract_color / rmcv_batch_run of the context first holds its stream back for this many
+ * microseconds (one sleeping wavefront): a stand-in for a kernel that does not finish in time.  One shot.  A test hook
+ * (tests/test_gpu_deadline.py). */
+#define RMCV_OPT_TEST_DELAY_US 16
 int  rmcv_ctx_set_option(rmcv_ctx* ctx, int option, int value);
 /* launches of k_binary_ws (RMCV_OPT_PIXEL_SHAPE 1) by this process so far: a diagnostic -- an option that is set but whose
  * conditions a batch does not meet falls back to k_binary silently (tests/test_gpu_pixel_shape.py) */
@@ -193,6 +209,10 @@ int64_t rmcv_pixel_ws_launches(void);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */
 int  rmcv_ctx_check_guards(rmcv_ctx* ctx, int32_t* n_damaged);
+/* where the last rmcv_extract_color spent its time on the HOST, six figures in microseconds: us[0] waiting for earlier work, binding,
+ * enqueuing the upload; us[1] enqueuing the kernels; us[2] enqueuing the byte image's download; us[3] waiting for it; us[4] waiting
+ * for the frame's kernels; us[5] handing the lists over.  cap >= 6.  A diagnosis hook (tools/frame_chain.c prints the medians). */
+int  rmcv_ctx_frame_timing(const rmcv_ctx* ctx, double* us, int cap);
 /* drop the pinning RMCV_OPT_FRAME_UPLOAD = 2 made for `frame` (NULL: all of them); drains the context's stream first */
 int  rmcv_ctx_forget_frame_buffer(rmcv_ctx* ctx, const void* frame);
 
@@ -399,9 +419,15 @@ int  rmcv_track_step(rmcv_track* tracking, int32_t* n_tracking, int cap, rmcv_tr
  *
  * Single-owner like a context: calls on one pipeline must not overlap.  The frames handed to submit are borrowed until the ticket
  * is collected (or waited for).  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once
- * when the HIP runtime starts: the default schedule wants 8 or more (kernels of two batches that share a queue cannot overlap).  The
- * library sets GPU_MAX_HW_QUEUES=12 in the process environment when it is LOADED and the variable is unset -- effective if no HIP
- * call preceded the load; rmcv_pipeline_get_info reports what the variable reads. */
+ * when the HIP runtime starts: the default schedule wants 8 or more (kernels of two batches that share a queue cannot overlap).
+ * The library does NOT touch the process environment (round 4's load-time setenv is gone): a host that wants the pipelined schedule
+ * calls rmcv_hw_queues_hint() before its first HIP call, or exports GPU_MAX_HW_QUEUES=12 itself; rmcv_pipeline_get_info reports
+ * what the variable reads and what the schedule wants.
+ *
+ * rmcv_pipeline_submit NEVER BLOCKS the host (round 5): it allocates nothing (the ring's contexts hold everything a batch of the
+ * limits' size needs from rmcv_pipeline_create on), synchronises nothing and copies nothing synchronously -- a change of geometry
+ * (planes zeroed, frame order recomputed) and a slot's change of finishing stream are enqueued work and event waits on the GPU.
+ * rmcv_pipeline_info::host_blocking_calls counts the exceptions: it stays 0. */
 typedef struct rmcv_pipeline rmcv_pipeline;
 typedef struct {            /* 0 in any field = the default; rmcv_default_pipeline_config fills them in */
     int32_t depth;          /* batches in flight = slots (records, tickets) = contexts in the ring (8)  */
@@ -420,13 +446,15 @@ typedef struct {            /* 0 in any field = the default; rmcv_default_pipeli
                              * 1.3 x the plain step time without, 1.01 x with).  Batches without such frames, and batches full of them,
                              * run as if this were off.  -1: off                                                              (4)  */
     int32_t hot_contexts;   /* WHILE the batches are calm -- no frame of the record that last came back went beyond findContours' LDS
-                             * tables, no classifier / pose stage asked for -- the batches take turns at the first `hot_contexts`
+                             * tables, no pose stage asked for -- the batches take turns at the first `hot_contexts`
                              * contexts of the ring (slot, record and ticket window stay `depth` deep) and run the wave-specialised pixel
                              * kernel (RMCV_OPT_PIXEL_SHAPE 1).  What a batch writes with ordinary stores and reads right back -- the
                              * 46 MB bit plane first of all -- then stays in the 256 MB Infinity Cache instead of going to HBM and
                              * back: 3-8 % on the plain stream.  A context's next batch waits for its last one's list, so dense
                              * batches (0.5-1 ms of sparse work) would stall the pixel stream: those run one context per slot, as
-                             * with -1.  Needs host_results = 1.  -1: off                                                     (4)  */
+                             * with -1.  Needs host_results = 1 and depth >= 4.  0: DERIVED per geometry -- as many contexts as keep
+                             * the batches' bit planes within 200 MB of the cache, 3 .. depth - 1 (4 at 256 x 1280x1024, 3 at
+                             * 256 x 1920x1200); n: exactly n (3 .. depth - 1); -1: off                                       (0)  */
     int32_t _reserved;
 } rmcv_pipeline_config;
 typedef struct {
@@ -443,7 +471,16 @@ typedef struct {
     int32_t hot_contexts, _pad2;
     uint64_t latency_batches;  /* batches whose back half ran with the latency kernel (8 wavefronts per frame): the newest batch when a call waited
                                 * for it -- wait / collect of it, drain -- before another submit (a burst's last batch; one batch at a time) */
+    uint64_t host_blocking_calls; /* allocations, host-side synchronisations and blocking copies made inside rmcv_pipeline_submit since the
+                                * pipeline was created: 0 (tests/test_gpu_pipeline.py asserts it over plain, dense and re-shaped streams) */
+    int32_t wait_timeout_ms, _pad3; /* rmcv_pipeline_set_wait_timeout */
+    uint64_t held_back;        /* pixel launches held back behind a burst's first one (k_delay): only launches of the wave-specialised
+                                * kernel on every CU, for a quarter of their expected time, 60 us at most, none below 100 us of launch */
 } rmcv_pipeline_info;
+/* GPU_MAX_HW_QUEUES=12 in the process environment unless the variable is set already; returns what it reads afterwards.  Effective
+ * only BEFORE the process's first HIP call (the runtime reads the variable once); not thread-safe (setenv) -- call it first thing
+ * in main.  12 = the default schedule's 2 + 4 + 4 streams + the null stream; more is harmful. */
+int  rmcv_hw_queues_hint(void);
 void rmcv_default_pipeline_config(rmcv_pipeline_config* c);
 int  rmcv_pipeline_create(int device, const rmcv_limits* limits /* nullable */, const rmcv_pipeline_config* cfg /* nullable */, rmcv_pipeline** out);
 void rmcv_pipeline_destroy(rmcv_pipeline* pl);   /* drains first */
@@ -455,10 +492,15 @@ rmcv_ctx* rmcv_pipeline_context(rmcv_pipeline* pl, int slot);
 /* the context a ticket's batch ran in, for the per-stage getters (binary image, contours, blobs, counts) on a ticket that has been
  * waited for.  The ticket's RECORD (rmcv_pipeline_collect / _record) lives until ticket + depth is submitted; its context's buffers
  * only until the context's next batch, which can be as early as ticket + hot_contexts (rmcv_pipeline_config): read them before
- * submitting that many more.  NULL for a ticket that is not live. */
+ * submitting that many more.  NULL for a ticket that is not live OR whose context a later batch has taken (rmcv_pipeline_last_error
+ * says which). */
 rmcv_ctx* rmcv_pipeline_context_of(rmcv_pipeline* pl, uint64_t ticket);
 /* rmcv_pipeline_config::hot_contexts from the next submit on (3 .. depth - 1; 0 or -1: off).  Batches in flight are not touched. */
 int  rmcv_pipeline_set_hot_contexts(rmcv_pipeline* pl, int n);
+/* the deadline of rmcv_pipeline_wait / _collect / _drain (and of the ring contexts' own waits), milliseconds; default 5000, 0: none.
+ * A wait that runs out returns RMCV_ERR_TIMEOUT (the batch is still in flight; waiting again is allowed);
+ * rmcv_pipeline_last_error names the enqueue made last. */
+int  rmcv_pipeline_set_wait_timeout(rmcv_pipeline* pl, int ms);
 /* enqueue one batch of n_frames frames that are resident in HBM (layout as rmcv_batch_set_device_frames); stages must include
  * RMCV_STAGE_BINARY.  Asynchronous; *ticket (0, 1, 2, ...) names the batch.  Without a hook, the batch's back half (sparse stage,
  * compaction) is enqueued by the NEXT call on the pipeline: another submit enqueues it as it always was; rmcv_pipeline_wait / _collect

@@ -26,7 +26,7 @@ TRACK = np.dtype([("armour", ARMOUR), ("timestamp", "<i8"), ("lost_count", "<i4"
                   ("gain", "<f8", (6, 6))])  # rmcv_track
 assert POINT.itemsize == 8 and LIGHTBLOB.itemsize == 56 and ARMOUR.itemsize == 88 and TRACK.itemsize == 2552
 
-OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE, ERR_RCCL = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE, ERR_RCCL, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
 COMM_ID_BYTES = 128
 CAMP_RED, CAMP_BLUE, CAMP_GUIDELIGHT, CAMP_NEUTRAL = 0, 1, 2, -1
 MORPH_NONE, MORPH_DILATE, MORPH_CLOSE = 0, 1, 2
@@ -39,21 +39,22 @@ OPT_DENSE_DEFER = 7
 OPT_PIXEL_HALO_NT = 11
 OPT_OVERLOADS = 13
 OPT_PIXEL_SHAPE = 14
-OPT_PIXEL_SHAPE = 14
+OPT_WAIT_TIMEOUT_MS = 15
+OPT_TEST_DELAY_US = 16
 STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE, STAGE_NO_IMAGE = 1, 2, 4, 8, 15, 16, 32, 64
 SVM_FEATURES = 1200
 FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_SLOW_PATH, FRAME_MID_PATH = 1, 2, 4, 8, 16, 64
 
 EXPORTS = [
     "rmcv_abi_version", "rmcv_default_params", "rmcv_default_limits", "rmcv_ctx_create", "rmcv_ctx_destroy",
-    "rmcv_last_error", "rmcv_ctx_set_option", "rmcv_ctx_forget_frame_buffer", "rmcv_ctx_check_guards", "rmcv_extract_color", "rmcv_filter_lightblobs", "rmcv_filter_armours", "rmcv_fit_ellipse",
+    "rmcv_last_error", "rmcv_ctx_set_option", "rmcv_ctx_forget_frame_buffer", "rmcv_ctx_check_guards", "rmcv_ctx_frame_timing", "rmcv_extract_color", "rmcv_filter_lightblobs", "rmcv_filter_armours", "rmcv_fit_ellipse",
     "rmcv_batch_upload", "rmcv_batch_set_device_frames", "rmcv_batch_run", "rmcv_batch_sync", "rmcv_batch_run_timed",
     "rmcv_batch_counts", "rmcv_batch_get_binary", "rmcv_batch_get_contours", "rmcv_batch_get_blobs",
     "rmcv_batch_get_armours", "rmcv_batch_device_views", "rmcv_batch_compact_armours", "rmcv_synth_frame", "rmcv_synth_checksum",
     "rmcv_svm_load", "rmcv_classify_armours", "rmcv_batch_get_identities", "rmcv_batch_get_icons",
     "rmcv_default_pnp_config", "rmcv_pnp_load", "rmcv_locate_armours", "rmcv_batch_set_base2gripper", "rmcv_batch_get_poses",
     "rmcv_max_iou", "rmcv_identity_max", "rmcv_comm_unique_id", "rmcv_comm_create", "rmcv_comm_destroy", "rmcv_comm_info", "rmcv_comm_last_error", "rmcv_gather",
-    "rmcv_default_pipeline_config", "rmcv_pipeline_create", "rmcv_pipeline_destroy", "rmcv_pipeline_last_error", "rmcv_pipeline_get_info", "rmcv_pipeline_context", "rmcv_pipeline_context_of", "rmcv_pipeline_set_hot_contexts", "rmcv_pixel_ws_launches",
+    "rmcv_default_pipeline_config", "rmcv_pipeline_create", "rmcv_pipeline_destroy", "rmcv_pipeline_last_error", "rmcv_pipeline_get_info", "rmcv_pipeline_context", "rmcv_pipeline_context_of", "rmcv_pipeline_set_hot_contexts", "rmcv_pipeline_set_wait_timeout", "rmcv_hw_queues_hint", "rmcv_pixel_ws_launches",
     "rmcv_pipeline_submit", "rmcv_pipeline_submit_legacy", "rmcv_pipeline_wait", "rmcv_pipeline_collect", "rmcv_pipeline_drain", "rmcv_pipeline_record",
     "rmcv_pipeline_set_hook", "rmcv_pipeline_set_gather", "rmcv_pipeline_gathered", "rmcv_device_alloc", "rmcv_device_free", "rmcv_device_upload", "rmcv_device_download",
     "rmcv_track_init", "rmcv_track_reset", "rmcv_track_update", "rmcv_track_predict", "rmcv_track_step", "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
@@ -99,7 +100,8 @@ class PipelineInfo(C.Structure):
                 ("sparse_waves", C.c_int32), ("pixel_groups", C.c_int32), ("host_results", C.c_int32), ("dense_streams", C.c_int32),
                 ("max_frames", C.c_int32), ("hw_queues_env", C.c_int32), ("hw_queues_wanted", C.c_int32), ("_pad", C.c_int32),
                 ("record_bytes", C.c_int64), ("armours_offset", C.c_int64), ("submitted", C.c_uint64), ("collected", C.c_uint64),
-                ("dense_split", C.c_uint64), ("hot_batches", C.c_uint64), ("hot_contexts", C.c_int32), ("_pad2", C.c_int32), ("latency_batches", C.c_uint64)]
+                ("dense_split", C.c_uint64), ("hot_batches", C.c_uint64), ("hot_contexts", C.c_int32), ("_pad2", C.c_int32), ("latency_batches", C.c_uint64),
+                ("host_blocking_calls", C.c_uint64), ("wait_timeout_ms", C.c_int32), ("_pad3", C.c_int32), ("held_back", C.c_uint64)]
 
 
 # rmcv_pipeline_hook: int (*)(void* user, uint64_t ticket, void* d_record, int64_t record_bytes, void* hip_stream, void** done_event)
@@ -133,6 +135,8 @@ def load(path):
     L.rmcv_pipeline_context.argtypes = [C.c_void_p, C.c_int]
     L.rmcv_pipeline_set_hot_contexts.restype = C.c_int
     L.rmcv_pipeline_set_hot_contexts.argtypes = [C.c_void_p, C.c_int]
+    L.rmcv_pipeline_set_wait_timeout.restype = C.c_int
+    L.rmcv_pipeline_set_wait_timeout.argtypes = [C.c_void_p, C.c_int]
     L.rmcv_pixel_ws_launches.restype = C.c_int64
     L.rmcv_pixel_ws_launches.argtypes = []
     L.rmcv_pipeline_context_of.restype = C.c_void_p

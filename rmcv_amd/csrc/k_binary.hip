@@ -627,6 +627,21 @@ static hipError_t launch_binary_t(const Geom& g, const Bufs& b, int lower_bound,
     return hipSuccess;
 }
 
+// launch_binary_t's own rule, for the pipeline's hold-back of a burst's second launch: will the batch bound to (g, b) run as ONE launch of
+// k_binary_ws with a workgroup on every CU?
+bool binary_ws_full(const Geom& g, const Bufs& b, int lower_bound)
+{
+    const int strips = (g.h + SR - 1) / SR;
+    const bool aligned = (g.w % 64 == 0) && (g.stride % 16 == 0) && (g.frame_pitch % 16 == 0) && ((uintptr_t)b.frames % 16 == 0);
+    const int64_t lim = 0xFFFFF000ll;
+    const int64_t per_frame = std::max<int64_t>(std::max<int64_t>(g.frame_pitch, g.plane_pitch * 8), (int64_t)g.w * g.h);
+    const bool one_launch = aligned && (int64_t)g.n_frames * per_frame < lim;
+    const bool linear = one_launch && !g.pixel_rowquad && g.stride == 3 * g.w;
+    const int n_cu = g.n_cu > 0 ? g.n_cu : 256, n_blocks = g.n_frames * strips;
+    const size_t planes_ws = ((size_t)2 * (SR + 4) + SR) * g.ww * sizeof(uint64_t);
+    return g.pixel_ws && linear && lower_bound > 0 && n_blocks * 2 > n_cu && planes_ws <= 60 * 1024 && n_blocks >= n_cu;
+}
+
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s)
 {
     // imgproc.cpp:56-65: GUIDELIGHT G-R; BLUE B-R; everything else (RED, NEUTRAL) R-B.  BGR byte order.

@@ -138,6 +138,7 @@ hipError_t launch_match(const Geom& g, const Bufs& b, const Limits& lim, const r
 hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, bool identity, int waves, hipStream_t s);
 hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s);
+bool binary_ws_full(const Geom& g, const Bufs& b, int lower_bound); // the batch will run as one launch of k_binary_ws with a workgroup on every CU
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
@@ -180,13 +181,21 @@ void ctx_external_order(rmcv_ctx* c, hipEvent_t done);
 // rmcv_batch_compact_armours + the batch's OR-ed status word
 int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s, void* hd_record = nullptr, int host_head = 0);
 const Limits& ctx_limits(const rmcv_ctx* c);
-// The foreground plane + row masks a context's pixel kernel writes and its sparse kernel reads: its own, or -- for the batches to come --
-// another context's of the same limits (a pipeline keeps FEWER planes in rotation than contexts: rmcv_pipeline.hip).  The caller orders
-// the users of a plane; a context zeroes only its OWN plane when the frame geometry changes.
-void ctx_planes(rmcv_ctx* c, uint64_t** bits, uint32_t** rowmask);
 // 1: whole batches with contiguous rows go to the wave-specialised pixel kernel (k_binary_ws.inc), 0: k_binary
 void ctx_pixel_shape(rmcv_ctx* c, int shape);
-void ctx_use_planes(rmcv_ctx* c, uint64_t* bits, uint32_t* rowmask);
+// rmcv_batch_set_device_frames without a blocking call: a change of geometry (planes zeroed, frame order recomputed) is ENQUEUED on `s`,
+// which the caller has made wait for the context's last batch
+int ctx_bind_frames(rmcv_ctx* c, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch, hipStream_t s);
+// everything binding a full batch would allocate (the mid tier's scratch), now
+int ctx_prepare_ring(rmcv_ctx* c);
+// allocations, host-side synchronisations and blocking copies this context has made while binding geometries
+uint64_t ctx_blocking_calls(const rmcv_ctx* c);
+int ctx_wait_timeout_ms(const rmcv_ctx* c);
+bool pixel_ws_full(const rmcv_ctx* c, int lower_bound); // binary_ws_full of what is bound to the context
+// waits that poll with a deadline instead of parking the thread in the runtime: 0 done, 1 deadline passed, -1 HIP error (*err)
+int wait_stream_deadline(hipStream_t s, int timeout_ms, hipError_t* err);
+int wait_event_deadline(hipEvent_t ev, int timeout_ms, hipError_t* err);
+hipError_t launch_delay(unsigned long long ns, hipStream_t s); // holds `s` back for `ns` nanoseconds
 // what rmcv_batch_run would refuse for (p, stages), checked without enqueuing anything
 int ctx_check_stages(rmcv_ctx* c, const rmcv_params* p, int stages);
 // Geom::dense_defer for the runs that follow: 0 off, 1 both launches on the run's stream (RMCV_OPT_DENSE_DEFER), 2 / 3 the first / second only

@@ -25,9 +25,6 @@
 
 using namespace rmcv;
 
-// HIP reads GPU_MAX_HW_QUEUES once, when the runtime starts.  Loaded before the first HIP call of the process (a C or C++ host that
-// links the library; bench.py sets the variable itself before torch starts HIP) this default takes effect; an existing value wins.
-__attribute__((constructor(101))) static void rmcv_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
 
 struct rmcv_pipeline {
     int device = 0;
@@ -89,10 +86,22 @@ struct rmcv_pipeline {
     std::vector<uint8_t*> d_recv;      // root: per slot, n_ranks x record_bytes
     hipEvent_t ev_gather = nullptr;    // behind the last gather: one communicator's operations run in ONE order on every rank
     bool gather_pending = false;
+    // Nothing in submit blocks the host (round 5): the mid tier's scratch of every ring context is allocated at creation, a change of
+    // geometry is enqueued (planes zeroed, frame order recomputed on the batch's pixel stream), a slot's change of finishing stream
+    // is an event wait on the GPU.  The counter proves it: allocations, host-side synchronisations and blocking copies made inside
+    // submit (by the pipeline or by the contexts' binding of a geometry) since the pipeline was created.
+    uint64_t blocking_base = 0, own_blocking = 0, held_back = 0;
+    std::vector<hipEvent_t> ev_chg;    // per slot: the tail of the stream the slot's record was finished on, when that stream changes
+    int wait_timeout_ms = 5000;        // rmcv_pipeline_set_wait_timeout
+    const char* last_what = "nothing"; // the enqueue made last (PCHK's label): named when a wait runs out
+    int hot_cfg = 0;                   // rmcv_pipeline_config::hot_contexts as given (0: derived from the bound geometry)
+    int64_t hot_plane_bytes = 0;       // ... the bit planes' bytes of a batch of the geometry `hot` was derived for
+    bool hot_identity = true;          // batches with a classifier stage take turns at the hot contexts too (round 5)
     char err[256] = {0};
 };
 
 static int finish_back(rmcv_pipeline* pl, bool latency);
+static int hot_for(const rmcv_pipeline* pl, int n_frames, int w, int h);
 
 static int pfail(rmcv_pipeline* pl, int code, const char* what, hipError_t e = hipSuccess)
 {
@@ -105,6 +114,7 @@ static int pfail(rmcv_pipeline* pl, int code, const char* what, hipError_t e = h
 }
 #define PCHK(pl, call, what)                                               \
     do {                                                                   \
+        (pl)->last_what = what;                                            \
         hipError_t e__ = (call);                                           \
         if (e__ != hipSuccess) return pfail((pl), RMCV_ERR_HIP, what, e__); \
     } while (0)
@@ -115,11 +125,34 @@ static int cfail(rmcv_pipeline* pl, rmcv_ctx* c, int rc)
     return rc;
 }
 
-// holds a stream back for `ns` nanoseconds (one wavefront asleep; the constant-rate counter runs at 100 MHz)
-__global__ void k_delay(unsigned long long ns)
+// a wait with the pipeline's deadline: RMCV_ERR_TIMEOUT names the enqueue made last
+static int pwait_event(rmcv_pipeline* pl, hipEvent_t ev, const char* what)
 {
-    const unsigned long long t0 = wall_clock64();
-    while ((wall_clock64() - t0) * 10ull < ns) __builtin_amdgcn_s_sleep(32);
+    hipError_t e = hipSuccess;
+    const int rcw = wait_event_deadline(ev, pl->wait_timeout_ms, &e);
+    if (rcw < 0) return pfail(pl, RMCV_ERR_HIP, what, e);
+    if (rcw > 0) {
+        snprintf(pl->err, sizeof(pl->err), "%s: not finished after %d ms (rmcv_pipeline_set_wait_timeout); enqueued last: %s", what, pl->wait_timeout_ms, pl->last_what);
+        return RMCV_ERR_TIMEOUT;
+    }
+    return RMCV_OK;
+}
+static int pwait_stream(rmcv_pipeline* pl, hipStream_t st, const char* what)
+{
+    hipError_t e = hipSuccess;
+    const int rcw = wait_stream_deadline(st, pl->wait_timeout_ms, &e);
+    if (rcw < 0) return pfail(pl, RMCV_ERR_HIP, what, e);
+    if (rcw > 0) {
+        snprintf(pl->err, sizeof(pl->err), "%s: not finished after %d ms (rmcv_pipeline_set_wait_timeout); enqueued last: %s", what, pl->wait_timeout_ms, pl->last_what);
+        return RMCV_ERR_TIMEOUT;
+    }
+    return RMCV_OK;
+}
+static uint64_t ring_blocking(const rmcv_pipeline* pl)
+{
+    uint64_t n = 0;
+    for (auto c : pl->ring) n += ctx_blocking_calls(c);
+    return n;
 }
 
 extern "C" {
@@ -136,7 +169,8 @@ void rmcv_default_pipeline_config(rmcv_pipeline_config* c)
     c->pixel_groups = 2;
     c->host_results = 1;
     c->dense_streams = 4;
-    c->hot_contexts = 4;   // measured (round 4, process against process on five boxes): 4 < 5 << 3, 6; 0.236-0.243 against 0.244-0.268 ms per step
+    c->hot_contexts = 0;   // derived: as many contexts as keep the batches' bit planes inside the Infinity Cache (4 at 256 x 1280x1024: measured in
+                           // round 4, process against process on five boxes: 4 < 5 << 3, 6; 0.236-0.243 against 0.244-0.268 ms per step)
 }
 
 void rmcv_pipeline_destroy(rmcv_pipeline* pl)
@@ -144,15 +178,23 @@ void rmcv_pipeline_destroy(rmcv_pipeline* pl)
     if (!pl) return;
     hipSetDevice(pl->device);
     if (!pl->ring.empty()) (void)finish_back(pl, true);
-    for (auto s : pl->pix) if (s) hipStreamSynchronize(s);
-    for (auto s : pl->sp) if (s) hipStreamSynchronize(s);
-    for (auto s : pl->dn) if (s) hipStreamSynchronize(s);
+    {   // with the deadline: batches that do not finish are not waited for without one -- the pipeline is leaked instead
+        bool stuck = false;
+        for (auto s : pl->pix) if (s) stuck |= pwait_stream(pl, s, "destroy") == RMCV_ERR_TIMEOUT;
+        for (auto s : pl->sp) if (s) stuck |= pwait_stream(pl, s, "destroy") == RMCV_ERR_TIMEOUT;
+        for (auto s : pl->dn) if (s) stuck |= pwait_stream(pl, s, "destroy") == RMCV_ERR_TIMEOUT;
+        if (stuck) {
+            fprintf(stderr, "rmcv_pipeline_destroy: %s; the pipeline's buffers are leaked\n", pl->err);
+            return;
+        }
+    }
     for (auto c : pl->ring) rmcv_ctx_destroy(c);
     for (auto e : pl->ev_bin) if (e) hipEventDestroy(e);
     for (auto e : pl->ev_done) if (e) hipEventDestroy(e);
     for (auto e : pl->ev_host) if (e) hipEventDestroy(e);
     for (auto e : pl->ev_sp) if (e) hipEventDestroy(e);
     for (auto e : pl->ev_free) if (e) hipEventDestroy(e);
+    for (auto e : pl->ev_chg) if (e) hipEventDestroy(e);
     if (pl->ev_gather) hipEventDestroy(pl->ev_gather);
     for (auto p : pl->d_rec) if (p) hipFree(p);
     for (auto p : pl->d_recv) if (p) hipFree(p);
@@ -188,10 +230,15 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     if (d.dense_streams > d.depth) d.dense_streams = d.depth;
     // (what came back is read from the records' host mirror; fewer than 3 in rotation stall even sparse batches; the 4-wavefront sparse
     // kernel is the one that fits beside the wave-specialised pixel kernel)
-    if (d.hot_contexts < 3 || d.hot_contexts >= d.depth || d.host_results != 1 || d.sparse_waves != 4) d.hot_contexts = 0;
+    // hot_contexts: 0 = derived from the bound geometry (hot_for below), -1 = off, n = exactly n
+    const int hot_given = cfg ? cfg->hot_contexts : 0;
+    if (hot_given > 0 && (hot_given < 3 || hot_given >= d.depth)) d.hot_contexts = -1;
+    if (d.depth < 4 || d.host_results != 1 || d.sparse_waves != 4) d.hot_contexts = -1;
     rmcv_pipeline* pl = new (std::nothrow) rmcv_pipeline();
     if (!pl) return RMCV_ERR_NOMEM;
     pl->device = device;
+    pl->hot_cfg = d.hot_contexts < 0 ? -1 : (hot_given > 0 ? hot_given : 0);
+    if (d.hot_contexts < 0) d.hot_contexts = 0;
     pl->cfg = d;
     int rc = RMCV_OK;
     for (int k = 0; k < d.depth && rc == RMCV_OK; k++) {
@@ -201,6 +248,8 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
             pl->ring.push_back(c);
             rc = rmcv_ctx_set_option(c, RMCV_OPT_SPARSE_WAVES, d.sparse_waves);
             if (rc == RMCV_OK) rc = rmcv_ctx_set_option(c, RMCV_OPT_PIXEL_GROUPS, d.pixel_groups);
+            // everything a batch will need is allocated NOW, for every context of the ring: rmcv_pipeline_submit never allocates
+            if (rc == RMCV_OK) rc = ctx_prepare_ring(c);
         }
     }
     if (rc != RMCV_OK) {
@@ -239,9 +288,11 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
         hipEvent_t a = nullptr, b = nullptr, h = nullptr, sp_ = nullptr;
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sp_, hipEventDisableTiming);
         pl->ev_sp.push_back(sp_);
-        hipEvent_t fr_ = nullptr;
+        hipEvent_t fr_ = nullptr, chg_ = nullptr;
         if (e == hipSuccess) e = hipEventCreateWithFlags(&fr_, hipEventDisableTiming);
         pl->ev_free.push_back(fr_);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&chg_, hipEventDisableTiming);
+        pl->ev_chg.push_back(chg_);
         uint8_t *dr = nullptr, *hr = nullptr;
         e = hipEventCreateWithFlags(&a, dev_flags);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b, dev_flags); // (the host reads the record's mirror behind ev_done: it must stay a system-scope event)
@@ -269,11 +320,16 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_gather, hipEventDisableTiming);
     pl->ctx_last.assign((size_t)d.depth, -1);
     pl->slot_ctx.assign((size_t)d.depth, 0);
-    pl->hot = d.hot_contexts;
+    pl->hot = hot_for(pl, pl->lim.max_frames, pl->lim.max_width, pl->lim.max_height); // (derived again for the geometry of every submit)
+    pl->wait_timeout_ms = ctx_wait_timeout_ms(pl->ring[0]);
+#ifdef RMCV_DEV_KNOBS // A/B switches of the schedule's parts (make EXTRA=-DRMCV_DEV_KNOBS): not in a product build
     pl->lazy_back = !(getenv("RMCV_LAZY_BACK") && atoi(getenv("RMCV_LAZY_BACK")) == 0);
     pl->chain_cold = !(getenv("RMCV_CHAIN_COLD") && atoi(getenv("RMCV_CHAIN_COLD")) == 0);
     if (getenv("RMCV_CHAIN_COLD")) pl->chain_cold_us = atoi(getenv("RMCV_CHAIN_COLD")) > 1 ? atoi(getenv("RMCV_CHAIN_COLD")) : 0;
     pl->early_free = !(getenv("RMCV_EARLY_FREE") && atoi(getenv("RMCV_EARLY_FREE")) == 0);
+    if (getenv("RMCV_HOT_IDENTITY")) pl->hot_identity = atoi(getenv("RMCV_HOT_IDENTITY")) != 0;
+#endif
+    pl->blocking_base = ring_blocking(pl);
     if (e != hipSuccess) {
         fprintf(stderr, "rmcv_pipeline_create: %s\n", hipGetErrorString(e));
         (void)hipGetLastError();
@@ -282,6 +338,13 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     }
     *out = pl;
     return RMCV_OK;
+}
+
+int rmcv_hw_queues_hint(void)
+{
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    return q ? atoi(q) : 0;
 }
 
 const char* rmcv_pipeline_last_error(const rmcv_pipeline* pl) { return pl ? pl->err : "null pipeline"; }
@@ -310,6 +373,9 @@ int rmcv_pipeline_get_info(const rmcv_pipeline* pl, rmcv_pipeline_info* o)
     o->hot_batches = pl->hot_batches;
     o->hot_contexts = pl->hot;
     o->latency_batches = pl->latency_batches;
+    o->host_blocking_calls = pl->own_blocking + ring_blocking(pl) - pl->blocking_base;
+    o->wait_timeout_ms = pl->wait_timeout_ms;
+    o->held_back = pl->held_back;
     return RMCV_OK;
 }
 
@@ -322,11 +388,34 @@ rmcv_ctx* rmcv_pipeline_context(rmcv_pipeline* pl, int slot)
 int rmcv_pipeline_set_hot_contexts(rmcv_pipeline* pl, int n)
 {
     if (!pl) return RMCV_ERR_BAD_ARG;
-    if (n <= 0) { pl->hot = 0; return RMCV_OK; }
+    if (n <= 0) { pl->hot = 0; pl->hot_cfg = -1; return RMCV_OK; }
     if (n < 3 || n >= pl->cfg.depth) return pfail(pl, RMCV_ERR_BAD_ARG, "hot_contexts: 3 .. depth - 1, or 0 / -1 for off");
     if (pl->cfg.host_results != 1 || pl->cfg.sparse_waves != 4) return pfail(pl, RMCV_ERR_BAD_ARG, "hot_contexts needs host_results = 1 and sparse_waves = 4");
-    pl->hot = n;
+    pl->hot = pl->hot_cfg = n;
     return RMCV_OK;
+}
+
+int rmcv_pipeline_set_wait_timeout(rmcv_pipeline* pl, int ms)
+{
+    if (!pl || ms < 0) return RMCV_ERR_BAD_ARG;
+    pl->wait_timeout_ms = ms;
+    for (auto c : pl->ring) rmcv_ctx_set_option(c, RMCV_OPT_WAIT_TIMEOUT_MS, ms);
+    return RMCV_OK;
+}
+
+// How many contexts take turns while the batches are calm: as many as keep the bit planes of the batches in flight inside the 256 MB
+// Infinity Cache (with the planes resident their writes never reach HBM; one context too many and every plane line is a
+// miss).  Budget 200 MB of the 256 (frames and byte image stream past it with the nt hint; the sparse kernels' tables want the rest):
+// 256 x 1280x1024 -> 46 MB per batch -> 4 (the measured optimum: 4 < 5 << 3, 6); 256 x 1920x1200 -> 79 MB -> 2, which is below the
+// three a context's reuse needs as slack -> 3.
+static int hot_for(const rmcv_pipeline* pl, int n_frames, int w, int h)
+{
+    if (pl->hot_cfg != 0) return pl->hot_cfg > 0 ? pl->hot_cfg : 0;
+    const int64_t plane = (int64_t)n_frames * (h + 2) * ((w + 63) / 64 + 2) * 8;
+    int n = (int)((200ll << 20) / (plane > 0 ? plane : 1));
+    if (n < 3) n = 3;
+    if (n > pl->cfg.depth - 1) n = pl->cfg.depth - 1;
+    return n;
 }
 
 static int slot_of(rmcv_pipeline* pl, uint64_t ticket);
@@ -335,7 +424,10 @@ rmcv_ctx* rmcv_pipeline_context_of(rmcv_pipeline* pl, uint64_t ticket)
     if (!pl) return nullptr;
     if (pl->pend.valid) { hipSetDevice(pl->device); if (finish_back(pl, pl->pend.t == ticket)) return nullptr; }
     const int k = slot_of(pl, ticket);
-    return k < 0 ? nullptr : pl->ring[(size_t)pl->slot_ctx[(size_t)k]];
+    if (k < 0) { pfail(pl, RMCV_ERR_BAD_ARG, "no such ticket in flight (never issued, or its slot has been reused)"); return nullptr; }
+    // (with the hot contexts a context is reused as early as ticket + hot_contexts, while the ticket's RECORD lives until ticket + depth)
+    if (pl->ctx_last[(size_t)pl->slot_ctx[(size_t)k]] != k) { pfail(pl, RMCV_ERR_BAD_ARG, "the ticket's context has been reused by a later batch (its record is still there: rmcv_pipeline_collect)"); return nullptr; }
+    return pl->ring[(size_t)pl->slot_ctx[(size_t)k]];
 }
 
 int rmcv_pipeline_set_hook(rmcv_pipeline* pl, rmcv_pipeline_hook fn, void* user)
@@ -414,8 +506,12 @@ static int finish_back(rmcv_pipeline* pl, bool latency)
     if (split) pl->split_batches++;
     hipStream_t T = split ? pl->dn[k % pl->dn.size()] : B; // the stream the batch's list is finished on
     // (a record's rewrite is ordered behind its readers by stream order: the slot meets the same stream every time -- unless the
-    // caller mixes stage masks that finish on different streams; then the old stream is drained first)
-    if (used && pl->slot_stream[k] && pl->slot_stream[k] != T) PCHK(pl, hipStreamSynchronize(pl->slot_stream[k]), "pipeline: change of the slot's stream");
+    // caller mixes stage masks that finish on different streams, or a stream's dense frames come and go)
+    // ... the new stream waits, on the GPU, for the tail of the old one
+    if (used && pl->slot_stream[k] && pl->slot_stream[k] != T) {
+        PCHK(pl, hipEventRecord(pl->ev_chg[k], pl->slot_stream[k]), "pipeline: change of the slot's stream (mark)");
+        PCHK(pl, hipStreamWaitEvent(T, pl->ev_chg[k], 0), "pipeline: change of the slot's stream (wait)");
+    }
     if (sparse) {
         if (split) {
             ctx_defer_phase(c, 2); // the first launch only: frames beyond the LDS tables are marked and left alone
@@ -475,6 +571,7 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     const uint64_t t = pl->next_ticket;
     const size_t k = (size_t)(t % (uint64_t)pl->cfg.depth);
     const bool used = pl->slot_ticket[k] != 0;
+    pl->hot = hot_for(pl, n_frames, w, h);
     if (pl->hot) { // the newest record that has come back: did any of its frames go beyond the LDS tables?
         for (uint64_t d = 1; d <= (uint64_t)pl->cfg.depth && d <= t; d++) {
             const size_t s_ = (size_t)((t - d) % (uint64_t)pl->cfg.depth);
@@ -485,17 +582,14 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
         }
         (void)hipGetLastError(); // (hipErrorNotReady is not an error)
     }
-    const bool fast = pl->hot && pl->calm && !lp && !(stages & (RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE));
-    const size_t j = fast ? (size_t)(pl->hot_seq++ % (uint64_t)pl->hot) : k;
-    if (fast) pl->hot_batches++;
+    const bool fast = pl->hot && pl->calm && !lp && !(stages & RMCV_STAGE_POSE) && (pl->hot_identity || !(stages & RMCV_STAGE_IDENTITY));
+    const size_t j = fast ? (size_t)(pl->hot_seq % (uint64_t)pl->hot) : k;
     rmcv_ctx* c = pl->ring[j];
     hipStream_t A = pl->pix[(size_t)(t % (uint64_t)pl->cfg.pixel_streams)], B = pl->sp[k % (size_t)pl->cfg.sparse_streams];
     int rc;
-    rc = rmcv_batch_set_device_frames(c, d_frames, n_frames, w, h, stride, frame_pitch); // (waits for the slot's work when the geometry changes)
-    if (rc) return cfail(pl, c, rc);
-    // a batch is several runs on several streams: everything that could refuse it is checked before the first enqueue
-    if ((rc = ctx_check_stages(c, p, stages))) return cfail(pl, c, rc);
-    const int pixel = stages & (RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE), sparse = stages & ~(RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE);
+    // ---- waits first: stream A is behind everything that still uses the slot and the context when the binding below enqueues on it.
+    // (Nothing of the pipeline's own state moves before the batch has been accepted: an error return leaves tickets, rotation and
+    // context ownership as they were; the waits already enqueued on A are harmless.)
     // the slot's context buffers are free once its previous list is compacted
     if (used) PCHK(pl, hipStreamWaitEvent(A, pl->ev_done[k], 0), "pipeline: wait for the slot");
     // The context's last batch (another slot's, when the hot contexts take turns): the pixel kernel rewrites byte image, bit plane and row
@@ -508,36 +602,51 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
         const bool early = pl->early_free && pl->slot_stream[last] == B;
         PCHK(pl, hipStreamWaitEvent(A, early ? pl->ev_free[last] : pl->ev_done[last], 0), "pipeline: wait for the context");
     }
-    pl->ctx_last[j] = (int)k;
-    pl->slot_ctx[k] = (int)j;
+    // ---- bind: a new geometry's work (planes zeroed, frame order) is ENQUEUED on A, nothing blocks
+    rc = ctx_bind_frames(c, d_frames, n_frames, w, h, stride, frame_pitch, A);
+    if (rc) return cfail(pl, c, rc);
+    // a batch is several runs on several streams: everything that could refuse it is checked before the first launch
+    if ((rc = ctx_check_stages(c, p, stages))) return cfail(pl, c, rc);
+    const int pixel = stages & (RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE), sparse = stages & ~(RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE);
     ctx_external_order(c, pl->ev_done[k]);
-    // A burst's SECOND pixel launch is held back for 60 us (k_delay on its stream).  k_binary_ws is one workgroup per CU: when two
-    // launches reach an empty machine 15 us apart, whether the first has taken every CU by then is a coin toss -- if not, the two split
-    // the CUs, run side by side and END together, and so do the next pairs (each pair's ramp and tail in the open, both sparse kernels
+    ctx_pixel_shape(c, fast ? 1 : 0);
+    // A burst's SECOND pixel launch is held back (k_delay on its stream).  k_binary_ws is one workgroup per CU: when two launches
+    // reach an empty machine 15 us apart, whether the first has taken every CU by then is a coin toss -- if not, the two split the
+    // CUs, run side by side and END together, and so do the next pairs (each pair's ramp and tail in the open, both sparse kernels
     // at once) until they drift apart: 0.258 instead of 0.242 ms per step over a 20-batch burst, in 15 % of the bursts
     // (tools/trace_regions.py, profiles/r04k_burst_start.txt).  Held back, the second launch finds every CU taken and its workgroups
     // move in as the first one's leave -- the steady state -- at no cost: they would have waited anyway.  (Waiting for the first
-    // launch's END instead puts the event's latency between the two: +1-3 %.)
+    // launch's END instead puts the event's latency between the two: +1-3 %.)  Round 5: only where that reason exists -- the launch
+    // WILL be k_binary_ws on every CU (launch_binary's own rule: pixel_ws_full) -- and for a quarter of the launch's expected time
+    // (its bytes at 5.5 TB/s), 60 us at most, nothing below 100 us of launch: two 16-frame batches are not held back at all.
+    bool cold = false;
     if (fast && pl->chain_cold) {
-        bool cold = t == 0;
+        cold = t == 0;
         const size_t s_ = t ? (size_t)((t - 1) % (uint64_t)pl->cfg.depth) : 0;
         if (t > 0) {
             cold = pl->slot_ticket[s_] == t && hipEventQuery(pl->ev_done[s_]) == hipSuccess;
             (void)hipGetLastError();
         }
-        if (!cold && pl->was_cold && pl->slot_ticket[s_] == t) {
+        if (!cold && pl->was_cold && pl->slot_ticket[s_] == t && pixel_ws_full(c, p->lower_bound)) {
+            const double launch_us = (double)n_frames * 4.0 * w * h / 5.5e6;
+            const int hold_us = launch_us < 100.0 ? 0 : (int)(launch_us / 4.0 < pl->chain_cold_us ? launch_us / 4.0 : pl->chain_cold_us);
             if (pl->chain_cold_us > 0) { // hold the second launch back until the first one's workgroups have taken every CU
-                hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, A, (unsigned long long)pl->chain_cold_us * 1000ull);
-                PCHK(pl, hipGetLastError(), "pipeline: k_delay");
+                if (hold_us > 0) {
+                    PCHK(pl, launch_delay((unsigned long long)hold_us * 1000ull, A), "pipeline: k_delay");
+                    pl->held_back++;
+                }
             } else
                 PCHK(pl, hipStreamWaitEvent(A, pl->ev_bin[s_], 0), "pipeline: chain a burst's second launch");
         }
-        pl->was_cold = cold;
-    } else
-        pl->was_cold = false;
-    ctx_pixel_shape(c, fast ? 1 : 0);
+    }
     rc = rmcv_batch_run(c, p, pixel, A);
     if (rc) return cfail(pl, c, rc);
+    pl->last_what = "the pixel kernel (k_binary / k_binary_ws)";
+    // ---- accepted: the pipeline's state moves
+    pl->was_cold = cold;
+    if (fast) { pl->hot_seq++; pl->hot_batches++; }
+    pl->ctx_last[j] = (int)k;
+    pl->slot_ctx[k] = (int)j;
     PCHK(pl, hipEventRecord(pl->ev_bin[k], A), "pipeline: mark the pixel kernel");
     PCHK(pl, hipStreamWaitEvent(B, pl->ev_bin[k], 0), "pipeline: chain the sparse stages");
     pl->next_ticket = t + 1;
@@ -590,8 +699,9 @@ int rmcv_pipeline_wait(rmcv_pipeline* pl, uint64_t ticket)
     const int k = slot_of(pl, ticket);
     if (k < 0) return pfail(pl, RMCV_ERR_BAD_ARG, "no such ticket in flight (never issued, or its slot has been reused)");
     hipSetDevice(pl->device);
-    PCHK(pl, hipEventSynchronize(pl->ev_done[(size_t)k]), "pipeline: wait");
-    if (pl->comm) PCHK(pl, hipEventSynchronize(pl->ev_host[(size_t)k]), "pipeline: wait (gather)");
+    int rcw = pwait_event(pl, pl->ev_done[(size_t)k], "rmcv_pipeline_wait");
+    if (rcw) return rcw;
+    if (pl->comm && (rcw = pwait_event(pl, pl->ev_host[(size_t)k], "rmcv_pipeline_wait (gather)"))) return rcw;
     return RMCV_OK;
 }
 
@@ -630,12 +740,13 @@ int rmcv_pipeline_drain(rmcv_pipeline* pl)
     if (!pl) return RMCV_ERR_BAD_ARG;
     hipSetDevice(pl->device);
     { const int rcb = finish_back(pl, true); if (rcb) return rcb; }
-    for (auto s : pl->pix) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
-    for (auto s : pl->sp) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
-    for (auto s : pl->dn) PCHK(pl, hipStreamSynchronize(s), "pipeline: drain");
+    int rcw;
+    for (auto s : pl->pix) if ((rcw = pwait_stream(pl, s, "rmcv_pipeline_drain (pixel stream)"))) return rcw;
+    for (auto s : pl->sp) if ((rcw = pwait_stream(pl, s, "rmcv_pipeline_drain (sparse stream)"))) return rcw;
+    for (auto s : pl->dn) if ((rcw = pwait_stream(pl, s, "rmcv_pipeline_drain (dense stream)"))) return rcw;
     for (size_t k = 0; k < pl->ev_hook.size(); k++)
         if (pl->ev_hook[k]) {
-            PCHK(pl, hipEventSynchronize((hipEvent_t)pl->ev_hook[k]), "pipeline: drain (hook)");
+            if ((rcw = pwait_event(pl, (hipEvent_t)pl->ev_hook[k], "rmcv_pipeline_drain (hook)"))) return rcw;
             pl->ev_hook[k] = nullptr;
         }
     return RMCV_OK;

@@ -99,6 +99,10 @@ class Pipeline:
         """rmcv_pipeline_config::hot_contexts from the next submit on (0: off)"""
         self._chk(self._lib.rmcv_pipeline_set_hot_contexts(self._h, int(n)))
 
+    def set_wait_timeout(self, ms):
+        """deadline of wait / collect / drain in milliseconds (0: none); a wait that runs out raises RmcvError(ERR_TIMEOUT)"""
+        self._chk(self._lib.rmcv_pipeline_set_wait_timeout(self._h, int(ms)))
+
     def drain(self):
         self._chk(self._lib.rmcv_pipeline_drain(self._h))
 
@@ -106,7 +110,7 @@ class Pipeline:
         """the Context view of the slot a (waited-for) ticket lives in: per-stage getters (binary, contours, blobs, counts)"""
         h = self._lib.rmcv_pipeline_context_of(self._h, int(ticket))
         if not h:
-            raise RmcvError(abi.ERR_BAD_ARG, "ticket %d is not live" % ticket)
+            raise RmcvError(abi.ERR_BAD_ARG, "ticket %d: %s" % (ticket, self._lib.rmcv_pipeline_last_error(self._h).decode()))
         for c in self.contexts:
             if c._h.value == h:
                 return c

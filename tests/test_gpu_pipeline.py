@@ -233,13 +233,13 @@ def test_c_host_drives_the_same_pipeline(oracle):
     subprocess.run([cc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "pipeline_bench.c"), "-o", exe, "-L", libdir,
                     "-lrmcv_hip", "-Wl,-rpath," + libdir, "-lpthread"], check=True, timeout=120)
     n, depth, sets, steps = 16, 4, 4, 6
-    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}   # the library's own default applies
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}   # the host's own rmcv_hw_queues_hint() applies
     cp = subprocess.run([exe, "--frames", str(n), "--depth", str(depth), "--sets", str(sets), "--steps", str(steps), "--repeats", "2", "--warmup", "2",
                          "--warmup-seconds", "0.05"], capture_output=True, text=True, timeout=600, env=env)
     assert cp.returncode == 0, cp.stderr
     out = json.loads(cp.stdout.strip().splitlines()[-1])
     assert out["steps"] == steps and out["depth"] == depth and out["value"] > 0
-    assert out["gpu_max_hw_queues"] == 12                                      # set by the library when it was loaded
+    assert out["gpu_max_hw_queues"] == 12                                      # set by the host's rmcv_hw_queues_hint() before its first HIP call
     per_set = [sum(len(a) for a in oracle_lists(oracle, synth.batch(k * 1000003, n, 1280, 1024, CAMP_BLUE, 0, threads=16))) for k in range(sets)]
     assert out["armours_set0"] == per_set[0]
     assert out["armours_last_%d_batches" % depth] == sum(per_set)               # the last four steps cover every set once (sets == depth)
@@ -316,7 +316,7 @@ def test_calm_and_dense_batches_in_turn(oracle):
     import torch
     dev = torch.device("cuda", 0)
     n, w, h = 64, 1280, 1024
-    pl = Pipeline(device=0, max_frames=n, max_width=w, max_height=h, max_contours=4096)
+    pl = Pipeline(device=0, max_frames=n, max_width=w, max_height=h, max_contours=4096, hot_contexts=4)
     assert pl.info.depth == 8 and pl.info.hot_contexts == 4
     p = default_params()
     kinds = [0] * 12 + [14] * 5 + [1] * 14 + [14] * 3 + [0] * 10
@@ -346,6 +346,9 @@ def test_calm_and_dense_batches_in_turn(oracle):
     info = pl.get_info()
     assert 10 <= info.hot_batches <= len(kinds) - 1 - 6               # most ran hot; the first one and the dense ones (but for the first of a run) did not
     assert abi.lib().rmcv_pixel_ws_launches() - ws0 == info.hot_batches
+    # rmcv_pipeline_submit never blocks the host: no allocation, no synchronisation, no blocking copy -- not at the first batch, not when
+    # the stream turns dense (the slots' finishing streams change), not when it turns calm again
+    assert info.host_blocking_calls == 0 and info.dense_split > 0
     pl.close()
 
 
@@ -355,7 +358,7 @@ def test_geometry_changes_with_batches_in_flight(oracle):
     import torch
     dev = torch.device("cuda", 0)
     pl = Pipeline(device=0, max_frames=96, max_width=1920, max_height=1200)
-    assert pl.info.depth == 8 and pl.info.hot_contexts == 4
+    assert pl.info.depth == 8 and pl.info.hot_contexts == 6            # derived: 96 x 1920x1200 bit planes = 29.5 MB per batch, 200 MB of cache
     p = default_params()
     geoms = [(96, 1280, 1024), (40, 1920, 1200), (96, 640, 512), (17, 1280, 720), (96, 1280, 1024), (64, 1920, 1080)]
     host, devf, got = [], [], {}
@@ -375,6 +378,7 @@ def test_geometry_changes_with_batches_in_flight(oracle):
     for i in range(30):
         check_batch(oracle, host[i], *got[i])
     assert pl.get_info().hot_batches > 0
+    assert pl.get_info().host_blocking_calls == 0                      # a change of geometry is enqueued work (planes zeroed, frame order on the device)
     pl.close()
 
 
@@ -384,7 +388,7 @@ def test_hot_contexts_config_and_switch():
     dev = torch.device("cuda", 0)
     n, w, h = 32, 640, 512
     pl = Pipeline(device=0, max_frames=n, max_width=w, max_height=h)
-    assert pl.info.hot_contexts == 4
+    assert pl.info.hot_contexts == 7                                  # derived: small planes, the whole ring but one
     with pytest.raises(RmcvError):
         pl.set_hot_contexts(2)                                        # fewer than 3 stall even sparse batches
     with pytest.raises(RmcvError):

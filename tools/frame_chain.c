@@ -32,7 +32,8 @@ int main(int argc, char** argv)
     rmcv_lightblob* blobs = malloc(sizeof(rmcv_lightblob) * 256);
     int32_t* neg = malloc(4 * 2048);
     rmcv_armour* arms = malloc(sizeof(rmcv_armour) * 256);
-    static double tot[300], ec[300];
+    static double tot[300], ec[300], st[6][300];
+    static const char* st_name[6] = {"sync+bind+upload", "enqueue kernels", "enqueue image D2H", "wait image", "wait kernels", "hand over"};
     for (int mode = 0; mode <= 2; mode += 2) {
         rmcv_ctx_set_option(c, RMCV_OPT_FRAME_UPLOAD, mode);
         int32_t nc = 0, np = 0, nb = 0, nn = 0, na = 0;
@@ -41,6 +42,9 @@ int main(int argc, char** argv)
             const double t0 = now_ms();
             int rc = rmcv_extract_color(c, f, W, H, 3 * W, RMCV_CAMP_BLUE, 80, RMCV_MORPH_CLOSE, binary, pts, 65536, offs, 2048, &nc, &np);
             const double t1 = now_ms();
+            double us[6] = {0};
+            rmcv_ctx_frame_timing(c, us, 6);
+            if (i >= 0) for (int k = 0; k < 6; k++) st[k][i] = us[k];
             rc |= rmcv_filter_lightblobs(c, pts, offs, nc, 70.0f, 1.5f, 80.0f, 10.0, 99999.0, RMCV_CAMP_BLUE, blobs, 256, &nb, NULL, neg, &nn);
             rc |= rmcv_filter_armours(c, blobs, nb, 12.0f, 22.0f, 0.4f, RMCV_CAMP_BLUE, arms, 256, &na);
             const double t2 = now_ms();
@@ -51,6 +55,12 @@ int main(int argc, char** argv)
         qsort(ec, N, sizeof(double), cmp);
         printf("%-20s median %.4f  min %.4f  p90 %.4f ms | extract_color median %.4f | contours %d blobs %d armours %d\n",
                mode == 0 ? "runtime_pageable" : "registered_in_place", tot[N / 2], tot[0], tot[9 * N / 10], ec[N / 2], nc, nb, na);
+        printf("    extract_color on the host, medians (p90) in us:");
+        for (int k = 0; k < 6; k++) {
+            qsort(st[k], N, sizeof(double), cmp);
+            printf("  %s %.1f (%.1f)", st_name[k], st[k][N / 2], st[k][9 * N / 10]);
+        }
+        printf("\n");
     }
     rmcv_ctx_destroy(c);
     return 0;

@@ -76,6 +76,7 @@ int main(int argc, char** argv)
         else if (!strcmp(k, "--warmup-seconds")) warm_s = atof(v);
         else { fprintf(stderr, "unknown option %s\n", k); return 2; }
     }
+    rmcv_hw_queues_hint(); /* GPU_MAX_HW_QUEUES=12 unless set: before the process's first HIP call (the library does not touch the environment by itself) */
     if (sets < depth) sets = depth; /* batches that overlap in time must not share input (the 256 MB Infinity Cache would serve the second) */
     if (steps < 1 || repeats < 1 || repeats > 64 || threads < 1 || threads > 64) return 2;
     rmcv_pipeline* pl = NULL;
