@@ -268,7 +268,7 @@ def main():
 
     # the kernel that moves the algorithmic 4 B/px in the steps: k_binary_ws in the contexts that take turns while the batches are calm
     # (rmcv_pipeline_config::hot_contexts), k_binary where that is off or does not apply (a pose stage, the legacy blob stage)
-    hot_mode = info.hot_contexts > 0 and legacy is None and not (stages & STAGE_POSE)
+    hot_mode = info.hot_contexts > 0 and legacy is None and not (stages & (STAGE_IDENTITY | STAGE_POSE))
     roof_kernel = "k_binary_ws" if hot_mode else "k_binary"
     roof_ctxs = pl.contexts[:info.hot_contexts] if hot_mode else pl.contexts
 
@@ -335,7 +335,8 @@ def main():
         return float(t.item())
 
     hot_each = []                                              # batches of each region that ran in a hot context
-    submit_max_each = []                                       # the longest single submit call of each region (host seconds)
+    submit_max_each = []                                       # the longest single submit call of each region (host seconds), as Python's clock sees it
+    submit_max_lib_each = []                                   # ... as the library's own clock sees it (rmcv_pipeline_info::max_submit_us: no ctypes, no GC pause)
 
     def regions(steps, repeats):
         """`repeats` regions of exactly `steps` steps between barrier + synchronize pairs -> (wall seconds each, host enqueue seconds each)"""
@@ -344,6 +345,7 @@ def main():
             barrier()
             h0 = cur["pl"].get_info().hot_batches
             cur["max_submit"] = 0.0
+            cur["pl"]._lib.rmcv_pipeline_reset_stats(cur["pl"]._h)
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
@@ -352,6 +354,7 @@ def main():
             rep.append(agree_max(time.perf_counter() - t0))
             hot_each.append(int(cur["pl"].get_info().hot_batches - h0))
             submit_max_each.append(cur["max_submit"])
+            submit_max_lib_each.append(cur["pl"].get_info().max_submit_us * 1e-6)
         return rep, enq
 
     def median(x):
@@ -378,9 +381,10 @@ def main():
     # value = the median repeat (median and min over the passes)
     del hot_each[:]
     del submit_max_each[:]
+    del submit_max_lib_each[:]
     rep_dt, enq_dt = regions(args.steps, max(1, args.repeats))
     hot_timed = list(hot_each)
-    submit_max_timed = list(submit_max_each)
+    submit_max_timed = list(submit_max_lib_each)
     if hot_mode and 2 * sum(hot_timed) < len(hot_timed) * args.steps:   # (a stream with dense frames is never calm: its steps run k_binary)
         hot_mode, roof_kernel, roof_ctxs = False, "k_binary", pl.contexts
     dt = median(rep_dt)
@@ -758,7 +762,8 @@ def main():
             cnt_ = pl_d.context_of(info_d.submitted - 1).counts()
             st_ = cnt_["status"]
             sweep.append({"stream": label, "ms_per_step": round(dsw * 1e3, 4), "ms_per_step_each": [round(x * 1e3, 4) for x in each_sw],
-                          "max_submit_host_ms": round(max(submit_max_each[n_sub0:]) * 1e3, 4), "host_blocking_calls": int(info_d.host_blocking_calls),
+                          "max_submit_host_ms": round(max(submit_max_lib_each[n_sub0:]) * 1e3, 4), "max_submit_host_ms_python_clock": round(max(submit_max_each[n_sub0:]) * 1e3, 4),
+                          "host_blocking_calls": int(info_d.host_blocking_calls),
                           "frames_per_s": round(n / dsw, 1),
                           "contours_per_frame": round(float(cnt_["n_contours"].mean()), 1),
                           "points_per_frame": round(float(cnt_["n_points"].mean()), 1),
@@ -773,7 +778,7 @@ def main():
             lv["x_plain"] = round(lv["ms_per_step"] / base_, 3)
         out["density_sweep"] = {"steps_per_region": region, "levels": sweep, "seconds": round(time.perf_counter() - t_sw, 1),
                                 "note": "three steady-state regions per level of the steps' own loop (%d batches in flight over %d sparse streams, 4 frame sets per "
-                                        "level), the median; max_submit_host_ms = the longest single rmcv_pipeline_submit call of the level's regions; "
+                                        "level), the median; max_submit_host_ms = the longest single rmcv_pipeline_submit call of the level's regions by the library's own clock (rmcv_pipeline_info::max_submit_us); "
                                         "x_plain = against this sweep's own plain level; not the metric" % (info.depth, info.sparse_streams)}
 
     if extras and args.workload == "c3" and args.variant == 0 and not args.pose and not args.one_dense:

@@ -209,9 +209,10 @@ int64_t rmcv_pixel_ws_launches(void);
 /* every device buffer of a context lies between two 4 KiB guard zones holding a fixed pattern: count the damaged ones (0 in a
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */
 int  rmcv_ctx_check_guards(rmcv_ctx* ctx, int32_t* n_damaged);
-/* where the last rmcv_extract_color spent its time on the HOST, six figures in microseconds: us[0] waiting for earlier work, binding,
- * enqueuing the upload; us[1] enqueuing the kernels; us[2] enqueuing the byte image's download; us[3] waiting for it; us[4] waiting
- * for the frame's kernels; us[5] handing the lists over.  cap >= 6.  A diagnosis hook (tools/frame_chain.c prints the medians). */
+/* where the last rmcv_extract_color spent its time on the HOST, seven figures in microseconds: us[0] waiting for earlier work, binding,
+ * enqueuing the upload; us[1] enqueuing the kernels; us[2] waiting for upload + pixel kernel; us[3] the byte image's download call;
+ * us[4] waiting for it; us[5] waiting for the frame's kernels; us[6] handing the lists over.  cap >= 7.  A diagnosis hook
+ * (tools/frame_chain.c prints the medians). */
 int  rmcv_ctx_frame_timing(const rmcv_ctx* ctx, double* us, int cap);
 /* drop the pinning RMCV_OPT_FRAME_UPLOAD = 2 made for `frame` (NULL: all of them); drains the context's stream first */
 int  rmcv_ctx_forget_frame_buffer(rmcv_ctx* ctx, const void* frame);
@@ -446,7 +447,7 @@ typedef struct {            /* 0 in any field = the default; rmcv_default_pipeli
                              * 1.3 x the plain step time without, 1.01 x with).  Batches without such frames, and batches full of them,
                              * run as if this were off.  -1: off                                                              (4)  */
     int32_t hot_contexts;   /* WHILE the batches are calm -- no frame of the record that last came back went beyond findContours' LDS
-                             * tables, no pose stage asked for -- the batches take turns at the first `hot_contexts`
+                             * tables, no classifier / pose stage asked for -- the batches take turns at the first `hot_contexts`
                              * contexts of the ring (slot, record and ticket window stay `depth` deep) and run the wave-specialised pixel
                              * kernel (RMCV_OPT_PIXEL_SHAPE 1).  What a batch writes with ordinary stores and reads right back -- the
                              * 46 MB bit plane first of all -- then stays in the 256 MB Infinity Cache instead of going to HBM and
@@ -474,6 +475,7 @@ typedef struct {
     uint64_t host_blocking_calls; /* allocations, host-side synchronisations and blocking copies made inside rmcv_pipeline_submit since the
                                 * pipeline was created: 0 (tests/test_gpu_pipeline.py asserts it over plain, dense and re-shaped streams) */
     int32_t wait_timeout_ms, _pad3; /* rmcv_pipeline_set_wait_timeout */
+    double   max_submit_us;    /* host time of the longest single rmcv_pipeline_submit since creation / rmcv_pipeline_reset_stats, microseconds */
     uint64_t held_back;        /* pixel launches held back behind a burst's first one (k_delay): only launches of the wave-specialised
                                 * kernel on every CU, for a quarter of their expected time, 60 us at most, none below 100 us of launch */
 } rmcv_pipeline_info;
@@ -497,6 +499,8 @@ rmcv_ctx* rmcv_pipeline_context(rmcv_pipeline* pl, int slot);
 rmcv_ctx* rmcv_pipeline_context_of(rmcv_pipeline* pl, uint64_t ticket);
 /* rmcv_pipeline_config::hot_contexts from the next submit on (3 .. depth - 1; 0 or -1: off).  Batches in flight are not touched. */
 int  rmcv_pipeline_set_hot_contexts(rmcv_pipeline* pl, int n);
+/* rmcv_pipeline_info::max_submit_us starts over (a diagnostic: bench.py reads it per timed region) */
+int  rmcv_pipeline_reset_stats(rmcv_pipeline* pl);
 /* the deadline of rmcv_pipeline_wait / _collect / _drain (and of the ring contexts' own waits), milliseconds; default 5000, 0: none.
  * A wait that runs out returns RMCV_ERR_TIMEOUT (the batch is still in flight; waiting again is allowed);
  * rmcv_pipeline_last_error names the enqueue made last. */

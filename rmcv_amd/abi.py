@@ -54,7 +54,7 @@ EXPORTS = [
     "rmcv_svm_load", "rmcv_classify_armours", "rmcv_batch_get_identities", "rmcv_batch_get_icons",
     "rmcv_default_pnp_config", "rmcv_pnp_load", "rmcv_locate_armours", "rmcv_batch_set_base2gripper", "rmcv_batch_get_poses",
     "rmcv_max_iou", "rmcv_identity_max", "rmcv_comm_unique_id", "rmcv_comm_create", "rmcv_comm_destroy", "rmcv_comm_info", "rmcv_comm_last_error", "rmcv_gather",
-    "rmcv_default_pipeline_config", "rmcv_pipeline_create", "rmcv_pipeline_destroy", "rmcv_pipeline_last_error", "rmcv_pipeline_get_info", "rmcv_pipeline_context", "rmcv_pipeline_context_of", "rmcv_pipeline_set_hot_contexts", "rmcv_pipeline_set_wait_timeout", "rmcv_hw_queues_hint", "rmcv_pixel_ws_launches",
+    "rmcv_default_pipeline_config", "rmcv_pipeline_create", "rmcv_pipeline_destroy", "rmcv_pipeline_last_error", "rmcv_pipeline_get_info", "rmcv_pipeline_context", "rmcv_pipeline_context_of", "rmcv_pipeline_set_hot_contexts", "rmcv_pipeline_set_wait_timeout", "rmcv_pipeline_reset_stats", "rmcv_hw_queues_hint", "rmcv_pixel_ws_launches",
     "rmcv_pipeline_submit", "rmcv_pipeline_submit_legacy", "rmcv_pipeline_wait", "rmcv_pipeline_collect", "rmcv_pipeline_drain", "rmcv_pipeline_record",
     "rmcv_pipeline_set_hook", "rmcv_pipeline_set_gather", "rmcv_pipeline_gathered", "rmcv_device_alloc", "rmcv_device_free", "rmcv_device_upload", "rmcv_device_download",
     "rmcv_track_init", "rmcv_track_reset", "rmcv_track_update", "rmcv_track_predict", "rmcv_track_step", "rmcv_min_area_rect", "rmcv_match_lightblob", "rmcv_find_lightblobs", "rmcv_lightblob_overlap", "rmcv_batch_run_legacy",
@@ -101,7 +101,7 @@ class PipelineInfo(C.Structure):
                 ("max_frames", C.c_int32), ("hw_queues_env", C.c_int32), ("hw_queues_wanted", C.c_int32), ("_pad", C.c_int32),
                 ("record_bytes", C.c_int64), ("armours_offset", C.c_int64), ("submitted", C.c_uint64), ("collected", C.c_uint64),
                 ("dense_split", C.c_uint64), ("hot_batches", C.c_uint64), ("hot_contexts", C.c_int32), ("_pad2", C.c_int32), ("latency_batches", C.c_uint64),
-                ("host_blocking_calls", C.c_uint64), ("wait_timeout_ms", C.c_int32), ("_pad3", C.c_int32), ("held_back", C.c_uint64)]
+                ("host_blocking_calls", C.c_uint64), ("wait_timeout_ms", C.c_int32), ("_pad3", C.c_int32), ("max_submit_us", C.c_double), ("held_back", C.c_uint64)]
 
 
 # rmcv_pipeline_hook: int (*)(void* user, uint64_t ticket, void* d_record, int64_t record_bytes, void* hip_stream, void** done_event)

@@ -79,7 +79,7 @@ struct rmcv_ctx {
     const char* last_what = "nothing";
     bool timed_out = false;       // a wait ran out: work of this context may still be in flight (cleared by the next wait that completes)
     int test_delay_us = 0;        // RMCV_OPT_TEST_DELAY_US: the next rmcv_extract_color holds its stream back this long first (tests of the deadline)
-    double marks[8] = {};         // rmcv_ctx_frame_timing: host clock at the steps of the last rmcv_extract_color (microseconds)
+    double marks[9] = {};         // rmcv_ctx_frame_timing: host clock at the steps of the last rmcv_extract_color (microseconds)
     uint64_t blocking_calls = 0;  // allocations, host-side synchronisations and blocking copies made while binding a geometry (ctx_blocking_calls)
     int32_t* order_scratch = nullptr; // [2 * max_frames] k_frame_order's work lists for batches beyond its LDS tables
     char err[256] = {0};
@@ -813,8 +813,8 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
 
 int rmcv_ctx_frame_timing(const rmcv_ctx* c, double* us, int cap)
 {
-    if (!c || !us || cap < 6) return RMCV_ERR_BAD_ARG;
-    for (int i = 0; i < 6; i++) us[i] = c->marks[i + 1] - c->marks[i];
+    if (!c || !us || cap < 7) return RMCV_ERR_BAD_ARG;
+    for (int i = 0; i < 7; i++) us[i] = c->marks[i + 1] - c->marks[i];
     return RMCV_OK;
 }
 
@@ -1365,14 +1365,15 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
         // source is ready -- behind a pixel kernel that never finishes, for good)
         c->last_what = "k_binary";
         WAITCHK(c, wait_event(c, c->ev_fork, "rmcv_extract_color: waiting for the pixel kernel"));
+        c->marks[3] = now_us(); // upload and pixel kernel are through
         HIPCHK(c, hipMemcpyAsync(binary_out, b.binary, (size_t)w * h, hipMemcpyDeviceToHost, c->side), "D2H binary");
-        c->marks[3] = now_us(); // the byte image's download is enqueued (pageable: the call may have done all of it)
+        c->marks[4] = now_us(); // the byte image's download is enqueued (pageable: the call may have done all of it)
         WAITCHK(c, wait_stream(c, c->side, "rmcv_extract_color: waiting for the byte image's download"));
-    } else c->marks[3] = c->marks[2];
-    c->marks[4] = now_us();
+    } else c->marks[3] = c->marks[4] = c->marks[2];
+    c->marks[5] = now_us();
     c->last_what = fused_ahead ? "k_binary, k_contours (fused), k_pack_contours + export" : "k_binary, k_contours, k_pack_contours, k_export";
     WAITCHK(c, wait_stream(c, s, "rmcv_extract_color: waiting for the frame's kernels"));
-    c->marks[5] = now_us();
+    c->marks[6] = now_us();
     const int32_t nc = c->h_hdr[0], total = c->h_hdr[1], st = c->h_hdr[2];
     if (n_contours) *n_contours = nc;
     if (n_points) *n_points = total;
@@ -1386,7 +1387,7 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     if (nc > contours_cap || total > pts_cap) return fail(c, RMCV_ERR_CAPACITY, "output capacity exceeded");
     if (offs_out) memcpy(offs_out, c->h_offs, (size_t)(nc + 1) * 4);
     if (pts_out && total) memcpy(pts_out, c->h_pts, (size_t)total * sizeof(rmcv_point));
-    c->marks[6] = now_us();
+    c->marks[7] = now_us();
     return RMCV_OK;
 }
 

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <new>
 #include <vector>
@@ -96,7 +97,9 @@ struct rmcv_pipeline {
     const char* last_what = "nothing"; // the enqueue made last (PCHK's label): named when a wait runs out
     int hot_cfg = 0;                   // rmcv_pipeline_config::hot_contexts as given (0: derived from the bound geometry)
     int64_t hot_plane_bytes = 0;       // ... the bit planes' bytes of a batch of the geometry `hot` was derived for
-    bool hot_identity = true;          // batches with a classifier stage take turns at the hot contexts too (round 5)
+    bool hot_identity = false;         // batches with a classifier stage take turns at the hot contexts too: measured in round 5 (three contexts at
+                                       // 256 x 1920x1200: 0.514 against 0.426 ms per step), off; RMCV_HOT_IDENTITY=1 in a dev build
+    double max_submit_us = 0;          // the longest single submit call (host time) since rmcv_pipeline_reset_stats
     char err[256] = {0};
 };
 
@@ -373,7 +376,8 @@ int rmcv_pipeline_get_info(const rmcv_pipeline* pl, rmcv_pipeline_info* o)
     o->hot_batches = pl->hot_batches;
     o->hot_contexts = pl->hot;
     o->latency_batches = pl->latency_batches;
-    o->host_blocking_calls = pl->own_blocking + ring_blocking(pl) - pl->blocking_base;
+    o->host_blocking_calls = pl->own_blocking;
+    o->max_submit_us = pl->max_submit_us;
     o->wait_timeout_ms = pl->wait_timeout_ms;
     o->held_back = pl->held_back;
     return RMCV_OK;
@@ -667,17 +671,40 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     return RMCV_OK;
 }
 
+// submit + its own bookkeeping: the host time of the call, and the blocking calls the ring's contexts counted during it
+static int submit_counted(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch, const rmcv_params* p,
+                          const rmcv_legacy_params* lp, int stages, uint64_t* ticket)
+{
+    if (!pl) return RMCV_ERR_BAD_ARG;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const uint64_t b0 = ring_blocking(pl);
+    const int rc = submit(pl, d_frames, n_frames, w, h, stride, frame_pitch, p, lp, stages, ticket);
+    pl->own_blocking += ring_blocking(pl) - b0;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+    if (us > pl->max_submit_us) pl->max_submit_us = us;
+    return rc;
+}
+
+int rmcv_pipeline_reset_stats(rmcv_pipeline* pl)
+{
+    if (!pl) return RMCV_ERR_BAD_ARG;
+    pl->max_submit_us = 0;
+    return RMCV_OK;
+}
+
 int rmcv_pipeline_submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch,
                          const rmcv_params* p, int stages, uint64_t* ticket)
 {
-    return submit(pl, d_frames, n_frames, w, h, stride, frame_pitch, p, nullptr, stages, ticket);
+    return submit_counted(pl, d_frames, n_frames, w, h, stride, frame_pitch, p, nullptr, stages, ticket);
 }
 
 int rmcv_pipeline_submit_legacy(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, int h, int stride, int64_t frame_pitch,
                                 const rmcv_params* p, const rmcv_legacy_params* lp, int stages, uint64_t* ticket)
 {
     if (!lp) return RMCV_ERR_BAD_ARG;
-    return submit(pl, d_frames, n_frames, w, h, stride, frame_pitch, p, lp, stages, ticket);
+    return submit_counted(pl, d_frames, n_frames, w, h, stride, frame_pitch, p, lp, stages, ticket);
 }
 
 // slot of a live ticket, or -1

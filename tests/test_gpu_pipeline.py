@@ -358,7 +358,7 @@ def test_geometry_changes_with_batches_in_flight(oracle):
     import torch
     dev = torch.device("cuda", 0)
     pl = Pipeline(device=0, max_frames=96, max_width=1920, max_height=1200)
-    assert pl.info.depth == 8 and pl.info.hot_contexts == 6            # derived: 96 x 1920x1200 bit planes = 29.5 MB per batch, 200 MB of cache
+    assert pl.info.depth == 8 and pl.info.hot_contexts == 7            # derived: 96 x 1920x1200 bit planes = 29.5 MB per batch, 200 MiB of cache -> the whole ring but one
     p = default_params()
     geoms = [(96, 1280, 1024), (40, 1920, 1200), (96, 640, 512), (17, 1280, 720), (96, 1280, 1024), (64, 1920, 1080)]
     host, devf, got = [], [], {}
