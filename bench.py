@@ -50,7 +50,7 @@ WORKLOADS = {"c3": (1280, 1024), "c5": (1920, 1200),   # BASELINE.json configs[2
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 # environment knobs that change what the timed region runs: refused unless --dev, echoed in config.dev_knobs either way
 DEV_KNOBS = ("RMCV_BENCH_STAGES", "RMCV_BENCH_AB", "RMCV_W4_ONE_PER_CU", "RMCV_EARLY_FREE", "RMCV_CHAIN_COLD", "RMCV_LAZY_BACK", "RMCV_SPARSE_WAVES", "RMCV_PIXEL_GROUPS", "RMCV_K1_BPC", "RMCV_FUSE_SPARSE", "RMCV_CONTOURS_LITERAL",
-             "RMCV_K1_HALO_NT", "RMCV_K1_LINEAR", "RMCV_DENSE_DEFER", "RMCV_LIB_PATH", "RMCV_NO_MID")
+             "RMCV_K1_HALO_NT", "RMCV_K1_LINEAR", "RMCV_DENSE_DEFER", "RMCV_LIB_PATH", "RMCV_NO_MID", "RMCV_HOT_IDENTITY", "RMCV_WAIT_RUNTIME")
 VARIANTS = {"plain": 0, "stress": 1, "dense1": 11, "dense2": 12, "dense3": 13, "dense4": 14, "dense": 14}
 
 
@@ -158,10 +158,45 @@ def dev_knobs(environ, dev):
     return found
 
 
+def c_host_chain(W, H):
+    """tools/frame_chain.c compiled and run: the per-frame drop-in chain from a C host -> {mode: {median_ms, min_ms, p90_ms, extract_color_host_us}}"""
+    try:
+        import re
+        import shutil
+        import subprocess
+        import tempfile
+        cc = shutil.which("gcc") or shutil.which("cc")
+        if not cc:
+            return {"error": "no C compiler"}
+        exe = os.path.join(tempfile.mkdtemp(prefix="rmcv_fc_"), "frame_chain")
+        libdir = os.path.join(ROOT, "rmcv_amd", "lib")
+        subprocess.run([cc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "frame_chain.c"), "-o", exe,
+                        "-L", libdir, "-lrmcv_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, timeout=120)
+        cp = subprocess.run([exe, str(W), str(H)], capture_output=True, text=True, timeout=120)
+        ch, last_ = {}, None
+        for ln in cp.stdout.splitlines():
+            w_ = ln.split()
+            if len(w_) > 6 and w_[1] == "median":
+                last_ = w_[0]
+                ch[last_] = {"median_ms": float(w_[2]), "min_ms": float(w_[4]), "p90_ms": float(w_[6])}
+            elif last_ and ln.strip().startswith("extract_color on the host"):
+                # where rmcv_extract_color's host time goes (rmcv_ctx_frame_timing): median (p90) microseconds per step
+                ch[last_]["extract_color_host_us"] = {k.strip(): [float(a), float(b_)] for k, a, b_ in
+                                                      re.findall(r"  ([a-zA-Z+ 2]+?) ([0-9.]+) \(([0-9.]+)\)", ln.split(":", 1)[1])}
+        if not ch:
+            return {"error": (cp.stderr or cp.stdout)[-200:]}
+        return dict(ch, note="tools/frame_chain.c: the three C-ABI calls from C, 300 chains per mode")
+    except Exception as e:  # noqa: BLE001 -- a side measurement: report, never fail the bench line
+        return {"error": repr(e)[:200]}
+
+
 def main():
     args = parse_args()
     world, rank, local_rank, launched = resolve_world(args, os.environ)
     knobs = dev_knobs(os.environ, args.dev)
+    c_host_first = None
+    if world == 1 and rank == 0 and not args.no_extras and not args.roofline_only and args.workload == "c3":
+        c_host_first = c_host_chain(*WORKLOADS[args.workload])   # before this process touches the GPU (see single_frame_ms)
     if args.gpus > 1 and not launched:
         import torch                                             # (may call hipGetDeviceCount; harmless: the ranks are fresh children)
         have = torch.cuda.device_count()
@@ -852,34 +887,13 @@ def main():
         sf["note"] = ("one %dx%d host frame per call chain, results copied back to host after every call (what rm::extract_color / "
                       "filter_lightblobs / filter_armours return); 60 chains per mode; PCIe-inclusive, never `value`" % (W, H))
         c1.close()
-        # the same chain from a C host (tools/frame_chain.c, compiled here if a C compiler is at hand): what an unchanged C++ caller
-        # sees -- the figures above carry three ctypes calls per frame
-        try:
-            import shutil
-            import subprocess
-            import tempfile
-            cc = shutil.which("gcc") or shutil.which("cc")
-            if cc:
-                exe = os.path.join(tempfile.mkdtemp(prefix="rmcv_fc_"), "frame_chain")
-                libdir = os.path.join(ROOT, "rmcv_amd", "lib")
-                subprocess.run([cc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "frame_chain.c"), "-o", exe,
-                                "-L", libdir, "-lrmcv_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, timeout=120)
-                cp = subprocess.run([exe, str(W), str(H)], capture_output=True, text=True, timeout=120)
-                ch, last_ = {}, None
-                for ln in cp.stdout.splitlines():
-                    w_ = ln.split()
-                    if len(w_) > 6 and w_[1] == "median":
-                        last_ = w_[0]
-                        ch[last_] = {"median_ms": float(w_[2]), "min_ms": float(w_[4]), "p90_ms": float(w_[6])}
-                    elif last_ and ln.strip().startswith("extract_color on the host"):
-                        import re
-                        # where rmcv_extract_color's host time goes (rmcv_ctx_frame_timing): median (p90) microseconds per step
-                        ch[last_]["extract_color_host_us"] = {k.strip(): [float(a), float(b_)] for k, a, b_ in
-                                                              re.findall(r"  ([a-zA-Z+ 2]+?) ([0-9.]+) \(([0-9.]+)\)", ln.split(":", 1)[1])}
-                if ch:
-                    sf["c_host"] = dict(ch, note="tools/frame_chain.c: the three C-ABI calls from C, 300 chains per mode")
-        except Exception as e:  # noqa: BLE001 -- a side measurement: report, never fail the bench line
-            sf["c_host"] = {"error": repr(e)[:200]}
+        # the same chain from a C host (tools/frame_chain.c): what an unchanged C++ caller sees -- the figures above carry three ctypes
+        # calls per frame.  Measured twice: FIRST THING in this run, before this process had touched the GPU (c_host: a host has the
+        # GPU to itself, as the reference's executable does), and here, as a child of a process that holds a dozen queues on the same
+        # GPU (c_host_beside_this_process: the runtime's own waits get slower then -- the library's do not depend on them any more)
+        if c_host_first is not None:
+            sf["c_host"] = c_host_first
+        sf["c_host_beside_this_process"] = c_host_chain(W, H)
         out["single_frame_ms"] = sf
 
     if rank == 0 and world == 1 and args.cpu_frames > 0:

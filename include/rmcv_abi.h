@@ -210,9 +210,10 @@ int64_t rmcv_pixel_ws_launches(void);
  * correct build; rmcv_last_error names the first).  Synchronises the context.  A test/diagnosis hook (tests/test_gpu_canary.py). */
 int  rmcv_ctx_check_guards(rmcv_ctx* ctx, int32_t* n_damaged);
 /* where the last rmcv_extract_color spent its time on the HOST, seven figures in microseconds: us[0] waiting for earlier work, binding,
- * enqueuing the upload; us[1] enqueuing the kernels; us[2] waiting for upload + pixel kernel; us[3] the byte image's download call;
- * us[4] waiting for it; us[5] waiting for the frame's kernels; us[6] handing the lists over.  cap >= 7.  A diagnosis hook
- * (tools/frame_chain.c prints the medians). */
+ * enqueuing the upload; us[1] enqueuing the kernels; us[2] until the byte image's first chunk is home (upload + pixel kernel + PCIe);
+ * us[3] the other chunks, copied into binary_out as they arrive; us[4] (the runtime's copy where there is no mapped pinned memory);
+ * us[5] waiting for the frame's kernels; us[6] handing the lists over.  cap >= 7.  A diagnosis hook (tools/frame_chain.c prints
+ * the medians). */
 int  rmcv_ctx_frame_timing(const rmcv_ctx* ctx, double* us, int cap);
 /* drop the pinning RMCV_OPT_FRAME_UPLOAD = 2 made for `frame` (NULL: all of them); drains the context's stream first */
 int  rmcv_ctx_forget_frame_buffer(rmcv_ctx* ctx, const void* frame);

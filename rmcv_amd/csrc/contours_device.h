@@ -221,7 +221,15 @@ struct LabelStore {
 // frames' workgroups, so the tables are sized for ~50 KB (3 per CU); measured +4-8 % on the 3-stream bench against 75 KB.
 // Frames beyond a capacity take the literal path (tests/test_gpu_parity.py covers each limit).
 static constexpr int KEPT_CAP = 512;
-static constexpr int SLOT_CAP = 1024;  // non-empty words of a frame the LDS label store can hold
+// Non-empty words of a frame the LDS label store can hold.  Round 5: 1664 instead of 1024 at the SAME struct size -- the per-word border
+// masks (bmask / e2mask: written in N1, last read in N3) and the label planes (lab / neg: first written in N7) never live at the same
+// time and share their storage, 20 bytes per word instead of 36.  A scene of 400 specks and a few lit windows (the synthetic stream's
+// dense2: 950-1560 non-empty words, 2 300 border points per frame) now stays in the LDS tier instead of taking the mid tier at four times
+// the cost per frame -- and its batches stay "calm" for the pipeline's hot contexts.
+#ifndef RMCV_SLOT_CAP
+#define RMCV_SLOT_CAP 1664
+#endif
+static constexpr int SLOT_CAP = RMCV_SLOT_CAP;
 // Workgroup size is a build parameter (k_contours_kernel.inc): 8 wavefronts build the borders and fit the bars of a frame (lowest
 // latency for one batch), 4 wavefronts leave room on every CU for the pixel kernels of the next batches AND the sparse kernel of the previous
 // one (VGPR budget per SIMD: 2 x 160 for this kernel at 8 wavefronts, 2 x 80 per pixel kernel, 512 in all) -- the better choice
@@ -238,21 +246,21 @@ static constexpr int CT_MAXH = RMCV_CT_MAXH;   // rows covered by the LDS row ta
 // a row costs 8 bytes (mask of its non-empty words, its place in the list of non-empty rows, its slot base), 2048 rows 16 KB but the
 // 1200 rows of a 1920x1200 frame 9.6 KB -- and with 16 KB the workgroup did not fit a CU's 160 KB beside the four pixel-kernel
 // workgroups (4 x 19.8 KB) of two batches at that width (round 3: C5 +4-6 % once it does, tools/ab_process_r3.sh c5_lds).
-// Layout: what the fused tail may overlay with its wave-private rows comes first (exactly 8 x sizeof(WaveLds) = 30 720 bytes: tables
-// that are dead once the contours are out), then what it needs (the work-list copies in bmask / e2mask, the node tables), then the
-// scalars.
+// Layout: first the tables of the LDS tier that are dead once the contours are out -- the fused tail overlays its wave-private rows on
+// the first 8 x sizeof(WaveLds) = 30 720 bytes of them, and the mid tier runs its pointer doubling on the whole of them (mid_lds_words)
+// --, then what every tier shares (scan, ringtab), then what the fused tail needs (the work list's copies, the node tables), then the scalars.
 struct ContoursLds {
-    unsigned long long lab[SLOT_CAP], neg[SLOT_CAP];
+    unsigned long long lab[SLOT_CAP], neg[SLOT_CAP]; // N1-N3: the words' border masks (bmask / e2mask below); from N7 on: the label planes
+    uint16_t nbase[SLOT_CAP], spos[SLOT_CAP]; // cycle formulation: node-id base and (row, word) per slot
     uint32_t kkey[KEPT_CAP];
     int32_t koff[KEPT_CAP], klen[KEPT_CAP];
-    int scan[CT_THREADS_MAX];
-    uint16_t nbase[SLOT_CAP], spos[SLOT_CAP]; // cycle formulation: node-id base and (row, word) per slot
-    uint32_t ringtab[256];
-    uint32_t multi[MULTI_CAP]; // cycles_frame: pixels the border visits 3 or 4 times: slot:16 | bit:6 << 16 | count << 24
     uint8_t kacc[KEPT_CAP];    // cycles_frame: outer border e is (still) accepted by the RETR_EXTERNAL rule
-    uint8_t pad_front[384];    // (brings the part above to 8 x sizeof(WaveLds))
-    // cycle formulation (cycles_frame): border pixels / two-visit pixels per slot, node tables
-    unsigned long long bmask[SLOT_CAP], e2mask[SLOT_CAP];
+    uint32_t multi[MULTI_CAP]; // cycles_frame: pixels the border visits 3 or 4 times: slot:16 | bit:6 << 16 | count << 24
+    // ---- shared by the tiers
+    int scan[CT_THREADS_MAX];
+    uint32_t ringtab[256];
+    // ---- the fused tail's: starts and lengths of the work list's contours (cycle path), the node tables (work list, sort keys)
+    uint32_t w_off[KEPT_CAP], w_cnt[KEPT_CAP];
     uint16_t n_a[NN_CAP], n_b[NN_CAP], n_d[NN_CAP];
     int nnodes, nkept, cursor, flags, nrows, nslots, nelig, lit[3];
     int nmulti;
@@ -260,7 +268,10 @@ struct ContoursLds {
     int wnext;    // fused tail: next entry of the sorted work list
     int sink[64]; // per-lane sinks: lanes != 0 add 0 here so that a wave-wide atomic stays convergent and does not serialise on one word
 };
-static_assert(offsetof(ContoursLds, bmask) == (CT_THREADS_MAX / 64) * 3840, "the part the fused tail overlays is exactly its wave-private rows (sizeof(WaveLds) = 3840)");
+static_assert(offsetof(ContoursLds, kkey) >= (CT_THREADS_MAX / 64) * 3840, "the fused tail's wave-private rows (sizeof(WaveLds) = 3840 each) overlay dead tables only");
+static_assert(offsetof(ContoursLds, scan) % 8 == 0 && offsetof(ContoursLds, w_off) % 8 == 0, "alignment");
+// words of LDS the mid tier may use for its pointer doubling: the LDS tier's own tables in front of `scan`
+static constexpr int MID_LDS_WORDS = (int)(offsetof(ContoursLds, scan) / 4);
 
 // the row tables behind the struct: `rows_cap` rows (the frame's height rounded up to 64, at most CT_MAXH)
 struct RowTabs {
@@ -268,8 +279,8 @@ struct RowTabs {
     uint16_t* rows;    // the non-empty rows
     uint16_t* rowbase; // [row] slot of the row's first non-empty word
 };
-__host__ __device__ inline int lds_rows_cap(int h) { const int r = (h + 63) & ~63; return r < CT_MAXH ? r : CT_MAXH; }
-__host__ __device__ inline size_t lds_bytes(int h) { return sizeof(ContoursLds) + (size_t)lds_rows_cap(h) * 8; }
+__host__ __device__ static inline int lds_rows_cap(int h) { const int r = (h + 63) & ~63; return r < CT_MAXH ? r : CT_MAXH; }
+__host__ __device__ static inline size_t lds_bytes(int h) { return sizeof(ContoursLds) + (size_t)lds_rows_cap(h) * 8; }
 __device__ __forceinline__ RowTabs row_tabs(void* smem, int rows_cap)
 {
     RowTabs R;
@@ -402,11 +413,11 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, 
 {
     constexpr int NPT = NN_CAP / T; // nodes per thread in the doubling rounds
     const LabelStore LS = {RT.rowmask, RT.rowbase, S.lab, S.neg};
-    uint16_t* const nxt = S.n_a; // successor, later the distance from the cycle's start
-    uint16_t* const mn = S.n_b;  // smallest node id of the cycle
-    uint16_t* const jp = S.n_d;  // doubling pointer, later the kept-contour slot of a start node
+    unsigned long long* const bmask = S.lab;  // border pixels / two-visit pixels per slot: N1-N3 only -- the label planes take their place in N7
+    unsigned long long* const e2mask = S.neg;
+    uint16_t* const nxt = S.n_a; // successor of every node (N3 .. N5)
 #ifdef RMCV_PROFILE
-    long long tc_[10]; int tci_ = 0;
+    long long tc_[12]; int tci_ = 0;
 #define CSTAMP() do { __syncthreads(); tc_[tci_++] = wall_clock64(); } while (0)
 #else
 #define CSTAMP() do {} while (0)
@@ -451,8 +462,8 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, 
             else atomicOr(&S.flags, FLCAP);
             extra += (int)cnt - 2;
         }
-        S.bmask[slot] = B;
-        S.e2mask[slot] = E2;
+        bmask[slot] = B;
+        e2mask[slot] = E2;
         S.nbase[slot] = (uint16_t)(__popcll(B) + __popcll(E2) + extra);
     }
     __syncthreads();
@@ -489,29 +500,84 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, 
     if (S.flags) return;
     const int nn = S.nnodes;
     CSTAMP();
-    // ---- N2: the nodes
-    for (int slot = tid; slot < nslots; slot += T) {
-        const uint64_t B = S.bmask[slot];
-        if (!B) continue;
-        const int y = S.spos[slot] & 2047, k = S.spos[slot] >> 11;
-        const int64_t base = (int64_t)(y + 1) * prow + 1;
-        const uint64_t mc = F[base + k];
-        const uint64_t ul = F[base - prow + k - 1], uc = F[base - prow + k], ur = F[base - prow + k + 1];
-        const uint64_t ml = F[base + k - 1], mr = F[base + k + 1];
-        const uint64_t dl = F[base + prow + k - 1], dc = F[base + prow + k], dr = F[base + prow + k + 1];
-        int id = S.nbase[slot];
-        uint64_t rem = B;
-        while (rem) {
-            const int b = __ffsll((long long)rem) - 1;
-            rem &= rem - 1;
-            const uint32_t e = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)];
-            const int cnt = (int)(e & 7u);
-            const uint32_t xy = (uint32_t)(k * 64 + b) | ((uint32_t)y << 12);
-            for (int a = 0; a < cnt && a < 4; a++) {
-                const uint32_t back = (e >> (3 + 3 * a)) & 7u, nextd = (e >> (15 + 3 * a)) & 7u, ng = (e >> (28 + a)) & 1u;
-                const uint32_t west = a == 0 ? (e >> 27) & 1u : 0u;
-                if (id < NN_CAP) pxy[id] = xy | (back << 24) | (ng << 27) | (west << 28) | (nextd << 29);
-                id++;
+    // ---- N2: the nodes.  Round 5: one border PIXEL per lane.  (One non-empty WORD per lane, walking its border pixels one after the
+    // other, ran as long as the fullest of a wavefront's 64 words -- the edge of a lit window is 64 border pixels in one word, a speck
+    // two: 35 of the 95 us a frame of 400 specks spent on its borders.)  A wavefront takes 64 words at a time: every lane stages its
+    // word's three centre words and six neighbouring edge bits in wave-private LDS (the node tables n_a .. n_d are still free), the lanes
+    // scatter (word, bit) of their border pixels into a list at the word's exclusive prefix, and then every lane takes list entries:
+    // ring -> visits -> node ids exactly as the word-wise walk numbered them (the id of a pixel's first visit = the word's base + the
+    // visits of the word's earlier pixels: the formula N3 uses to find a successor).
+    {
+        constexpr int NWV = T / 64;
+        constexpr int STG = (int)(3 * NN_CAP * sizeof(uint16_t)) / NWV; // bytes of staging per wavefront
+        constexpr int LCAP = (STG - 2048) / 2;                           // list entries per pass
+        static_assert(LCAP >= 256 && offsetof(ContoursLds, n_b) == offsetof(ContoursLds, n_a) + NN_CAP * sizeof(uint16_t) &&
+                      offsetof(ContoursLds, n_d) == offsetof(ContoursLds, n_b) + NN_CAP * sizeof(uint16_t), "n_a .. n_d are one block");
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned char* const stg = reinterpret_cast<unsigned char*>(S.n_a) + wave * STG;
+        unsigned long long* const sw = reinterpret_cast<unsigned long long*>(stg); // [4][64]: uc, mc, dc, edge bits
+        uint16_t* const list = reinterpret_cast<uint16_t*>(stg + 2048);
+        for (int c0 = wave * 64; c0 < nslots; c0 += T) { // (wave-uniform)
+            const int slot = c0 + lane;
+            uint64_t B = 0;
+            if (slot < nslots) {
+                B = bmask[slot];
+                const int y = S.spos[slot] & 2047, k = S.spos[slot] >> 11;
+                const int64_t base = (int64_t)(y + 1) * prow + 1 + k;
+                const uint64_t ul = F[base - prow - 1], uc = F[base - prow], ur = F[base - prow + 1];
+                const uint64_t ml = F[base - 1], mc = F[base], mr = F[base + 1];
+                const uint64_t dl = F[base + prow - 1], dc = F[base + prow], dr = F[base + prow + 1];
+                sw[lane] = uc;
+                sw[64 + lane] = mc;
+                sw[128 + lane] = dc;
+                sw[192 + lane] = (ul >> 63) | ((ur & 1ull) << 1) | ((ml >> 63) << 2) | ((mr & 1ull) << 3) | ((dl >> 63) << 4) | ((dr & 1ull) << 5);
+            }
+            const int pc = __popcll(B);
+            int incl = pc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+            }
+            const int excl = incl - pc, P = __shfl(incl, 63);
+            for (int p0 = 0; p0 < P; p0 += LCAP) { // (wave-uniform)
+                uint64_t rem = B;
+                int r = excl - p0;
+                while (rem) {
+                    const int b = __ffsll((long long)rem) - 1;
+                    rem &= rem - 1;
+                    if (r >= 0 && r < LCAP) list[r] = (uint16_t)((lane << 6) | b);
+                    r++;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int m = P - p0 < LCAP ? P - p0 : LCAP;
+                for (int j = lane; j < m; j += 64) {
+                    const int en = list[j], sl = en >> 6, bb = en & 63;
+                    const uint64_t uc = sw[sl], mc = sw[64 + sl], dc = sw[128 + sl], eb = sw[192 + sl];
+                    const int slot2 = c0 + sl;
+                    const uint32_t e = S.ringtab[ring_of(bb, (eb & 1ull) << 63, uc, (eb >> 1) & 1ull, ((eb >> 2) & 1ull) << 63, mc, (eb >> 3) & 1ull,
+                                                         ((eb >> 4) & 1ull) << 63, dc, (eb >> 5) & 1ull)];
+                    const int cnt = (int)(e & 7u);
+                    const int y = S.spos[slot2] & 2047, k = S.spos[slot2] >> 11;
+                    const uint32_t xy = (uint32_t)(k * 64 + bb) | ((uint32_t)y << 12);
+                    const uint64_t below = (1ull << bb) - 1;
+                    int id = S.nbase[slot2] + __popcll(bmask[slot2] & below) + __popcll(e2mask[slot2] & below);
+                    if (S.nmulti) {
+                        int own;
+                        id += multi_extra(S, slot2, bb, &own);
+                    }
+                    for (int a = 0; a < cnt && a < 4; a++) {
+                        const uint32_t back = (e >> (3 + 3 * a)) & 7u, nextd = (e >> (15 + 3 * a)) & 7u, ng = (e >> (28 + a)) & 1u;
+                        const uint32_t west = a == 0 ? (e >> 27) & 1u : 0u;
+                        if (id < NN_CAP) pxy[id] = xy | (back << 24) | (ng << 27) | (west << 28) | (nextd << 29);
+                        id++;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier(); // the list (and, behind the last pass, the staged words) are rewritten
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
     }
@@ -528,12 +594,12 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, 
         int slot2 = 0;
         if (ok) {
             slot2 = LS.slot(ys, ks);
-            ok = (S.bmask[slot2] >> bs) & 1ull;
+            ok = (bmask[slot2] >> bs) & 1ull;
         }
         if (ok) {
             const uint64_t below = (1ull << bs) - 1;
-            int id0 = S.nbase[slot2] + __popcll(S.bmask[slot2] & below) + __popcll(S.e2mask[slot2] & below);
-            int cnt2 = 1 + (int)((S.e2mask[slot2] >> bs) & 1ull);
+            int id0 = S.nbase[slot2] + __popcll(bmask[slot2] & below) + __popcll(e2mask[slot2] & below);
+            int cnt2 = 1 + (int)((e2mask[slot2] >> bs) & 1ull);
             if (S.nmulti) {
                 int own;
                 id0 += multi_extra(S, slot2, bs, &own);
@@ -558,74 +624,66 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, 
     __syncthreads();
     if (S.flags) return;
     CSTAMP();
-    // ---- N4: smallest node id of every cycle, by pointer doubling
+    // ---- N4: smallest node id of every cycle, by pointer doubling.  Round 5: ONE packed word per node (mn : 16 | jp : 16), swept in
+    // place -- a word always describes a true segment [i, jp) of the cycle with its minimum, so a sweep may read words other threads
+    // have already advanced (after `rounds` sweeps every segment is at least nn long, i.e. covers its whole cycle): one gather and one
+    // barrier per node and round instead of two and two (the mid tier's form; 14.4 -> 7 us per phase on a frame of 2 000 visits).
+    static_assert(offsetof(ContoursLds, n_d) == offsetof(ContoursLds, n_b) + NN_CAP * sizeof(uint16_t), "n_b + n_d hold one 32-bit word per node");
+    uint32_t* const Rw = reinterpret_cast<uint32_t*>(S.n_b);
     int rounds = 0;
     while ((1 << rounds) < nn) rounds++;
-    for (int i = tid; i < nn; i += T) {
-        mn[i] = (uint16_t)i;
-        jp[i] = nxt[i];
-    }
+    for (int i = tid; i < nn; i += T) Rw[i] = ((uint32_t)i << 16) | nxt[i];
     __syncthreads();
     for (int rd = 0; rd < rounds; rd++) {
-        uint16_t m2[NPT], j2[NPT];
+        uint32_t w[NPT], wt[NPT];
 #pragma unroll
-        for (int u = 0; u < NPT; u++) {
-            const int i = tid + u * T;
-            if (i < nn) {
-                const int t = jp[i];
-                m2[u] = mn[t];
-                j2[u] = jp[t];
-            }
-        }
-        __syncthreads();
+        for (int u = 0; u < NPT; u++) w[u] = tid + u * T < nn ? Rw[tid + u * T] : 0u;
 #pragma unroll
-        for (int u = 0; u < NPT; u++) {
-            const int i = tid + u * T;
-            if (i < nn) {
-                if (m2[u] < mn[i]) mn[i] = m2[u];
-                jp[i] = j2[u];
-            }
-        }
+        for (int u = 0; u < NPT; u++) wt[u] = Rw[w[u] & 0xFFFFu];
+#pragma unroll
+        for (int u = 0; u < NPT; u++)
+            if (tid + u * T < nn) Rw[tid + u * T] = (((w[u] >> 16) < (wt[u] >> 16) ? (w[u] >> 16) : (wt[u] >> 16)) << 16) | (wt[u] & 0xFFFFu);
         __syncthreads();
     }
     CSTAMP();
     // ---- N5: number of steps from every node FORWARD to its cycle's start (the smallest id); a node's position in the contour is
-    // the cycle length minus that.  The doubling pointers are the successors with the start made absorbing.
-    uint16_t* const dist = nxt; // in place: the successors are read into the doubling pointers first
+    // the cycle length minus that.  The doubling pointers are the successors with the start made absorbing; the word is (dist : 16 | jp : 16).
+    // From here on: mn lives where the successors were (n_a), the distances in n_b, the starts' kept-contour slots in n_d.
+    uint16_t* const mn = S.n_a;
+    uint16_t* const dist = S.n_b;
+    uint16_t* const jp = S.n_d;
     uint16_t succ0[NPT]; // the successor of a start node: the last node of its contour
 #pragma unroll
-    for (int u = 0; u < NPT; u++) {
+    for (int u = 0; u < NPT; u++) { // (a thread touches only its own nodes' words: no barrier inside)
         const int i = tid + u * T;
         succ0[u] = 0;
         if (i < nn) {
-            const bool start = mn[i] == i;
-            succ0[u] = nxt[i];
-            jp[i] = start ? (uint16_t)i : nxt[i];
+            const uint32_t mnv = Rw[i] >> 16, sc = nxt[i];
+            succ0[u] = (uint16_t)sc;
+            mn[i] = (uint16_t)mnv; // (overwrites nxt[i])
+            Rw[i] = mnv == (uint32_t)i ? (uint32_t)i : ((1u << 16) | sc);
         }
     }
     __syncthreads();
-    for (int i = tid; i < nn; i += T) dist[i] = mn[i] == i ? 0 : 1;
-    __syncthreads();
     for (int rd = 0; rd < rounds; rd++) {
-        uint16_t d2[NPT], j2[NPT];
+        uint32_t w[NPT], wt[NPT];
 #pragma unroll
-        for (int u = 0; u < NPT; u++) {
-            const int i = tid + u * T;
-            if (i < nn) {
-                const int t = jp[i];
-                d2[u] = dist[t];
-                j2[u] = jp[t];
-            }
-        }
+        for (int u = 0; u < NPT; u++) w[u] = tid + u * T < nn ? Rw[tid + u * T] : 0u;
+#pragma unroll
+        for (int u = 0; u < NPT; u++) wt[u] = Rw[w[u] & 0xFFFFu];
+#pragma unroll
+        for (int u = 0; u < NPT; u++)
+            if (tid + u * T < nn) Rw[tid + u * T] = (((w[u] >> 16) + (wt[u] >> 16)) << 16) | (wt[u] & 0xFFFFu);
+        __syncthreads();
+    }
+    {   // the distances move into their 16-bit table (half of the words' own storage: everybody reads before anybody writes)
+        uint16_t dv[NPT];
+#pragma unroll
+        for (int u = 0; u < NPT; u++) dv[u] = tid + u * T < nn ? (uint16_t)(Rw[tid + u * T] >> 16) : (uint16_t)0;
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < NPT; u++) {
-            const int i = tid + u * T;
-            if (i < nn) {
-                dist[i] = (uint16_t)(dist[i] + d2[u]);
-                jp[i] = j2[u];
-            }
-        }
+        for (int u = 0; u < NPT; u++)
+            if (tid + u * T < nn) dist[tid + u * T] = dv[u];
         __syncthreads();
     }
     CSTAMP();
@@ -652,6 +710,7 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, 
     }
     __syncthreads();
     if (S.flags) return;
+    CSTAMP();
     // ---- N7: RETR_EXTERNAL.  OpenCV's scanner skips an outer-border start when the last labelled pixel it met on the row is
     // positive, and only the borders it traced carry labels: a component inside a hole of a traced one is skipped.  A start's
     // left context consists of raster-earlier borders only, so the scanner's decisions are the fixed point of "label the accepted
@@ -704,6 +763,7 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, 
             return;
         }
     }
+    CSTAMP();
     // ---- N8: output of the accepted borders
     for (int e = tid; e < ncand; e += T)
         if (S.kacc[e]) {
@@ -747,10 +807,10 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, 
     }
 #ifdef RMCV_PROFILE
     CSTAMP();
-    if (tid == 0 && (blockIdx.x == 100))
-        printf("[cycles f%d nn=%d rounds=%d] ringtab %.1f N1+scan %.1f N2 %.1f N3 %.1f N4 %.1f N5 %.1f N6+N7 %.1f us\n", (int)blockIdx.x, nn, rounds,
-               (tc_[1] - tc_[0]) / 100.0, (tc_[2] - tc_[1]) / 100.0, (tc_[3] - tc_[2]) / 100.0, (tc_[4] - tc_[3]) / 100.0,
-               (tc_[5] - tc_[4]) / 100.0, (tc_[6] - tc_[5]) / 100.0, (tc_[7] - tc_[6]) / 100.0);
+    if (tid == 0 && (blockIdx.x == 100 || blockIdx.x == 1))
+        printf("[cycles b%d nn=%d slots=%d cand=%d rounds=%d] ringtab+spos %.1f N1+scan %.1f N2 %.1f N3 %.1f N4 %.1f N5 %.1f N6 %.1f N7 %.1f N8+kept %.1f us\n", (int)blockIdx.x, nn, nslots, ncand, rounds,
+               (tc_[2] - tc_[0]) / 100.0, (tc_[3] - tc_[2]) / 100.0, (tc_[4] - tc_[3]) / 100.0, (tc_[5] - tc_[4]) / 100.0,
+               (tc_[6] - tc_[5]) / 100.0, (tc_[7] - tc_[6]) / 100.0, (tc_[8] - tc_[7]) / 100.0, (tc_[9] - tc_[8]) / 100.0, (tc_[10] - tc_[9]) / 100.0);
 #endif
 }
 
@@ -930,45 +990,83 @@ __device__ __forceinline__ void cycles_frame_mid(ContoursLds& S, const RowTabs& 
     if (tid == 0) S.nnodes = nn;
     __syncthreads();
     MSTAMP(); // 1: M0 + M1 + prefix
-    // ---- M2: the nodes
-    for (int s0 = tid; s0 < nslots; s0 += 2 * T) {
-        uint32_t sp[2], idb[2];
-        uint64_t wd[2][9];
+    // ---- M2: the nodes, one border PIXEL per lane (see N2 of cycles_frame): a wavefront stages 64 words -- centre words, edge bits, the four
+    // visit masks, node base, position -- in the LDS the tier-0 tables do not need here, scatters (word, bit) of their border pixels into a
+    // list and takes list entries.  (Word-wise: 100-130 us of a 380 us frame of 8 500 visits, as long as the fullest word of every 64.)
+    {
+        constexpr int NWV = T / 64;
+        constexpr int WST = 64 * (8 * 8 + 2 * 4);                           // staged bytes per wavefront
+        constexpr int LCAP = (int)(3 * NN_CAP * sizeof(uint16_t)) / NWV / 2; // list entries per pass (the node tables n_a .. n_d)
+        static_assert(NWV * WST <= (int)offsetof(ContoursLds, scan), "the staged words fit the tier-0 tables");
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned char* const stg = reinterpret_cast<unsigned char*>(S.lab) + wave * WST;
+        unsigned long long* const sw = reinterpret_cast<unsigned long long*>(stg); // [8][64]: uc, mc, dc, edge bits, B, E2, E3, E4
+        uint32_t* const sn = reinterpret_cast<uint32_t*>(stg + 64 * 64);            // [2][64]: nbase, spos
+        uint16_t* const list = S.n_a + wave * LCAP;
+        for (int c0 = wave * 64; c0 < nslots; c0 += T) { // (wave-uniform)
+            const int slot = c0 + lane;
+            uint64_t B = 0;
+            if (slot < nslots) {
+                const uint32_t sp = M.spos[slot];
+                const int y = sp & 2047, k = sp >> 11;
+                const int64_t base = (int64_t)(y + 1) * prow + 1 + k;
+                const uint64_t ul = F[base - prow - 1], uc = F[base - prow], ur = F[base - prow + 1];
+                const uint64_t ml = F[base - 1], mc = F[base], mr = F[base + 1];
+                const uint64_t dl = F[base + prow - 1], dc = F[base + prow], dr = F[base + prow + 1];
+                B = M.bmask[slot];
+                sw[lane] = uc;
+                sw[64 + lane] = mc;
+                sw[128 + lane] = dc;
+                sw[192 + lane] = (ul >> 63) | ((ur & 1ull) << 1) | ((ml >> 63) << 2) | ((mr & 1ull) << 3) | ((dl >> 63) << 4) | ((dr & 1ull) << 5);
+                sw[256 + lane] = B;
+                sw[320 + lane] = M.e2[slot];
+                sw[384 + lane] = M.e3[slot];
+                sw[448 + lane] = M.e4[slot];
+                sn[lane] = M.nbase[slot];
+                sn[64 + lane] = sp;
+            }
+            const int pc = __popcll(B);
+            int incl = pc;
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const bool ok = s0 + u * T < nslots;
-            sp[u] = ok ? M.spos[s0 + u * T] : 0u;
-            idb[u] = ok ? M.nbase[s0 + u * T] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int y = sp[u] & 2047, k = sp[u] >> 11;
-            const int64_t base = (int64_t)(y + 1) * prow + 1 + k;
-            const bool ok = s0 + u * T < nslots;
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) wd[u][3 * r + c] = ok ? F[base + (r - 1) * prow + (c - 1)] : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            if (s0 + u * T >= nslots) continue;
-            const uint64_t ul = wd[u][0], uc = wd[u][1], ur = wd[u][2], ml = wd[u][3], mc = wd[u][4], mr = wd[u][5], dl = wd[u][6], dc = wd[u][7], dr = wd[u][8];
-            const uint64_t left = (mc << 1) | (ml >> 63), right = (mc >> 1) | (mr << 63);
-            const int y = sp[u] & 2047, k = sp[u] >> 11;
-            uint32_t id = idb[u];
-            uint64_t rem = mc & ~(uc & dc & left & right);
-            while (rem) {
-                const int b = __ffsll((long long)rem) - 1;
-                rem &= rem - 1;
-                const uint32_t e = S.ringtab[ring_of(b, ul, uc, ur, ml, mc, mr, dl, dc, dr)];
-                const int cnt = (int)(e & 7u);
-                const uint32_t xy = (uint32_t)(k * 64 + b) | ((uint32_t)y << 12);
-                for (int a2 = 0; a2 < cnt && a2 < 4; a2++) {
-                    const uint32_t back = (e >> (3 + 3 * a2)) & 7u, nextd = (e >> (15 + 3 * a2)) & 7u, ng = (e >> (28 + a2)) & 1u;
-                    const uint32_t west = a2 == 0 ? (e >> 27) & 1u : 0u;
-                    M.pxy[id++] = xy | (back << 24) | (ng << 27) | (west << 28) | (nextd << 29);
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+            }
+            const int excl = incl - pc, P = __shfl(incl, 63);
+            for (int p0 = 0; p0 < P; p0 += LCAP) { // (wave-uniform)
+                uint64_t rem = B;
+                int r = excl - p0;
+                while (rem) {
+                    const int b = __ffsll((long long)rem) - 1;
+                    rem &= rem - 1;
+                    if (r >= 0 && r < LCAP) list[r] = (uint16_t)((lane << 6) | b);
+                    r++;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int m = P - p0 < LCAP ? P - p0 : LCAP;
+                for (int j = lane; j < m; j += 64) {
+                    const int en = list[j], sl = en >> 6, bb = en & 63;
+                    const uint64_t uc = sw[sl], mc = sw[64 + sl], dc = sw[128 + sl], eb = sw[192 + sl];
+                    const uint32_t e = S.ringtab[ring_of(bb, (eb & 1ull) << 63, uc, (eb >> 1) & 1ull, ((eb >> 2) & 1ull) << 63, mc, (eb >> 3) & 1ull,
+                                                         ((eb >> 4) & 1ull) << 63, dc, (eb >> 5) & 1ull)];
+                    const int cnt = (int)(e & 7u);
+                    const uint32_t sp = sn[64 + sl];
+                    const int y = sp & 2047, k = sp >> 11;
+                    const uint32_t xy = (uint32_t)(k * 64 + bb) | ((uint32_t)y << 12);
+                    const uint64_t below = (1ull << bb) - 1;
+                    uint32_t id = sn[sl] + (uint32_t)(__popcll(sw[256 + sl] & below) + __popcll(sw[320 + sl] & below) + __popcll(sw[384 + sl] & below) +
+                                                      __popcll(sw[448 + sl] & below));
+                    for (int a2 = 0; a2 < cnt && a2 < 4; a2++) {
+                        const uint32_t back = (e >> (3 + 3 * a2)) & 7u, nextd = (e >> (15 + 3 * a2)) & 7u, ng = (e >> (28 + a2)) & 1u;
+                        const uint32_t west = a2 == 0 ? (e >> 27) & 1u : 0u;
+                        M.pxy[id++] = xy | (back << 24) | (ng << 27) | (west << 28) | (nextd << 29);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier(); // the list (and, behind the last pass, the staged words) are rewritten
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
     }
@@ -1041,11 +1139,10 @@ __device__ __forceinline__ void cycles_frame_mid(ContoursLds& S, const RowTabs& 
     int rounds = 0;
     while ((1 << rounds) < nn) rounds++;
     // The doubling sweeps are rounds x 2 dependent accesses per node.  Up to NN_LDS nodes they run on a packed 32-bit word per node
-    // (mn or dist : 16 | jp : 16) in the LDS the tier-0 tables do not need here (bmask .. n_d, 44 KB) -- an LDS round trip is a tenth
+    // (mn or dist : 16 | jp : 16) in the LDS the tier-0 tables do not need here (lab .. multi, 38 KB) -- an LDS round trip is a tenth
     // of an L2 one; the final values go to the global tables the later phases read.  Larger frames sweep the global tables.
-    static_assert(offsetof(ContoursLds, n_d) > offsetof(ContoursLds, bmask), "bmask .. n_d are laid out in this order");
-    constexpr int NN_LDS = (int)((offsetof(ContoursLds, n_d) + sizeof(uint16_t) * NN_CAP - offsetof(ContoursLds, bmask)) / 4);
-    uint32_t* const R = reinterpret_cast<uint32_t*>(S.bmask);
+    constexpr int NN_LDS = MID_LDS_WORDS;
+    uint32_t* const R = reinterpret_cast<uint32_t*>(S.lab);
     const bool in_lds = nn <= NN_LDS && nn <= 65535;
     if (in_lds) {
         for (int i0 = tid; i0 < nn; i0 += 8 * T) {

@@ -75,6 +75,7 @@ def test_24_distinct_batches_through_a_depth_8_pipeline(oracle, one_dense, dense
     assert pl.get_info().submitted == nb
     # the dense frames get their own launch and stream from the second ring cycle on (the first cycle has nothing to go by), and only
     # where there are some
+    assert pl.get_info().host_blocking_calls == 0                      # ... nor when a slot's finishing stream changes (the dense frames' second launch comes and goes)
     split = pl.get_info().dense_split
     assert (split >= nb - 2 * 8) if (one_dense and dense_streams >= 0) else split == 0
     # calm batches (no frame beyond the LDS tables in what came back) take turns at four contexts and run the wave-specialised pixel
@@ -348,7 +349,7 @@ def test_calm_and_dense_batches_in_turn(oracle):
     assert abi.lib().rmcv_pixel_ws_launches() - ws0 == info.hot_batches
     # rmcv_pipeline_submit never blocks the host: no allocation, no synchronisation, no blocking copy -- not at the first batch, not when
     # the stream turns dense (the slots' finishing streams change), not when it turns calm again
-    assert info.host_blocking_calls == 0 and info.dense_split > 0
+    assert info.host_blocking_calls == 0
     pl.close()
 
 

@@ -50,7 +50,7 @@ int main(int argc, char** argv)
     int32_t* neg = malloc(4 * 2048);
     rmcv_armour* arms = malloc(sizeof(rmcv_armour) * 256);
     static double tot[300], ec[300], st[7][300];
-    static const char* st_name[7] = {"sync+bind+upload", "enqueue kernels", "wait pixel kernel", "image D2H call", "wait image", "wait kernels", "hand over"};
+    static const char* st_name[7] = {"sync+bind+upload", "enqueue kernels", "first image chunk", "image chunks", "runtime copy", "wait kernels", "hand over"};
     for (int mode = 0; mode <= 2; mode += 2) {
         rmcv_ctx_set_option(c, RMCV_OPT_FRAME_UPLOAD, mode);
         int32_t nc = 0, np = 0, nb = 0, nn = 0, na = 0;
