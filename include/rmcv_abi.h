@@ -198,6 +198,14 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * (every call first waits, with the same deadline, for what is in flight) or the context is destroyed; rmcv_ctx_destroy waits
  * once more and, if the work has still not finished, leaks the context's device memory instead of freeing it under a kernel. */
 #define RMCV_OPT_WAIT_TIMEOUT_MS 15
+/* RMCV_OPT_IMAGE_EXPORT: how rmcv_extract_color brings the byte image to `binary_out` -- 0 (default): the HIP runtime's pageable
+ * device-to-host copy, issued once the pixel kernel has finished (the library polls for that with the deadline first): fastest when all
+ * is well (0.186 ms per 1280x1024 chain from a C host), but the copy happens INSIDE the runtime's call and was measured at 160-280 us
+ * instead of 35 in some processes (bench.py's C-host child: the chain 0.28-0.40 ms); 1: a kernel on the library's side stream copies
+ * the image into pinned host memory chunk by chunk, raising a flag per chunk that the host polls in memory, and the library copies
+ * the chunks into `binary_out` as they arrive -- no runtime-internal wait anywhere in the chain: 0.192 ms alone, 0.21-0.22 ms as
+ * bench.py's child.  For hosts that share the GPU with other processes.  Same bytes. */
+#define RMCV_OPT_IMAGE_EXPORT 17
 /* RMCV_OPT_TEST_DELAY_US: the next rmcv_extract_color / rmcv_batch_run of the context first holds its stream back for this many
  * microseconds (one sleeping wavefront): a stand-in for a kernel that does not finish in time.  One shot.  A test hook
  * (tests/test_gpu_deadline.py). */

@@ -41,6 +41,7 @@ OPT_OVERLOADS = 13
 OPT_PIXEL_SHAPE = 14
 OPT_WAIT_TIMEOUT_MS = 15
 OPT_TEST_DELAY_US = 16
+OPT_IMAGE_EXPORT = 17
 STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE, STAGE_NO_IMAGE = 1, 2, 4, 8, 15, 16, 32, 64
 SVM_FEATURES = 1200
 FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_SLOW_PATH, FRAME_MID_PATH = 1, 2, 4, 8, 16, 64

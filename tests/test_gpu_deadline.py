@@ -9,7 +9,7 @@ import time
 import numpy as np
 import pytest
 
-from rmcv_amd import (CAMP_BLUE, OPT_TEST_DELAY_US, OPT_WAIT_TIMEOUT_MS, STAGE_ALL, Context, Pipeline, RmcvError, default_params, synth)
+from rmcv_amd import (CAMP_BLUE, OPT_IMAGE_EXPORT, OPT_TEST_DELAY_US, OPT_WAIT_TIMEOUT_MS, STAGE_ALL, Context, Pipeline, RmcvError, default_params, synth)
 from rmcv_amd import abi
 
 pytestmark = pytest.mark.gpu
@@ -21,8 +21,10 @@ def chain(ctx, img):
     return pts, offs, binary, blobs, ctx.filter_armours(blobs)
 
 
-def test_per_frame_call_gives_up_at_the_deadline_and_names_the_work(oracle):
+@pytest.mark.parametrize("image_export", [0, 1])
+def test_per_frame_call_gives_up_at_the_deadline_and_names_the_work(oracle, image_export):
     c = Context(device=0, max_frames=1, max_width=1280, max_height=1024)
+    c.set_option(OPT_IMAGE_EXPORT, image_export)
     img = synth.frame(3, 1280, 1024, CAMP_BLUE, 0)
     ref = oracle.detect_frame(img)
     pts, offs, binary, blobs, arm = chain(c, img)                     # an ordinary frame first

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import pytest
 
-from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, OPT_FRAME_UPLOAD, OPT_PIXEL_GROUPS, STAGE_ALL, STAGE_ARMOURS,
+from rmcv_amd import (CAMP_BLUE, CAMP_RED, MORPH_CLOSE, MORPH_DILATE, OPT_FRAME_UPLOAD, OPT_IMAGE_EXPORT, OPT_PIXEL_GROUPS, STAGE_ALL, STAGE_ARMOURS,
                       STAGE_BINARY, STAGE_BLOBS, STAGE_CONTOURS, STAGE_IDENTITY, Context, RmcvError, default_params, synth)
 
 pytestmark = pytest.mark.gpu
@@ -91,12 +91,13 @@ def check_chain(oracle, got, img, camp=CAMP_BLUE):
     return ref
 
 
-@pytest.mark.parametrize("upload", [1, 0, 2])
-def test_per_frame_chain_equals_oracle(oracle, upload):
+@pytest.mark.parametrize("upload,image_export", [(1, 0), (0, 0), (2, 0), (0, 1), (2, 1)])
+def test_per_frame_chain_equals_oracle(oracle, upload, image_export):
     """rm::extract_color -> rm::filter_lightblobs -> rm::filter_armours as executable/main.cpp:172-176 calls them, one host frame
     at a time: results stay on the device between the calls (resident hand-over); all three upload modes"""
     c = Context(device=0, max_frames=1, max_width=1920, max_height=1200)
     c.set_option(OPT_FRAME_UPLOAD, upload)
+    c.set_option(OPT_IMAGE_EXPORT, image_export)                # the byte image through the runtime's pageable copy / the library's export kernel
     total = 0
     buf = np.empty((1024, 1280, 3), np.uint8)                   # one reused host buffer, as a camera ring would be
     for idx in (0, 1, 2, 3, 1004, 1005):
