@@ -158,7 +158,7 @@ def dev_knobs(environ, dev):
     return found
 
 
-def c_host_chain(W, H, image_export=0):
+def c_host_chain(W, H, image_export=None):
     """tools/frame_chain.c compiled and run: the per-frame drop-in chain from a C host -> {mode: {median_ms, min_ms, p90_ms, extract_color_host_us}}"""
     try:
         import re
@@ -172,7 +172,7 @@ def c_host_chain(W, H, image_export=0):
         libdir = os.path.join(ROOT, "rmcv_amd", "lib")
         subprocess.run([cc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "frame_chain.c"), "-o", exe,
                         "-L", libdir, "-lrmcv_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, timeout=120)
-        cp = subprocess.run([exe, str(W), str(H)], capture_output=True, text=True, timeout=120, env=dict(os.environ, RMCV_IMAGE_EXPORT=str(image_export)))
+        cp = subprocess.run([exe, str(W), str(H)], capture_output=True, text=True, timeout=120, env=dict(os.environ, **({} if image_export is None else {"RMCV_IMAGE_EXPORT": str(image_export), "RMCV_FRAME_UPLOAD": "0" if image_export == 0 else "1"})))
         ch, last_ = {}, None
         for ln in cp.stdout.splitlines():
             w_ = ln.split()
@@ -894,7 +894,8 @@ def main():
         if c_host_first is not None:
             sf["c_host"] = c_host_first
         sf["c_host_beside_this_process"] = c_host_chain(W, H)
-        sf["c_host_beside_this_process_image_export"] = c_host_chain(W, H, 1)   # RMCV_OPT_IMAGE_EXPORT = 1: no runtime-internal wait in the chain
+        sf["c_host_beside_this_process_runtime_copies_only"] = c_host_chain(W, H, 0)  # RMCV_OPT_FRAME_UPLOAD 0 + RMCV_OPT_IMAGE_EXPORT 0: round 4's chain
+        sf["c_host_beside_this_process_own_paths_only"] = c_host_chain(W, H, 1)       # pinned staging + export kernel: nothing of the runtime's pageable copies
         out["single_frame_ms"] = sf
 
     if rank == 0 and world == 1 and args.cpu_frames > 0:

@@ -137,9 +137,12 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * 5 % slower, 4 within 3 %); 2: leaves wave slots and registers on every CU to the kernels of the other batches in flight
  * (two pixel launches of consecutive batches then overlap, i.e. 4 workgroups per CU are resident).  Results are identical. */
 #define RMCV_OPT_PIXEL_GROUPS 2
-/* RMCV_OPT_FRAME_UPLOAD: how rmcv_extract_color brings the caller's host frame to the device -- 0 (default): the HIP runtime's
- * pageable copy (measured fastest of the two safe ways: 0.37 ms per frame chain against 0.41); 1: through the context's
- * pinned staging buffer; 2: the caller's buffer is pinned in place on first sight (hipHostRegister, kept for the context's
+/* RMCV_OPT_FRAME_UPLOAD: how rmcv_extract_color brings the caller's host frame to the device -- 0: the HIP runtime's
+ * pageable copy (the fastest of the two safe ways when all is well: 0.186 ms per frame chain against 0.22); 1: through the context's
+ * pinned staging buffer (a CPU copy, then DMA: nothing of it depends on the runtime pinning the caller's pages); 3 (default): 0, and
+ * 1 WHILE 0 IS SLOW -- the library times the upload of every frame whose byte image it returns, moves to the staging buffer after three
+ * slow frames in a row (the runtime's pageable copies were measured 120-250 us slower each for tens of seconds after a large GPU
+ * process had exited: the chain 0.28-0.40 ms instead of 0.18), stays there for 512 frames and tries again; 2: the caller's buffer is pinned in place on first sight (hipHostRegister, kept for the context's
  * lifetime, at most 16 buffers) and read by DMA with no CPU copy (0.35 ms) -- for camera SDKs that hand out a fixed ring of
  * frame buffers (the reference's cameras do, hardware/src/daheng.cpp:83).  A pinning is keyed by ADDRESS (and size): the
  * buffers must stay mapped while the context lives, or be handed to rmcv_ctx_forget_frame_buffer BEFORE they are freed -- memory
@@ -198,14 +201,18 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * (every call first waits, with the same deadline, for what is in flight) or the context is destroyed; rmcv_ctx_destroy waits
  * once more and, if the work has still not finished, leaks the context's device memory instead of freeing it under a kernel. */
 #define RMCV_OPT_WAIT_TIMEOUT_MS 15
-/* RMCV_OPT_IMAGE_EXPORT: how rmcv_extract_color brings the byte image to `binary_out` -- 0 (default): the HIP runtime's pageable
+/* RMCV_OPT_IMAGE_EXPORT: how rmcv_extract_color brings the byte image to `binary_out` -- 0: the HIP runtime's pageable
  * device-to-host copy, issued once the pixel kernel has finished (the library polls for that with the deadline first): fastest when all
  * is well (0.186 ms per 1280x1024 chain from a C host), but the copy happens INSIDE the runtime's call and was measured at 160-280 us
  * instead of 35 in some processes (bench.py's C-host child: the chain 0.28-0.40 ms); 1: a kernel on the library's side stream copies
  * the image into pinned host memory chunk by chunk, raising a flag per chunk that the host polls in memory, and the library copies
- * the chunks into `binary_out` as they arrive -- no runtime-internal wait anywhere in the chain: 0.192 ms alone, 0.21-0.22 ms as
- * bench.py's child.  For hosts that share the GPU with other processes.  Same bytes. */
+ * the chunks into `binary_out` as they arrive -- no runtime-internal wait anywhere in the chain: 0.192 ms alone, 0.19-0.22 ms where
+ * the runtime's copy is slow; 2 (default): 0, and 1 while 0 is slow (three slow frames in a row -> 512 frames on the library's
+ * path, then another try; see RMCV_OPT_FRAME_UPLOAD).  Same bytes. */
 #define RMCV_OPT_IMAGE_EXPORT 17
+/* RMCV_OPT_TEST_SLOW_US: microseconds added to what the library MEASURES of the runtime's two copies (not to the copies): the switch of
+ * RMCV_OPT_FRAME_UPLOAD 3 / RMCV_OPT_IMAGE_EXPORT 2 on demand.  A test hook (tests/test_gpu_deadline.py). */
+#define RMCV_OPT_TEST_SLOW_US 18
 /* RMCV_OPT_TEST_DELAY_US: the next rmcv_extract_color / rmcv_batch_run of the context first holds its stream back for this many
  * microseconds (one sleeping wavefront): a stand-in for a kernel that does not finish in time.  One shot.  A test hook
  * (tests/test_gpu_deadline.py). */
@@ -220,8 +227,9 @@ int  rmcv_ctx_check_guards(rmcv_ctx* ctx, int32_t* n_damaged);
 /* where the last rmcv_extract_color spent its time on the HOST, seven figures in microseconds: us[0] waiting for earlier work, binding,
  * enqueuing the upload; us[1] enqueuing the kernels; us[2] until the byte image's first chunk is home (upload + pixel kernel + PCIe);
  * us[3] the other chunks, copied into binary_out as they arrive; us[4] (the runtime's copy where there is no mapped pinned memory);
- * us[5] waiting for the frame's kernels; us[6] handing the lists over.  cap >= 7.  A diagnosis hook (tools/frame_chain.c prints
- * the medians). */
+ * us[5] waiting for the frame's kernels; us[6] handing the lists over.  cap >= 7; with cap >= 9 also us[7] = the upload path the frame
+ * took (0 pageable, 1 pinned staging, 2 registered) and us[8] = the image path (0 the runtime's copy, 1 the export kernel).  A diagnosis
+ * hook (tools/frame_chain.c prints the medians). */
 int  rmcv_ctx_frame_timing(const rmcv_ctx* ctx, double* us, int cap);
 /* drop the pinning RMCV_OPT_FRAME_UPLOAD = 2 made for `frame` (NULL: all of them); drains the context's stream first */
 int  rmcv_ctx_forget_frame_buffer(rmcv_ctx* ctx, const void* frame);
@@ -473,7 +481,8 @@ typedef struct {
     int32_t hw_queues_env;     /* what GPU_MAX_HW_QUEUES reads in this process (0: unset) */
     int32_t hw_queues_wanted;  /* 1 + pixel_streams + sparse_streams + dense_streams (+ 1 with a communicator) */
     int32_t _pad;
-    int64_t record_bytes;      /* a batch's record in HBM: [frame_offs: max_frames + 1 int32 | status: int32 | dense frames: int32 | pad to 16 B | armours: armour_cap x 88 B] */
+    int64_t record_bytes;      /* a batch's record in HBM: [frame_offs: max_frames + 1 int32 | status: int32 | load: int32 = frames beyond the LDS tables
+                                * (bits 0-19) + border points per frame / 16 (bits 20-31) | pad to 16 B | armours: armour_cap x 88 B] */
     int64_t armours_offset;    /* = the layout of rmcv_amd/dist.py, the payload of rmcv_gather */
     uint64_t submitted, collected;
     uint64_t dense_split;      /* batches whose dense frames were given a launch and a stream of their own (see dense_streams) */
@@ -485,6 +494,9 @@ typedef struct {
                                 * pipeline was created: 0 (tests/test_gpu_pipeline.py asserts it over plain, dense and re-shaped streams) */
     int32_t wait_timeout_ms, _pad3; /* rmcv_pipeline_set_wait_timeout */
     double   max_submit_us;    /* host time of the longest single rmcv_pipeline_submit since creation / rmcv_pipeline_reset_stats, microseconds */
+    uint64_t heavy_batches;    /* batches run in DENSE MODE: while the records that come back are heavy (more than an eighth of the frames beyond
+                                * findContours' LDS tables, or >= 1 500 border points per frame; back below 1 200) the sparse stage runs its lean build
+                                * (every frame on the mid tier, two workgroups per CU) beside one pixel workgroup per CU and launch */
     uint64_t held_back;        /* pixel launches held back behind a burst's first one (k_delay): only launches of the wave-specialised
                                 * kernel on every CU, for a quarter of their expected time, 60 us at most, none below 100 us of launch */
 } rmcv_pipeline_info;

@@ -42,6 +42,7 @@ OPT_PIXEL_SHAPE = 14
 OPT_WAIT_TIMEOUT_MS = 15
 OPT_TEST_DELAY_US = 16
 OPT_IMAGE_EXPORT = 17
+OPT_TEST_SLOW_US = 18
 STAGE_BINARY, STAGE_CONTOURS, STAGE_BLOBS, STAGE_ARMOURS, STAGE_ALL, STAGE_IDENTITY, STAGE_POSE, STAGE_NO_IMAGE = 1, 2, 4, 8, 15, 16, 32, 64
 SVM_FEATURES = 1200
 FRAME_OVF_CONTOURS, FRAME_OVF_POINTS, FRAME_OVF_BLOBS, FRAME_OVF_ARMOURS, FRAME_SLOW_PATH, FRAME_MID_PATH = 1, 2, 4, 8, 16, 64
@@ -102,7 +103,7 @@ class PipelineInfo(C.Structure):
                 ("max_frames", C.c_int32), ("hw_queues_env", C.c_int32), ("hw_queues_wanted", C.c_int32), ("_pad", C.c_int32),
                 ("record_bytes", C.c_int64), ("armours_offset", C.c_int64), ("submitted", C.c_uint64), ("collected", C.c_uint64),
                 ("dense_split", C.c_uint64), ("hot_batches", C.c_uint64), ("hot_contexts", C.c_int32), ("_pad2", C.c_int32), ("latency_batches", C.c_uint64),
-                ("host_blocking_calls", C.c_uint64), ("wait_timeout_ms", C.c_int32), ("_pad3", C.c_int32), ("max_submit_us", C.c_double), ("held_back", C.c_uint64)]
+                ("host_blocking_calls", C.c_uint64), ("wait_timeout_ms", C.c_int32), ("_pad3", C.c_int32), ("max_submit_us", C.c_double), ("heavy_batches", C.c_uint64), ("held_back", C.c_uint64)]
 
 
 # rmcv_pipeline_hook: int (*)(void* user, uint64_t ticket, void* d_record, int64_t record_bytes, void* hip_stream, void** done_event)

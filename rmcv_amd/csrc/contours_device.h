@@ -220,7 +220,12 @@ struct LabelStore {
 // LDS budget: the workgroup shares its CU with the pixel kernels of the next two batches (2 x 2 x 11.5 KB) and with other
 // frames' workgroups, so the tables are sized for ~50 KB (3 per CU); measured +4-8 % on the 3-stream bench against 75 KB.
 // Frames beyond a capacity take the literal path (tests/test_gpu_parity.py covers each limit).
-static constexpr int KEPT_CAP = 512;
+// (The capacities are per translation unit: k_contours_lean.hip compiles the same kernel body with tiny LDS-tier tables for frames that
+// take the mid tier anyway -- everything that depends on them has internal linkage or is device code.)
+#ifndef RMCV_KEPT_CAP
+#define RMCV_KEPT_CAP 512
+#endif
+static constexpr int KEPT_CAP = RMCV_KEPT_CAP;
 // Non-empty words of a frame the LDS label store can hold.  Round 5: 1664 instead of 1024 at the SAME struct size -- the per-word border
 // masks (bmask / e2mask: written in N1, last read in N3) and the label planes (lab / neg: first written in N7) never live at the same
 // time and share their storage, 20 bytes per word instead of 36.  A scene of 400 specks and a few lit windows (the synthetic stream's
@@ -236,7 +241,14 @@ static constexpr int SLOT_CAP = RMCV_SLOT_CAP;
 // when several batches are in flight (886 k against 800 k frames/s with three batches; 0.57 against 0.475 ms for a lone batch).
 static constexpr int CT_THREADS_MAX = 512;
 static constexpr int MULTI_CAP = 32;    // pixels of a frame visited 3 or 4 times (junctions of 1-pixel lines) the cycle formulation lists
-static constexpr int NN_CAP = VISIT_CAP;    // border visits (nodes) of a frame the cycle formulation holds in LDS
+#ifndef RMCV_NN_CAP
+#define RMCV_NN_CAP VISIT_CAP
+#endif
+static constexpr int NN_CAP = RMCV_NN_CAP;  // border visits (nodes) of a frame the cycle formulation holds in LDS
+static_assert(NN_CAP <= VISIT_CAP, "the visits' global scratch (Bufs::visit_xy) is VISIT_CAP entries per frame");
+#ifndef RMCV_MID_PAD
+#define RMCV_MID_PAD 0
+#endif
 #ifndef RMCV_CT_MAXH
 #define RMCV_CT_MAXH 2048
 #endif
@@ -256,6 +268,9 @@ struct ContoursLds {
     int32_t koff[KEPT_CAP], klen[KEPT_CAP];
     uint8_t kacc[KEPT_CAP];    // cycles_frame: outer border e is (still) accepted by the RETR_EXTERNAL rule
     uint32_t multi[MULTI_CAP]; // cycles_frame: pixels the border visits 3 or 4 times: slot:16 | bit:6 << 16 | count << 24
+#if RMCV_MID_PAD > 0
+    unsigned long long mid_pad[RMCV_MID_PAD / 8]; // (lean build: the mid tier's pointer doubling and staging want this much in front of `scan`)
+#endif
     // ---- shared by the tiers
     int scan[CT_THREADS_MAX];
     uint32_t ringtab[256];
@@ -268,7 +283,7 @@ struct ContoursLds {
     int wnext;    // fused tail: next entry of the sorted work list
     int sink[64]; // per-lane sinks: lanes != 0 add 0 here so that a wave-wide atomic stays convergent and does not serialise on one word
 };
-static_assert(offsetof(ContoursLds, kkey) >= (CT_THREADS_MAX / 64) * 3840, "the fused tail's wave-private rows (sizeof(WaveLds) = 3840 each) overlay dead tables only");
+static_assert(offsetof(ContoursLds, scan) >= (CT_THREADS_MAX / 64) * 3840, "the fused tail's wave-private rows (sizeof(WaveLds) = 3840 each) overlay dead tables only");
 static_assert(offsetof(ContoursLds, scan) % 8 == 0 && offsetof(ContoursLds, w_off) % 8 == 0, "alignment");
 // words of LDS the mid tier may use for its pointer doubling: the LDS tier's own tables in front of `scan`
 static constexpr int MID_LDS_WORDS = (int)(offsetof(ContoursLds, scan) / 4);
@@ -634,12 +649,14 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, 
     while ((1 << rounds) < nn) rounds++;
     for (int i = tid; i < nn; i += T) Rw[i] = ((uint32_t)i << 16) | nxt[i];
     __syncthreads();
-    for (int rd = 0; rd < rounds; rd++) {
+    for (int rd = 0; rd < rounds; rd++) { // (u * T < nn: wave-uniform -- a frame of 400 visits touches 2 of the 16 words a thread could own)
         uint32_t w[NPT], wt[NPT];
 #pragma unroll
-        for (int u = 0; u < NPT; u++) w[u] = tid + u * T < nn ? Rw[tid + u * T] : 0u;
+        for (int u = 0; u < NPT; u++)
+            if (u * T < nn) w[u] = tid + u * T < nn ? Rw[tid + u * T] : 0u;
 #pragma unroll
-        for (int u = 0; u < NPT; u++) wt[u] = Rw[w[u] & 0xFFFFu];
+        for (int u = 0; u < NPT; u++)
+            if (u * T < nn) wt[u] = Rw[w[u] & 0xFFFFu];
 #pragma unroll
         for (int u = 0; u < NPT; u++)
             if (tid + u * T < nn) Rw[tid + u * T] = (((w[u] >> 16) < (wt[u] >> 16) ? (w[u] >> 16) : (wt[u] >> 16)) << 16) | (wt[u] & 0xFFFFu);
@@ -668,9 +685,11 @@ __device__ __forceinline__ void cycles_frame(ContoursLds& S, const RowTabs& RT, 
     for (int rd = 0; rd < rounds; rd++) {
         uint32_t w[NPT], wt[NPT];
 #pragma unroll
-        for (int u = 0; u < NPT; u++) w[u] = tid + u * T < nn ? Rw[tid + u * T] : 0u;
+        for (int u = 0; u < NPT; u++)
+            if (u * T < nn) w[u] = tid + u * T < nn ? Rw[tid + u * T] : 0u;
 #pragma unroll
-        for (int u = 0; u < NPT; u++) wt[u] = Rw[w[u] & 0xFFFFu];
+        for (int u = 0; u < NPT; u++)
+            if (u * T < nn) wt[u] = Rw[w[u] & 0xFFFFu];
 #pragma unroll
         for (int u = 0; u < NPT; u++)
             if (tid + u * T < nn) Rw[tid + u * T] = (((w[u] >> 16) + (wt[u] >> 16)) << 16) | (wt[u] & 0xFFFFu);

@@ -1,0 +1,48 @@
+// k_contours_lean.hip -- the per-frame sparse kernel (k_contours_kernel.inc) for DENSE streams: 4 wavefronts per frame, every frame on the
+// mid tier of findContours (tables in global memory), and an LDS footprint of 61 KB instead of 80 -- TWO workgroups per CU.
+//
+// Why (round 5).  cv::findContours has no bound (/root/reference/src/imgproc.cpp:71-72), and a scene of hundreds of specks or lit windows
+// costs a frame 0.2-0.6 ms of sparse work on one workgroup where a plain frame costs 0.1.  Beside the pixel kernels only ONE workgroup of
+// the standard build fits a CU (80 KB of LDS, 157 VGPRs beside four pixel workgroups): a batch of 256 such frames is 256 x 0.2-0.6 ms
+// over 256 workgroup slots -- the stream becomes sparse-bound (dense4: 0.53 ms per step against the pixel kernel's 0.23).  A frame that
+// takes the mid tier needs none of the LDS tier's tables (label planes, node tables for 4 096 visits, per-word tables for 1 664 words):
+// compiled with those at token size the same kernel body needs the row tables, 36 KB for the mid tier's pointer doubling and staging
+// (which the fused tail's wave-private rows overlay afterwards) and a work list.  The pipeline switches a stream to this kernel, with
+// ONE pixel workgroup per CU and launch (two resident: 158 VGPRs, 28 KB), while the records that come back say the batches are heavy
+// (rmcv_pipeline.hip: dense mode).  Same results: the mid tier is the same formulation as the LDS tier, bit for bit (tests/test_gpu_dense.py).
+#define RMCV_SLOT_CAP 64
+#define RMCV_KEPT_CAP 64
+#define RMCV_NN_CAP 2048
+#define RMCV_MID_PAD 34816
+#include "contours_device.h"
+
+#include <algorithm>
+
+namespace rmcv {
+
+#define KC_KERNEL k_contours_lean
+#define KC_THREADS 256
+#define KC_NO_CLASSIFY
+#include "k_contours_kernel.inc"
+#undef KC_NO_CLASSIFY
+#undef KC_KERNEL
+#undef KC_THREADS
+
+static_assert(sizeof(ContoursLds) <= 54 * 1024, "two of these workgroups and two pixel workgroups share a CU's 160 KB");
+
+// every frame on the mid tier (`flags`: 2, + 8 = only the frames the first launch marked as deferred)
+hipError_t launch_contours_lean(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int flags, const SparseSched& Q, int grid, hipStream_t s)
+{
+    static bool attr_set[MAX_DEVICES] = {}; // hipFuncSetAttribute applies to the current device only (a process may drive several)
+    if (!attr_set[g.device]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(CT_MAXH));
+        if (e != hipSuccess) return e;
+        attr_set[g.device] = true;
+    }
+    return launch(k_contours_lean, dim3(grid), dim3(256), lds_bytes(g.h), s, b.bits, b.rowmask, g.h, b.lab, b.neg, g.w,
+                  g.h, g.ww, g.prow, g.plane_pitch, b.points, b.cont_start, b.cont_len, b.n_contours, b.n_points, b.status,
+                  lim.max_contours, lim.max_points, flags, b.elig, b.n_elig, b.slot_kind, X, b.visit_xy, b.mid, b.mid_stride,
+                  b.mid_slot_cap, Q, lds_rows_cap(g.h));
+}
+
+} // namespace rmcv

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
                                                         const int32_t* __restrict__ n_armours, int n_frames, int max_armours,
                                                         rmcv_armour* __restrict__ out, int cap, int32_t* __restrict__ frame_offs,
                                                         const int32_t* __restrict__ status, int32_t* __restrict__ status_or,
-                                                        uint8_t* __restrict__ host_rec, int host_head)
+                                                        uint8_t* __restrict__ host_rec, int host_head, const int32_t* __restrict__ n_points)
 {
     // host_rec (nullable): the same record a second time, in pinned host memory mapped into the device's address space -- the
     // kernel's own stores cross PCIe as posted writes, and only the armours there are travel (a copy of the whole record behind the
@@ -196,17 +196,23 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
     rmcv_armour* const h_out = reinterpret_cast<rmcv_armour*>(host_rec + host_head);
     __shared__ int s_part[256];
     __shared__ int s_base, s_st, s_mid;
+    __shared__ unsigned long long s_pts;
     __shared__ int s_off[COMPACT_FRAMES], s_cnt[COMPACT_FRAMES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f_begin = blockIdx.x * COMPACT_FRAMES; // this workgroup's frames
-    if (tid == 0) { s_base = 0; s_st = 0; s_mid = 0; }
+    if (tid == 0) { s_base = 0; s_st = 0; s_mid = 0; s_pts = 0; }
     __syncthreads();
     for (int f0 = 0; f0 < n_frames; f0 += 256) {
         const int f = f0 + tid;
         const int c = f < n_frames ? n_armours[f] : 0;
         // the batch's status bits OR-ed into one word (rmcv_pipeline_collect reads it with the list instead of n_frames words)
         // ... and the number of frames that were beyond findContours' LDS tables (the pipeline's schedule follows it)
-        if (status_or && blockIdx.x == 0 && f < n_frames) { const int st = status[f]; if (st) { atomicOr(&s_st, st); if (st & RMCV_FRAME_MID_PATH) atomicAdd(&s_mid, 1); } }
+        // ... and how heavy the batch's sparse work was: border points per frame (the pipeline's dense mode follows it)
+        if (status_or && blockIdx.x == 0 && f < n_frames) {
+            const int st = status[f];
+            if (st) { atomicOr(&s_st, st); if (st & RMCV_FRAME_MID_PATH) atomicAdd(&s_mid, 1); }
+            atomicAdd(&s_pts, (unsigned long long)(n_points[f] > 0 ? n_points[f] : 0));
+        }
         s_part[tid] = c;
         __syncthreads();
         for (int d = 1; d < 256; d <<= 1) { // inclusive Hillis-Steele scan
@@ -228,11 +234,14 @@ __global__ __launch_bounds__(256) void k_compact_armours(const rmcv_armour* __re
     }
     if (tid == 0 && blockIdx.x == 0) {
         frame_offs[n_frames] = s_base;
-        if (status_or) { status_or[0] = s_st; status_or[1] = s_mid; }
+        // the record's second word: frames beyond the LDS tables (bits 0-19) | border points per frame / 16, capped (bits 20-31)
+        const unsigned long long per16 = n_frames > 0 ? s_pts / (unsigned long long)n_frames / 16ull : 0ull;
+        const int word2 = (s_mid & 0xFFFFF) | (int)((per16 > 4095ull ? 4095ull : per16) << 20);
+        if (status_or) { status_or[0] = s_st; status_or[1] = word2; }
         if (host_rec) {
             h_offs[n_frames] = s_base;
             h_offs[status_or - frame_offs] = s_st; // (the status word's place in the record)
-            h_offs[status_or - frame_offs + 1] = s_mid;
+            h_offs[status_or - frame_offs + 1] = word2;
         }
     }
     constexpr int DW = (int)(sizeof(rmcv_armour) / 4);
@@ -266,7 +275,7 @@ hipError_t launch_compact_armours(const Geom& g, const Bufs& b, const Limits& li
 {
     if (hd_record && !d_status_or) return hipErrorInvalidValue; // (the host mirror has the record's layout, status word included)
     return launch(k_compact_armours, dim3(std::max(1, (g.n_frames + COMPACT_FRAMES - 1) / COMPACT_FRAMES)), dim3(256), 0, s, b.armours, b.n_armours, g.n_frames, lim.max_armours, d_out,
-                       cap, d_frame_offs, b.status, d_status_or, hd_record, host_head);
+                       cap, d_frame_offs, b.status, d_status_or, hd_record, host_head, b.n_points);
 }
 
 static hipError_t launch_pairs_tail(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, bool pairs, hipStream_t s)

@@ -37,7 +37,7 @@ struct rmcv_ctx {
     bool external_order = false;  // a pipeline owns the ordering of this context's launches (rmcv_internal.h: ctx_external_order)
     hipEvent_t ext_done = nullptr; // ... and records this event behind the last of them
     // ---- per-frame drop-in path (rmcv_extract_color -> rmcv_filter_lightblobs -> rmcv_filter_armours, executable/main.cpp:172-176)
-    int frame_upload = 0;          // RMCV_OPT_FRAME_UPLOAD
+    int frame_upload = 3;          // RMCV_OPT_FRAME_UPLOAD (3: the runtime's pageable copy, the pinned staging buffer while that is slow)
     int run_ahead = 1;             // RMCV_OPT_RUN_AHEAD
     struct Reg { const void* p; size_t bytes; };
     std::vector<Reg> registered;   // caller buffers pinned by hipHostRegister (RMCV_OPT_FRAME_UPLOAD = 2)
@@ -83,7 +83,16 @@ struct rmcv_ctx {
     size_t h_image_bytes = 0;
     uint32_t *h_iflags = nullptr, *hd_iflags = nullptr; // [IMG_CHUNKS] a chunk's flag = the sequence number of the frame whose bytes it holds
     uint32_t img_seq = 0;
-    int image_export = 0;         // RMCV_OPT_IMAGE_EXPORT
+    int image_export = 2;         // RMCV_OPT_IMAGE_EXPORT (2: the runtime's pageable copy, the library's export while that is slow)
+    // The runtime's pageable copies pin and unpin the caller's pages on every call; in some conditions (measured: for tens of seconds
+    // after a large GPU process has exited -- the driver's test suite in front of bench.py, every round) each such copy costs 120-250 us
+    // more, and the per-frame chain reads 0.28 ms (one of them slow) or 0.40 (both) instead of 0.18.  The library measures both copies on
+    // every frame and moves to its own paths -- pinned staging up, export kernel down -- after three slow frames in a row, for 512 frames,
+    // then tries the runtime's again.
+    int upload_now = 0, image_now = 0;   // the paths the last frame took (upload: 0 pageable / 1 pinned staging / 2 registered; image: 0 runtime / 1 export)
+    int slow_upload = 0, slow_image = 0; // consecutive slow frames on the runtime's path
+    int hold_upload = 0, hold_image = 0; // frames left on the library's own path
+    int test_slow_us = 0;                // RMCV_OPT_TEST_SLOW_US: added to what the library measures of the runtime's copies (tests of the switch)
     uint32_t* d_iarrived = nullptr; // [IMG_CHUNKS] device: workgroups of k_image_export that have stored their slice of a chunk
     double marks[9] = {};         // rmcv_ctx_frame_timing: host clock at the steps of the last rmcv_extract_color (microseconds)
     uint64_t blocking_calls = 0;  // allocations, host-side synchronisations and blocking copies made while binding a geometry (ctx_blocking_calls)
@@ -314,7 +323,8 @@ int rmcv_ctx_create(int device, const rmcv_limits* limits, rmcv_ctx** out)
         c->geom.device = device;
         c->geom.pixel_halo_nt = getenv("RMCV_K1_HALO_NT") ? atoi(getenv("RMCV_K1_HALO_NT")) : 0;
         c->geom.pixel_rowquad = getenv("RMCV_K1_LINEAR") && atoi(getenv("RMCV_K1_LINEAR")) == 0;
-        c->image_export = getenv("RMCV_IMAGE_EXPORT") ? atoi(getenv("RMCV_IMAGE_EXPORT")) != 0 : 0; // (the option's default, for hosts that cannot call it: tools/frame_chain.c)
+        if (getenv("RMCV_IMAGE_EXPORT")) c->image_export = atoi(getenv("RMCV_IMAGE_EXPORT")); // (the options' defaults for hosts that cannot call them: tools/frame_chain.c)
+        if (getenv("RMCV_FRAME_UPLOAD")) c->frame_upload = atoi(getenv("RMCV_FRAME_UPLOAD"));
         c->geom.pixel_ws = 1; // RMCV_OPT_PIXEL_SHAPE: whole batches with contiguous rows -> k_binary_ws
         c->geom.dense_defer = getenv("RMCV_DENSE_DEFER") ? atoi(getenv("RMCV_DENSE_DEFER")) : 0; // RMCV_OPT_DENSE_DEFER (env: dev A/B knob)
         c->geom.n_cu = (device < MAX_DEVICES && hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
@@ -390,6 +400,7 @@ uint64_t ctx_blocking_calls(const rmcv_ctx* c) { return c->blocking_calls; }
 int ctx_wait_timeout_ms(const rmcv_ctx* c) { return c->wait_timeout_ms; }
 bool pixel_ws_full(const rmcv_ctx* c, int lower_bound) { return binary_ws_full(c->geom, c->bufs, lower_bound); }
 void ctx_defer_phase(rmcv_ctx* c, int phase) { c->geom.dense_defer = phase; }
+void ctx_sparse_lean(rmcv_ctx* c, int on) { c->geom.sparse_lean = on ? 1 : 0; }
 int ctx_compact(rmcv_ctx* c, void* d_armours_out, int cap, void* d_frame_offs, void* d_status_or, hipStream_t s, void* hd_record, int host_head)
 {
     HIPCHK(c, launch_compact_armours(c->geom, c->bufs, c->lim, (rmcv_armour*)d_armours_out, cap, (int32_t*)d_frame_offs, s, (int32_t*)d_status_or, (uint8_t*)hd_record, host_head), "k_compact_armours");
@@ -820,8 +831,13 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         c->run_ahead = value;
         return RMCV_OK;
     }
-    if (option == RMCV_OPT_FRAME_UPLOAD && value >= 0 && value <= 2) {
+    if (option == RMCV_OPT_FRAME_UPLOAD && value >= 0 && value <= 3) {
         c->frame_upload = value;
+        c->slow_upload = c->hold_upload = 0;
+        return RMCV_OK;
+    }
+    if (option == RMCV_OPT_TEST_SLOW_US && value >= 0) {
+        c->test_slow_us = value;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_PIXEL_HALO_NT && (value == 0 || value == 1)) {
@@ -849,8 +865,9 @@ int rmcv_ctx_set_option(rmcv_ctx* c, int option, int value)
         c->geom.contour_tier = value;
         return RMCV_OK;
     }
-    if (option == RMCV_OPT_IMAGE_EXPORT && (value == 0 || value == 1)) {
+    if (option == RMCV_OPT_IMAGE_EXPORT && value >= 0 && value <= 2) {
         c->image_export = value;
+        c->slow_image = c->hold_image = 0;
         return RMCV_OK;
     }
     if (option == RMCV_OPT_WAIT_TIMEOUT_MS && value >= 0) {
@@ -872,6 +889,7 @@ int rmcv_ctx_frame_timing(const rmcv_ctx* c, double* us, int cap)
 {
     if (!c || !us || cap < 7) return RMCV_ERR_BAD_ARG;
     for (int i = 0; i < 7; i++) us[i] = c->marks[i + 1] - c->marks[i];
+    if (cap >= 9) { us[7] = c->upload_now; us[8] = c->image_now; }
     return RMCV_OK;
 }
 
@@ -1165,7 +1183,9 @@ static int upload_one(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride,
 {
     const size_t dpitch = (size_t)dstride * h;
     hipStream_t s = c->stream;
-    if (c->frame_upload == 2) { // pin the caller's buffer once (camera SDKs hand out a small ring of frame buffers) and DMA from it
+    const int mode = c->frame_upload == 3 ? (c->hold_upload > 0 ? 1 : 0) : c->frame_upload;
+    c->upload_now = mode;
+    if (mode == 2) { // pin the caller's buffer once (camera SDKs hand out a small ring of frame buffers) and DMA from it
         const size_t span = (size_t)stride * (h - 1) + (size_t)3 * w;
         bool known = false;
         for (auto& r : c->registered) known |= (r.p == bgr && r.bytes >= span);
@@ -1184,7 +1204,7 @@ static int upload_one(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride,
         HIPCHK(c, hipMemcpy2DAsync(c->own_frames, dstride, bgr, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, s), "H2D frame");
         return RMCV_OK;
     }
-    if (c->frame_upload == 0) { // the runtime's own pageable path
+    if (mode == 0) { // the runtime's own pageable path
         HIPCHK(c, hipMemcpy2DAsync(c->own_frames, dstride, bgr, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, s), "H2D frame");
         return RMCV_OK;
     }
@@ -1303,7 +1323,7 @@ static int finish_armours(rmcv_ctx* c, rmcv_armour* armours_out, int armours_cap
 // the pinned, device-mapped landing buffer of the byte image + its chunk flags (lazy; false: not to be had -> the runtime's copy)
 static bool image_ready(rmcv_ctx* c, size_t bytes)
 {
-    if (!c->image_export) return false; // RMCV_OPT_IMAGE_EXPORT (default 0: the runtime's pageable copy)
+    if (!(c->image_export == 1 || (c->image_export == 2 && c->hold_image > 0))) return false; // RMCV_OPT_IMAGE_EXPORT
     if (!c->h_iflags) {
         if (hipHostMalloc((void**)&c->h_iflags, IMG_CHUNKS * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void**)&c->hd_iflags, c->h_iflags, 0) != hipSuccess) {
@@ -1479,7 +1499,9 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
             if (hi > lo) memcpy(binary_out + lo, c->h_image + lo, (size_t)(hi - lo));
         }
         c->marks[4] = now_us(); // the byte image is in the caller's buffer
-    } else if (binary_out) { // (no mapped pinned memory to be had: the runtime's pageable copy)
+        c->image_now = 1;
+    } else if (binary_out) {
+        c->image_now = 0; // (no mapped pinned memory to be had: the runtime's pageable copy)
         c->last_what = "k_binary";
         WAITCHK(c, wait_event(c, c->ev_fork, "rmcv_extract_color: waiting for the pixel kernel"));
         c->marks[3] = now_us();
@@ -1505,6 +1527,18 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
     if (offs_out) memcpy(offs_out, c->h_offs, (size_t)(nc + 1) * 4);
     if (pts_out && total) memcpy(pts_out, c->h_pts, (size_t)total * sizeof(rmcv_point));
     c->marks[7] = now_us();
+    if (binary_out) { // what the runtime's copies cost this frame (see rmcv_ctx::image_export)
+        const double up_us = c->marks[3] - c->marks[1] + c->test_slow_us, img_us = c->marks[4] - c->marks[3] + c->test_slow_us;
+        const double frame_bytes = 3.0 * w * h, image_bytes = (double)w * h;
+        if (c->upload_now == 0) {
+            c->slow_upload = up_us > frame_bytes / 45e3 + 100.0 ? c->slow_upload + 1 : 0; // (45 GB/s + the pixel kernel + the waits' slack)
+            if (c->frame_upload == 3 && c->slow_upload >= 3) { c->hold_upload = 512; c->slow_upload = 0; }
+        } else if (c->hold_upload > 0) c->hold_upload--;
+        if (c->image_now == 0) {
+            c->slow_image = img_us > image_bytes / 40e3 + 60.0 ? c->slow_image + 1 : 0;
+            if (c->image_export == 2 && c->slow_image >= 3) { c->hold_image = 512; c->slow_image = 0; }
+        } else if (c->hold_image > 0) c->hold_image--;
+    }
     return RMCV_OK;
 }
 

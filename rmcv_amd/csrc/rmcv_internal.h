@@ -23,6 +23,7 @@ struct Geom {
     int pixel_ws;        // RMCV_OPT_PIXEL_SHAPE: whole batches with contiguous rows go to k_binary_ws (one 1024-thread workgroup per CU)
     int dense_defer;     // RMCV_OPT_DENSE_DEFER: frames beyond the LDS tables are left to a second launch with 8 wavefronts per frame
     int overloads;       // RMCV_OPT_OVERLOADS: SURVEY A.6, which functions the reference's unqualified abs / atan2 / sin / cos on floats are
+    int sparse_lean;     // a pipeline's dense mode: the batch's sparse stage runs the lean build (k_contours_lean.hip), every frame on the mid tier
     int contour_tier;    // RMCV_OPT_CONTOUR_TIER: 0 = per frame (LDS tables, else mid tier, else literal scanner), 1 = literal, 2 = mid tier
     int n_frames;
     int w, h;
@@ -200,5 +201,7 @@ hipError_t launch_delay(unsigned long long ns, hipStream_t s); // holds `s` back
 int ctx_check_stages(rmcv_ctx* c, const rmcv_params* p, int stages);
 // Geom::dense_defer for the runs that follow: 0 off, 1 both launches on the run's stream (RMCV_OPT_DENSE_DEFER), 2 / 3 the first / second only
 void ctx_defer_phase(rmcv_ctx* c, int phase);
+// Geom::sparse_lean for the runs that follow
+void ctx_sparse_lean(rmcv_ctx* c, int on);
 
 } // namespace rmcv

@@ -68,7 +68,7 @@ struct rmcv_pipeline {
         rmcv_ctx* c = nullptr;
         rmcv_params p{};
         rmcv_legacy_params lp{};
-        bool has_lp = false, used = false;
+        bool has_lp = false, used = false, heavy = false;
         int sparse = 0, n_frames = 0;
         hipStream_t B = nullptr;
     } pend;
@@ -77,6 +77,14 @@ struct rmcv_pipeline {
     bool chain_cold = true, was_cold = false; // (dev knob RMCV_CHAIN_COLD=0)
     int chain_cold_us = 60;             // (dev knob RMCV_CHAIN_COLD=n > 1: the delay in microseconds; 1: wait for the first launch's end instead)
     bool early_free = true;             // (dev knob RMCV_EARLY_FREE=0: a context's next batch waits for the whole list, as ev_done)
+    // DENSE MODE (round 5).  While the records that come back say the batches are heavy -- more than an eighth of the frames beyond
+    // findContours' LDS tables, or 1 500 border points per frame and more (a plain frame has 650) -- the stream is bound by its sparse
+    // stage, not by the pixel kernel: one workgroup of the standard sparse kernel per CU, 0.2-0.6 ms per frame.  Such batches run the LEAN
+    // build of the sparse kernel (k_contours_lean.hip: every frame on the mid tier, 61 KB of LDS) TWO workgroups per CU, beside ONE pixel
+    // workgroup per CU and launch instead of two.  The way back: fewer than 1 200 points per frame (in this mode every frame reports the
+    // mid tier, so only the points say what the stream is like).
+    bool heavy = false;
+    uint64_t heavy_batches = 0;
     bool split_now = false;            // the batches of the moment have a FEW dense frames: give those a launch and a stream of their own
     uint64_t split_batches = 0;        // batches submitted that way
     rmcv_pipeline_hook hook = nullptr;
@@ -380,6 +388,7 @@ int rmcv_pipeline_get_info(const rmcv_pipeline* pl, rmcv_pipeline_info* o)
     o->max_submit_us = pl->max_submit_us;
     o->wait_timeout_ms = pl->wait_timeout_ms;
     o->held_back = pl->held_back;
+    o->heavy_batches = pl->heavy_batches;
     return RMCV_OK;
 }
 
@@ -488,7 +497,8 @@ static int finish_back(rmcv_pipeline* pl, bool latency)
     const int sparse = pl->pend.sparse, n_frames = pl->pend.n_frames;
     hipStream_t B = pl->pend.B;
     int rc = RMCV_OK;
-    const bool w8 = latency && pl->cfg.sparse_waves == 4 && !lp;
+    const bool heavy = pl->pend.heavy;
+    const bool w8 = latency && pl->cfg.sparse_waves == 4 && !lp && !heavy;
     if (w8) {
         rmcv_ctx_set_option(c, RMCV_OPT_SPARSE_WAVES, 8);
         pl->latency_batches++;
@@ -502,11 +512,11 @@ static int finish_back(rmcv_pipeline* pl, bool latency)
     // 1-3 %: 256 workgroups of 8 wavefronts and 80 KB of LDS to be placed just to find their frame is not marked); a batch full of
     // them is better off with every frame finished where it is (measured: 0.312 against 0.360 ms per step at 233 dense frames of 256).
     if (used && !pl->dn.empty() && hipEventQuery(pl->ev_done[k]) == hipSuccess) {
-        const int32_t dense = reinterpret_cast<const int32_t*>(pl->h_rec[k])[pl->lim.max_frames + 2];
+        const int32_t dense = reinterpret_cast<const int32_t*>(pl->h_rec[k])[pl->lim.max_frames + 2] & 0xFFFFF;
         pl->split_now = dense > 0 && dense * 8 <= pl->slot_frames[k];
     }
     (void)hipGetLastError(); // (hipErrorNotReady is not an error)
-    const bool split = !w8 && pl->split_now && !pl->dn.empty() && !lp && (sparse & RMCV_STAGE_CONTOURS) && (sparse & RMCV_STAGE_BLOBS);
+    const bool split = !w8 && !heavy && pl->split_now && !pl->dn.empty() && !lp && (sparse & RMCV_STAGE_CONTOURS) && (sparse & RMCV_STAGE_BLOBS);
     if (split) pl->split_batches++;
     hipStream_t T = split ? pl->dn[k % pl->dn.size()] : B; // the stream the batch's list is finished on
     // (a record's rewrite is ordered behind its readers by stream order: the slot meets the same stream every time -- unless the
@@ -527,8 +537,11 @@ static int finish_back(rmcv_pipeline* pl, bool latency)
                 rc = rmcv_batch_run(c, p, sparse, T);
             }
             ctx_defer_phase(c, 0);
-        } else
+        } else {
+            if (heavy) ctx_sparse_lean(c, 1); // (the launcher takes the lean build where it applies: fused stages, no classifier, the mid tier's scratch there)
             rc = lp ? rmcv_batch_run_legacy(c, p, lp, sparse, B) : rmcv_batch_run(c, p, sparse, B);
+            if (heavy) ctx_sparse_lean(c, 0);
+        }
         if (rc) return cfail(pl, c, rc);
     }
     PCHK(pl, hipEventRecord(pl->ev_free[k], T), "pipeline: mark the pixel outputs' last reader");
@@ -576,16 +589,22 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     const size_t k = (size_t)(t % (uint64_t)pl->cfg.depth);
     const bool used = pl->slot_ticket[k] != 0;
     pl->hot = hot_for(pl, n_frames, w, h);
-    if (pl->hot) { // the newest record that has come back: did any of its frames go beyond the LDS tables?
+    if (pl->cfg.host_results == 1) { // the newest record that has come back: did any of its frames go beyond the LDS tables?  how heavy was it?
         for (uint64_t d = 1; d <= (uint64_t)pl->cfg.depth && d <= t; d++) {
             const size_t s_ = (size_t)((t - d) % (uint64_t)pl->cfg.depth);
             if (pl->slot_ticket[s_] != t - d + 1 || !pl->h_rec[s_]) break;
             if (hipEventQuery(pl->ev_done[s_]) != hipSuccess) continue;
-            pl->calm = reinterpret_cast<const int32_t*>(pl->h_rec[s_])[pl->lim.max_frames + 2] == 0;
+            const uint32_t word2 = reinterpret_cast<const uint32_t*>(pl->h_rec[s_])[pl->lim.max_frames + 2];
+            const int dense = (int)(word2 & 0xFFFFFu), points = (int)(word2 >> 20) * 16; // frames beyond the LDS tables; border points per frame
+            pl->heavy = pl->heavy ? points >= 1200 : (dense * 8 > pl->slot_frames[s_] || points >= 1500);
+            pl->calm = dense == 0 && !pl->heavy;
             break;
         }
         (void)hipGetLastError(); // (hipErrorNotReady is not an error)
     }
+    // (dense mode needs the records on the host, the 4-wavefront kernel and two pixel streams to make up for the halved launches)
+    const bool heavy = pl->heavy && pl->cfg.host_results == 1 && pl->cfg.sparse_waves == 4 && pl->cfg.dense_streams >= 0 && !lp &&
+                       !(stages & (RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE)) && (stages & RMCV_STAGE_CONTOURS) && (stages & RMCV_STAGE_BLOBS);
     const bool fast = pl->hot && pl->calm && !lp && !(stages & RMCV_STAGE_POSE) && (pl->hot_identity || !(stages & RMCV_STAGE_IDENTITY));
     const size_t j = fast ? (size_t)(pl->hot_seq % (uint64_t)pl->hot) : k;
     rmcv_ctx* c = pl->ring[j];
@@ -643,12 +662,15 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
                 PCHK(pl, hipStreamWaitEvent(A, pl->ev_bin[s_], 0), "pipeline: chain a burst's second launch");
         }
     }
+    if (heavy) rmcv_ctx_set_option(c, RMCV_OPT_PIXEL_GROUPS, 1); // one pixel workgroup per CU and launch: room for two lean sparse workgroups
     rc = rmcv_batch_run(c, p, pixel, A);
+    if (heavy) rmcv_ctx_set_option(c, RMCV_OPT_PIXEL_GROUPS, pl->cfg.pixel_groups);
     if (rc) return cfail(pl, c, rc);
     pl->last_what = "the pixel kernel (k_binary / k_binary_ws)";
     // ---- accepted: the pipeline's state moves
     pl->was_cold = cold;
     if (fast) { pl->hot_seq++; pl->hot_batches++; }
+    if (heavy) pl->heavy_batches++;
     pl->ctx_last[j] = (int)k;
     pl->slot_ctx[k] = (int)j;
     PCHK(pl, hipEventRecord(pl->ev_bin[k], A), "pipeline: mark the pixel kernel");
@@ -663,6 +685,7 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     pl->pend.has_lp = lp != nullptr;
     if (lp) pl->pend.lp = *lp;
     pl->pend.used = used;
+    pl->pend.heavy = heavy;
     pl->pend.sparse = sparse;
     pl->pend.n_frames = n_frames;
     pl->pend.B = B;

@@ -226,7 +226,7 @@ __device__ __forceinline__ void normal_refine(NormalFac& Fac, int n, int lane, d
 
 // cv::fitEllipseDirect (objdetect.cpp:68) for one contour, by one wavefront.  sumx/sumy = integer coordinate sums.
 // returns 0 = direct solution, 1 = general fit.  All results are wave-uniform.
-#ifdef RMCV_PROFILE
+#ifdef RMCV_PROFILE_FITS
 #define FSTAMP(k) do { if (prof) prof[k] = wall_clock64(); } while (0)
 #else
 #define FSTAMP(k) do {} while (0)
@@ -441,7 +441,7 @@ __device__ inline void fit_contour_slot_at(int f, int k, int n, const rmcv_point
         sy = wave_sum_i64(sy);
         const double area = dabs(a00 * 0.5);
         if (area >= G.area_lo && area <= G.area_hi) {
-#ifdef RMCV_PROFILE
+#ifdef RMCV_PROFILE_FITS // (every fit prints: the phase timings of -DRMCV_PROFILE are only meaningful WITHOUT this one)
             long long pr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const int path = fit_ellipse_wave(cp, len, sx, sy, L, lane, &ell, pr);
             if (lane == 0 && ((f == 0 && len > 150) || (path == 1 && f < 64)))
@@ -608,5 +608,7 @@ struct SparseTail {
 
 hipError_t launch_contours_w4(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int force_literal, const SparseSched& Q, int grid,
                               hipStream_t s);
+// the lean build for dense streams (k_contours_lean.hip): every frame on the mid tier, two workgroups per CU; flags: 2 (+ 8: deferred frames only)
+hipError_t launch_contours_lean(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int flags, const SparseSched& Q, int grid, hipStream_t s);
 
 } // namespace rmcv

@@ -96,7 +96,7 @@ def test_pipeline_entry_points_without_a_gpu():
     import torch
     from rmcv_amd import abi
     L = abi.lib()
-    assert C.sizeof(abi.PipelineConfig) == 40 and C.sizeof(abi.PipelineInfo) == 144
+    assert C.sizeof(abi.PipelineConfig) == 40 and C.sizeof(abi.PipelineInfo) == 152
     cfg = abi.PipelineConfig()
     L.rmcv_default_pipeline_config(C.byref(cfg))
     assert (cfg.depth, cfg.pixel_streams, cfg.sparse_streams, cfg.sparse_waves, cfg.pixel_groups, cfg.host_results, cfg.dense_streams, cfg.hot_contexts) == (8, 2, 4, 4, 2, 1, 4, 0)

@@ -9,7 +9,7 @@ import time
 import numpy as np
 import pytest
 
-from rmcv_amd import (CAMP_BLUE, OPT_IMAGE_EXPORT, OPT_TEST_DELAY_US, OPT_WAIT_TIMEOUT_MS, STAGE_ALL, Context, Pipeline, RmcvError, default_params, synth)
+from rmcv_amd import (CAMP_BLUE, OPT_FRAME_UPLOAD, OPT_IMAGE_EXPORT, OPT_TEST_DELAY_US, OPT_TEST_SLOW_US, OPT_WAIT_TIMEOUT_MS, STAGE_ALL, Context, Pipeline, RmcvError, default_params, synth)
 from rmcv_amd import abi
 
 pytestmark = pytest.mark.gpu
@@ -111,3 +111,36 @@ def test_small_bursts_are_not_held_back():
         assert info.hot_batches > 0
         assert (info.held_back > 0) == want_held, (n, info.held_back)
         pl.close()
+
+
+def test_the_chain_leaves_the_runtimes_copies_while_they_are_slow(oracle):
+    """RMCV_OPT_FRAME_UPLOAD 3 / RMCV_OPT_IMAGE_EXPORT 2 (the defaults): the runtime's pageable copies while they are fast; three slow
+    frames in a row (here: RMCV_OPT_TEST_SLOW_US added to what the library measures) and the chain moves to the pinned staging buffer
+    and the export kernel, and back when they have recovered; the results never change"""
+    L = abi.lib()
+    c = Context(device=0, max_frames=1, max_width=1280, max_height=1024)
+    img = synth.frame(5, 1280, 1024, CAMP_BLUE, 1)
+    ref = oracle.detect_frame(img)
+
+    def paths():
+        us = (C.c_double * 9)()
+        assert L.rmcv_ctx_frame_timing(c._h, us, 9) == 0
+        return int(us[7]), int(us[8])
+
+    def one():
+        pts, offs, binary, blobs, arm = chain(c, img)
+        assert np.array_equal(binary, ref["binary"]) and np.array_equal(pts, ref["pts"]) and arm.tobytes() == ref["armours"].tobytes()
+        return paths()
+    assert [one() for _ in range(4)][-1] == (0, 0)                      # all is well: the runtime's copies
+    c.set_option(OPT_TEST_SLOW_US, 400)
+    seen = [one() for _ in range(5)]
+    assert seen[:3] == [(0, 0)] * 3 and seen[3:] == [(1, 1)] * 2, seen  # three slow frames, then the library's own paths
+    c.set_option(OPT_TEST_SLOW_US, 0)
+    for _ in range(512):
+        last = one()
+    assert last == (0, 0)                                               # 512 frames later the runtime's copies get another try -- and stay
+    c.set_option(OPT_FRAME_UPLOAD, 0)
+    c.set_option(OPT_IMAGE_EXPORT, 0)
+    c.set_option(OPT_TEST_SLOW_US, 400)
+    assert [one() for _ in range(5)][-1] == (0, 0)                      # pinned to the runtime's paths: no switch
+    c.close()

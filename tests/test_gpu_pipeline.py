@@ -450,3 +450,40 @@ def test_the_newest_batch_is_finished_by_the_call_that_waits_for_it(oracle):
     assert pl.get_info().latency_batches == 3
     t5 = pl.submit(d[5].data_ptr(), n, h, w, p, STAGE_ALL)
     pl.close()                                                         # a pipeline destroyed with a batch in hand finishes it first
+
+
+def test_dense_mode_follows_the_stream(oracle):
+    """a stream that turns heavy -- 400 specks per frame (dense2: frames the LDS tier still holds), then 2 000 (dense4: every frame beyond
+    it) -- and plain again: while the records say so the batches run in dense mode (the lean build of the sparse kernel, every frame on the
+    mid tier, two workgroups per CU; one pixel workgroup per CU and launch) and leave it when the stream calms down; every list equals
+    the oracle's whichever kernel produced it; submit never blocks"""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, w, h = 48, 1280, 1024
+    pl = Pipeline(device=0, max_frames=n, max_width=w, max_height=h, max_contours=4096)
+    p = default_params()
+    kinds = [0] * 10 + [12] * 12 + [14] * 10 + [0] * 14
+    host, devf, got = [], [], {}
+    heavy_at = []
+    for i, kind in enumerate(kinds):
+        fr = synth.batch(990000 + 37 * i, n, w, h, CAMP_BLUE, kind, threads=16)
+        host.append(fr)
+        devf.append(torch.from_numpy(fr).to(dev))
+        pl.submit(devf[i].data_ptr(), n, h, w, p, STAGE_ALL)
+        heavy_at.append(pl.get_info().heavy_batches)
+        if i >= 7:
+            got[i - 7] = pl.collect(i - 7)
+    pl.drain()
+    for i in range(len(kinds) - 7, len(kinds)):
+        got[i] = pl.collect(i)
+    for i in range(len(kinds)):
+        check_batch(oracle, host[i], *got[i])
+    info = pl.get_info()
+    is_heavy = np.diff([0] + heavy_at) > 0
+    assert not is_heavy[:10].any()                                     # the plain stream: never
+    assert is_heavy[12:32].sum() >= 8                                  # the dense part: once its first records are back
+    assert not is_heavy[-4:].any() and info.hot_batches > 0            # plain again: out of dense mode, back into the hot contexts
+    assert info.host_blocking_calls == 0
+    st = pl.context_of(len(kinds) - 1).counts()["status"]
+    assert not (st & abi.FRAME_MID_PATH).any()                         # the last plain batch ran the standard kernel
+    pl.close()

@@ -43,7 +43,12 @@ int main(int argc, char** argv)
     uint8_t* img[4];
     for (int i = 0; i < 4; i++) { img[i] = buf_alloc((size_t)3 * W * H); rmcv_synth_frame(img[i], W, H, 3 * W, (uint64_t)i, 1, 0); }
     uint8_t* binary = buf_alloc((size_t)W * H);
-    printf("cpu %d, FC_ALLOC=%s, binary at %p\n", sched_getcpu(), getenv("FC_ALLOC") ? getenv("FC_ALLOC") : "malloc", (void*)binary);
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        sched_getaffinity(0, sizeof(set), &set);
+        printf("cpu %d of %d allowed, FC_ALLOC=%s, binary at %p\n", sched_getcpu(), CPU_COUNT(&set), getenv("FC_ALLOC") ? getenv("FC_ALLOC") : "malloc", (void*)binary);
+    }
     rmcv_point* pts = malloc(sizeof(rmcv_point) * 65536);
     int32_t* offs = malloc(4 * 2049);
     rmcv_lightblob* blobs = malloc(sizeof(rmcv_lightblob) * 256);
@@ -52,15 +57,17 @@ int main(int argc, char** argv)
     static double tot[300], ec[300], st[7][300];
     static const char* st_name[7] = {"sync+bind+upload", "enqueue kernels", "first image chunk", "image chunks", "runtime copy", "wait kernels", "hand over"};
     for (int mode = 0; mode <= 2; mode += 2) {
-        rmcv_ctx_set_option(c, RMCV_OPT_FRAME_UPLOAD, mode);
+        rmcv_ctx_set_option(c, RMCV_OPT_FRAME_UPLOAD, mode == 0 ? (getenv("RMCV_FRAME_UPLOAD") ? atoi(getenv("RMCV_FRAME_UPLOAD")) : 3) : mode);
         int32_t nc = 0, np = 0, nb = 0, nn = 0, na = 0;
+        int n_up1 = 0, n_img1 = 0; /* chains that took the pinned staging buffer / the export kernel */
         for (int i = -8; i < N; i++) {
             const uint8_t* f = img[(i + 8) % 4];
             const double t0 = now_ms();
             int rc = rmcv_extract_color(c, f, W, H, 3 * W, RMCV_CAMP_BLUE, 80, RMCV_MORPH_CLOSE, binary, pts, 65536, offs, 2048, &nc, &np);
             const double t1 = now_ms();
-            double us[7] = {0};
-            rmcv_ctx_frame_timing(c, us, 7);
+            double us[9] = {0};
+            rmcv_ctx_frame_timing(c, us, 9);
+            if (i >= 0) { n_up1 += us[7] == 1; n_img1 += us[8] == 1; }
             if (i >= 0) for (int k = 0; k < 7; k++) st[k][i] = us[k];
             rc |= rmcv_filter_lightblobs(c, pts, offs, nc, 70.0f, 1.5f, 80.0f, 10.0, 99999.0, RMCV_CAMP_BLUE, blobs, 256, &nb, NULL, neg, &nn);
             rc |= rmcv_filter_armours(c, blobs, nb, 12.0f, 22.0f, 0.4f, RMCV_CAMP_BLUE, arms, 256, &na);
@@ -71,13 +78,13 @@ int main(int argc, char** argv)
         qsort(tot, N, sizeof(double), cmp);
         qsort(ec, N, sizeof(double), cmp);
         printf("%-20s median %.4f  min %.4f  p90 %.4f ms | extract_color median %.4f | contours %d blobs %d armours %d\n",
-               mode == 0 ? "runtime_pageable" : "registered_in_place", tot[N / 2], tot[0], tot[9 * N / 10], ec[N / 2], nc, nb, na);
+               mode == 0 ? "default_upload" : "registered_in_place", tot[N / 2], tot[0], tot[9 * N / 10], ec[N / 2], nc, nb, na);
         printf("    extract_color on the host, medians (p90) in us:");
         for (int k = 0; k < 7; k++) {
             qsort(st[k], N, sizeof(double), cmp);
             printf("  %s %.1f (%.1f)", st_name[k], st[k][N / 2], st[k][9 * N / 10]);
         }
-        printf("\n");
+        printf("  | chains on the staging buffer %d, on the export kernel %d of %d\n", n_up1, n_img1, N);
     }
     rmcv_ctx_destroy(c);
     return 0;
