@@ -38,6 +38,13 @@ namespace rmcv {
 
 static_assert(sizeof(ContoursLds) >= (CT_THREADS_MAX / 64) * sizeof(WaveLds), "the fit rows reuse the contour tables");
 
+// Geom::sparse_lean (a pipeline's dense mode) can be honoured: the mid tier applies to every frame (its scratch is there, the row tables
+// cover the frame).
+bool sparse_lean_applies(const Geom& g, const Bufs& b)
+{
+    return g.sparse_lean && !g.dense_defer && g.contour_tier == 0 && b.mid && g.h <= CT_MAXH && g.ww <= 32;
+}
+
 static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& lim, const SparseTail& X, int waves, hipStream_t s)
 {
     SparseSched Q;
@@ -52,11 +59,9 @@ static hipError_t launch_contours_x(const Geom& g, const Bufs& b, const Limits& 
         attr_set[g.device] = true;
     }
     const int force = force_literal ? force_literal : g.contour_tier;
-    // Geom::sparse_lean (a pipeline's dense mode): the whole batch through the lean build -- every frame on the mid tier, 61 KB of LDS, two
-    // workgroups per CU.  Only where the mid tier applies to every frame (its scratch is there, the row tables cover the frame) and no
-    // classifier stage rides along (the lean build has no room for its feature rows).
-    if (waves == 4 && g.sparse_lean && !g.dense_defer && force == 0 && b.mid && !X.C.enabled && g.h <= CT_MAXH && g.ww <= 32)
-        return launch_contours_lean(g, b, lim, X, 2, Q, grid, s);
+    // a pipeline's dense mode: the whole batch through the lean build (every frame on the mid tier, 61 KB of LDS: two workgroups per CU);
+    // not with a classifier stage (the lean build has no room for its feature rows)
+    if (waves == 4 && X.fused && !X.C.enabled && sparse_lean_applies(g, b) && force == 0) return launch_contours_lean(g, b, lim, X, 2, Q, grid, s);
     if (waves == 4) {
         // RMCV_OPT_DENSE_DEFER (off by default): the 4-wavefront launch leaves the frames beyond its LDS tables alone and the
         // 8-wavefront kernel takes them in a launch of its own right behind (1.4-1.5x faster per frame; a workgroup of any other

@@ -7,9 +7,14 @@
 // over 256 workgroup slots -- the stream becomes sparse-bound (dense4: 0.53 ms per step against the pixel kernel's 0.23).  A frame that
 // takes the mid tier needs none of the LDS tier's tables (label planes, node tables for 4 096 visits, per-word tables for 1 664 words):
 // compiled with those at token size the same kernel body needs the row tables, 36 KB for the mid tier's pointer doubling and staging
-// (which the fused tail's wave-private rows overlay afterwards) and a work list.  The pipeline switches a stream to this kernel, with
-// ONE pixel workgroup per CU and launch (two resident: 158 VGPRs, 28 KB), while the records that come back say the batches are heavy
+// (which the fused tail's wave-private rows overlay afterwards) and a work list.  The pipeline switches a stream to this kernel
+// while the records that come back say the batches are heavy
 // (rmcv_pipeline.hip: dense mode).  Same results: the mid tier is the same formulation as the LDS tier, bit for bit (tests/test_gpu_dense.py).
+// Measured (round 5, tools/dense_mode_ab.sh, ms per step off / on): dense2 0.320 / 0.291, dense3 0.396 / 0.372, dense4 0.571 / 0.512 (with
+// the pixel kernel's two workgroups per CU and launch; with one -- room for two of these per CU -- 0.314 / 0.368 / 0.504).  Tried and not kept: the same
+// build WITHOUT the fused tail (114 VGPRs, 6 spilled SGPRs instead of 155 / 292 -- the fits are what the registers go to) with k_fit
+// and k_pairs as launches of their own behind it: dense4 0.545 (rocprofv3: k_contours_lean 1.05 ms, k_fit 0.73 ms, k_pairs 0.08 ms per
+// batch, overlapped: a dense4 frame's 13 lit windows are 13 general fits of 50 us each, as heavy as its contours).
 #define RMCV_SLOT_CAP 64
 #define RMCV_KEPT_CAP 64
 #define RMCV_NN_CAP 2048

@@ -140,6 +140,7 @@ hipError_t launch_sparse(const Geom& g, const Bufs& b, const Limits& lim, const 
 hipError_t launch_pnp(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 hipError_t launch_binary(const Geom& g, const Bufs& b, int camp, int lower_bound, int morph, bool image, int groups, hipStream_t s);
 bool binary_ws_full(const Geom& g, const Bufs& b, int lower_bound); // the batch will run as one launch of k_binary_ws with a workgroup on every CU
+bool sparse_lean_applies(const Geom& g, const Bufs& b); // Geom::sparse_lean can be honoured for what is bound (k_contours.hip)
 hipError_t launch_contours(const Geom& g, const Bufs& b, const Limits& lim, hipStream_t s);
 hipError_t launch_blobs(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);
 hipError_t launch_armours(const Geom& g, const Bufs& b, const Limits& lim, const rmcv_params& p, hipStream_t s);

@@ -80,11 +80,15 @@ struct rmcv_pipeline {
     // DENSE MODE (round 5).  While the records that come back say the batches are heavy -- more than an eighth of the frames beyond
     // findContours' LDS tables, or 1 500 border points per frame and more (a plain frame has 650) -- the stream is bound by its sparse
     // stage, not by the pixel kernel: one workgroup of the standard sparse kernel per CU, 0.2-0.6 ms per frame.  Such batches run the LEAN
-    // build of the sparse kernel (k_contours_lean.hip: every frame on the mid tier, 61 KB of LDS) TWO workgroups per CU, beside ONE pixel
-    // workgroup per CU and launch instead of two.  The way back: fewer than 1 200 points per frame (in this mode every frame reports the
-    // mid tier, so only the points say what the stream is like).
+    // build of the sparse kernel (k_contours_lean.hip: every frame on the mid tier, 61 KB of LDS instead of 80).  The way back: fewer than
+    // 1 200 points per frame (in this mode every frame reports the mid tier, so only the points say what the stream is like).
+    // Measured (tools/dense_mode_ab.sh, process against process on one box, ms per step off / on): dense2 0.320 / 0.291, dense3 0.396 /
+    // 0.372, dense4 0.571 / 0.512; with ONE pixel workgroup per CU and launch as well (room for two lean workgroups per CU, but the pixel
+    // kernel needs four resident workgroups to hide its latency): 0.314 / 0.368 / 0.504 -- not kept as the default.
     bool heavy = false;
+    int heavy_pixel_groups = 0;        // pixel workgroups per CU and launch in dense mode; 0: as configured (dev knob RMCV_HEAVY_PG; -1: dense mode off)
     uint64_t heavy_batches = 0;
+    std::vector<char> slot_lean;       // per slot: its batch ran in dense mode (every frame of its record reports the mid tier)
     bool split_now = false;            // the batches of the moment have a FEW dense frames: give those a launch and a stream of their own
     uint64_t split_batches = 0;        // batches submitted that way
     rmcv_pipeline_hook hook = nullptr;
@@ -330,6 +334,7 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_gather, hipEventDisableTiming);
     pl->ctx_last.assign((size_t)d.depth, -1);
+    pl->slot_lean.assign((size_t)d.depth, 0);
     pl->slot_ctx.assign((size_t)d.depth, 0);
     pl->hot = hot_for(pl, pl->lim.max_frames, pl->lim.max_width, pl->lim.max_height); // (derived again for the geometry of every submit)
     pl->wait_timeout_ms = ctx_wait_timeout_ms(pl->ring[0]);
@@ -339,6 +344,8 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     if (getenv("RMCV_CHAIN_COLD")) pl->chain_cold_us = atoi(getenv("RMCV_CHAIN_COLD")) > 1 ? atoi(getenv("RMCV_CHAIN_COLD")) : 0;
     pl->early_free = !(getenv("RMCV_EARLY_FREE") && atoi(getenv("RMCV_EARLY_FREE")) == 0);
     if (getenv("RMCV_HOT_IDENTITY")) pl->hot_identity = atoi(getenv("RMCV_HOT_IDENTITY")) != 0;
+    if (getenv("RMCV_HEAVY_PG")) pl->heavy_pixel_groups = atoi(getenv("RMCV_HEAVY_PG")) > 0 ? atoi(getenv("RMCV_HEAVY_PG")) : 0;
+    if (getenv("RMCV_HEAVY_OFF") && atoi(getenv("RMCV_HEAVY_OFF"))) pl->heavy_pixel_groups = -1; // (dense mode off)
 #endif
     pl->blocking_base = ring_blocking(pl);
     if (e != hipSuccess) {
@@ -559,6 +566,7 @@ static int finish_back(rmcv_pipeline* pl, bool latency)
     PCHK(pl, hipEventRecord(pl->ev_done[k], T), "pipeline: mark the slot");
     pl->slot_ticket[k] = t + 1;
     pl->slot_frames[k] = n_frames;
+    pl->slot_lean[k] = heavy ? 1 : 0;
     pl->slot_stream[k] = T;
     if (pl->comm) {
         // one communicator: its operations must execute in one order on every rank; they are issued in ticket order on alternating
@@ -596,14 +604,15 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
             if (hipEventQuery(pl->ev_done[s_]) != hipSuccess) continue;
             const uint32_t word2 = reinterpret_cast<const uint32_t*>(pl->h_rec[s_])[pl->lim.max_frames + 2];
             const int dense = (int)(word2 & 0xFFFFFu), points = (int)(word2 >> 20) * 16; // frames beyond the LDS tables; border points per frame
-            pl->heavy = pl->heavy ? points >= 1200 : (dense * 8 > pl->slot_frames[s_] || points >= 1500);
+            // (decided from the record alone -- a dense-mode record says "every frame on the mid tier" by construction: only its points count)
+            pl->heavy = pl->slot_lean[s_] ? points >= 1200 : (dense * 8 > pl->slot_frames[s_] || points >= 1500);
             pl->calm = dense == 0 && !pl->heavy;
             break;
         }
         (void)hipGetLastError(); // (hipErrorNotReady is not an error)
     }
     // (dense mode needs the records on the host, the 4-wavefront kernel and two pixel streams to make up for the halved launches)
-    const bool heavy = pl->heavy && pl->cfg.host_results == 1 && pl->cfg.sparse_waves == 4 && pl->cfg.dense_streams >= 0 && !lp &&
+    const bool heavy = pl->heavy && pl->heavy_pixel_groups >= 0 && pl->cfg.host_results == 1 && pl->cfg.sparse_waves == 4 && pl->cfg.dense_streams >= 0 && !lp &&
                        !(stages & (RMCV_STAGE_IDENTITY | RMCV_STAGE_POSE)) && (stages & RMCV_STAGE_CONTOURS) && (stages & RMCV_STAGE_BLOBS);
     const bool fast = pl->hot && pl->calm && !lp && !(stages & RMCV_STAGE_POSE) && (pl->hot_identity || !(stages & RMCV_STAGE_IDENTITY));
     const size_t j = fast ? (size_t)(pl->hot_seq % (uint64_t)pl->hot) : k;
@@ -662,9 +671,9 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
                 PCHK(pl, hipStreamWaitEvent(A, pl->ev_bin[s_], 0), "pipeline: chain a burst's second launch");
         }
     }
-    if (heavy) rmcv_ctx_set_option(c, RMCV_OPT_PIXEL_GROUPS, 1); // one pixel workgroup per CU and launch: room for two lean sparse workgroups
+    if (heavy && pl->heavy_pixel_groups > 0) rmcv_ctx_set_option(c, RMCV_OPT_PIXEL_GROUPS, pl->heavy_pixel_groups);
     rc = rmcv_batch_run(c, p, pixel, A);
-    if (heavy) rmcv_ctx_set_option(c, RMCV_OPT_PIXEL_GROUPS, pl->cfg.pixel_groups);
+    if (heavy && pl->heavy_pixel_groups > 0) rmcv_ctx_set_option(c, RMCV_OPT_PIXEL_GROUPS, pl->cfg.pixel_groups);
     if (rc) return cfail(pl, c, rc);
     pl->last_what = "the pixel kernel (k_binary / k_binary_ws)";
     // ---- accepted: the pipeline's state moves
