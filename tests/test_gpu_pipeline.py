@@ -454,8 +454,8 @@ def test_the_newest_batch_is_finished_by_the_call_that_waits_for_it(oracle):
 
 def test_dense_mode_follows_the_stream(oracle):
     """a stream that turns heavy -- 400 specks per frame (dense2: frames the LDS tier still holds), then 2 000 (dense4: every frame beyond
-    it) -- and plain again: while the records say so the batches run in dense mode (the lean build of the sparse kernel, every frame on the
-    mid tier, two workgroups per CU; one pixel workgroup per CU and launch) and leave it when the stream calms down; every list equals
+    it) -- and plain again: while the records say so the batches run in dense mode (the lean build of the sparse kernel: every frame on the
+    mid tier, 61 KB of LDS instead of 80) and leave it when the stream calms down; every list equals
     the oracle's whichever kernel produced it; submit never blocks"""
     import torch
     dev = torch.device("cuda", 0)
