@@ -606,7 +606,7 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
             const int dense = (int)(word2 & 0xFFFFFu), points = (int)(word2 >> 20) * 16; // frames beyond the LDS tables; border points per frame
             // (decided from the record alone -- a dense-mode record says "every frame on the mid tier" by construction: only its points count)
             pl->heavy = pl->slot_lean[s_] ? points >= 1200 : (dense * 8 > pl->slot_frames[s_] || points >= 1500);
-            pl->calm = dense == 0 && !pl->heavy;
+            pl->calm = dense == 0 && !pl->heavy; // (measured once more in round 5: one 0.5 ms frame per batch in the hot contexts, its own launch or not: 0.424 ms per step against 0.27)
             break;
         }
         (void)hipGetLastError(); // (hipErrorNotReady is not an error)
