@@ -239,7 +239,10 @@ static constexpr int SLOT_CAP = RMCV_SLOT_CAP;
 // latency for one batch), 4 wavefronts leave room on every CU for the pixel kernels of the next batches AND the sparse kernel of the previous
 // one (VGPR budget per SIMD: 2 x 160 for this kernel at 8 wavefronts, 2 x 80 per pixel kernel, 512 in all) -- the better choice
 // when several batches are in flight (886 k against 800 k frames/s with three batches; 0.57 against 0.475 ms for a lone batch).
-static constexpr int CT_THREADS_MAX = 512;
+#ifndef RMCV_CT_THREADS_MAX
+#define RMCV_CT_THREADS_MAX 512
+#endif
+static constexpr int CT_THREADS_MAX = RMCV_CT_THREADS_MAX; // the largest workgroup a translation unit instantiates the kernel body with
 static constexpr int MULTI_CAP = 32;    // pixels of a frame visited 3 or 4 times (junctions of 1-pixel lines) the cycle formulation lists
 #ifndef RMCV_NN_CAP
 #define RMCV_NN_CAP VISIT_CAP

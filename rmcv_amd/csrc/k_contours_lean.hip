@@ -14,11 +14,19 @@
 // the pixel kernel's two workgroups per CU and launch; with one -- room for two of these per CU -- 0.314 / 0.368 / 0.504).  Tried and not kept: the same
 // build WITHOUT the fused tail (114 VGPRs, 6 spilled SGPRs instead of 155 / 292 -- the fits are what the registers go to) with k_fit
 // and k_pairs as launches of their own behind it: dense4 0.545 (rocprofv3: k_contours_lean 1.05 ms, k_fit 0.73 ms, k_pairs 0.08 ms per
-// batch, overlapped: a dense4 frame's 13 lit windows are 13 general fits of 50 us each, as heavy as its contours).
+// batch, overlapped: a dense4 frame's 13 lit windows are 13 general fits of 50 us each, as heavy as its contours); 24 KB instead of 34 for
+// the mid tier's LDS (two of these beside FOUR pixel workgroups by LDS): dense2 -1..-3 %, dense3 -3 %, dense4 +14 % (its 8 000 visits then
+// double their pointers in global memory); the register cap that would let two of them in by registers as well (96 VGPRs: 176 spilled,
+// 280 B of scratch per lane) faulted the queue (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION) -- the deadline waits turned that into an
+// error code after five seconds instead of a hung process -- and was not pursued.
 #define RMCV_SLOT_CAP 64
 #define RMCV_KEPT_CAP 64
 #define RMCV_NN_CAP 2048
-#define RMCV_MID_PAD 34816
+#define RMCV_CT_THREADS_MAX 256
+#ifndef RMCV_LEAN_PAD
+#define RMCV_LEAN_PAD 34816
+#endif
+#define RMCV_MID_PAD RMCV_LEAN_PAD
 #include "contours_device.h"
 
 #include <algorithm>
