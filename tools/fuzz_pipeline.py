@@ -27,6 +27,7 @@ checked = batches = 0
 t_end = time.time() + secs
 geom = geoms[0]
 i = 0
+last_kind = 0
 
 
 def check(t):
@@ -45,7 +46,10 @@ while time.time() < t_end:
         geom = geoms[int(rng.integers(len(geoms)))]
     w, h = geom
     n = int(rng.choice([NMAX, NMAX, NMAX, 40, 17, 5, 1]))
-    kind = int(rng.choice([0, 0, 0, 1, 2, 14]))
+    kind = int(rng.choice([0, 0, 0, 1, 2, 14, 12, 12, 13]))   # (12, 13: whole batches of dense2 / dense3 frames -- dense mode comes and goes)
+    if kind in (12, 13) and rng.random() < 0.7 and i > 0:
+        kind = last_kind if last_kind in (12, 13) else kind      # runs of dense batches
+    last_kind = kind
     fr = synth.batch(int(rng.integers(1 << 30)), n, w, h, CAMP_BLUE, kind if kind != 14 else 0, threads=16)
     if kind == 14:
         k = max(1, n // int(rng.choice([2, 8, 64])))
@@ -73,6 +77,7 @@ pl.drain()
 for t in sorted(pending):
     check(t)
 info = pl.get_info()
-print("fuzz_pipeline: %d batches, %d lists checked against the oracle, %d ran hot, %d with their dense frames split off: all equal" %
-      (batches, checked, info.hot_batches, info.dense_split))
+assert info.host_blocking_calls == 0
+print("fuzz_pipeline: %d batches, %d lists checked against the oracle, %d ran hot, %d with their dense frames split off, %d in dense mode, 0 blocking calls in submit: all equal" %
+      (batches, checked, info.hot_batches, info.dense_split, info.heavy_batches))
 pl.close()
