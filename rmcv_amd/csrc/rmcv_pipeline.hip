@@ -109,6 +109,7 @@ struct rmcv_pipeline {
     const char* last_what = "nothing"; // the enqueue made last (PCHK's label): named when a wait runs out
     int hot_cfg = 0;                   // rmcv_pipeline_config::hot_contexts as given (0: derived from the bound geometry)
     int64_t hot_plane_bytes = 0;       // ... the bit planes' bytes of a batch of the geometry `hot` was derived for
+    bool ws_always = false;            // dev knob RMCV_WS_ALWAYS: the wave-specialised pixel kernel for every batch, hot rotation or not
     bool hot_identity = false;         // batches with a classifier stage take turns at the hot contexts too: measured in round 5 (three contexts at
                                        // 256 x 1920x1200: 0.514 against 0.426 ms per step), off; RMCV_HOT_IDENTITY=1 in a dev build
     double max_submit_us = 0;          // the longest single submit call (host time) since rmcv_pipeline_reset_stats
@@ -344,6 +345,7 @@ int rmcv_pipeline_create(int device, const rmcv_limits* limits, const rmcv_pipel
     if (getenv("RMCV_CHAIN_COLD")) pl->chain_cold_us = atoi(getenv("RMCV_CHAIN_COLD")) > 1 ? atoi(getenv("RMCV_CHAIN_COLD")) : 0;
     pl->early_free = !(getenv("RMCV_EARLY_FREE") && atoi(getenv("RMCV_EARLY_FREE")) == 0);
     if (getenv("RMCV_HOT_IDENTITY")) pl->hot_identity = atoi(getenv("RMCV_HOT_IDENTITY")) != 0;
+    if (getenv("RMCV_WS_ALWAYS")) pl->ws_always = atoi(getenv("RMCV_WS_ALWAYS")) != 0;
     if (getenv("RMCV_HEAVY_PG")) pl->heavy_pixel_groups = atoi(getenv("RMCV_HEAVY_PG")) > 0 ? atoi(getenv("RMCV_HEAVY_PG")) : 0;
     if (getenv("RMCV_HEAVY_OFF") && atoi(getenv("RMCV_HEAVY_OFF"))) pl->heavy_pixel_groups = -1; // (dense mode off)
 #endif
@@ -641,7 +643,7 @@ static int submit(rmcv_pipeline* pl, const void* d_frames, int n_frames, int w, 
     if ((rc = ctx_check_stages(c, p, stages))) return cfail(pl, c, rc);
     const int pixel = stages & (RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE), sparse = stages & ~(RMCV_STAGE_BINARY | RMCV_STAGE_NO_IMAGE);
     ctx_external_order(c, pl->ev_done[k]);
-    ctx_pixel_shape(c, fast ? 1 : 0);
+    ctx_pixel_shape(c, (fast || pl->ws_always) ? 1 : 0);
     // A burst's SECOND pixel launch is held back (k_delay on its stream).  k_binary_ws is one workgroup per CU: when two launches
     // reach an empty machine 15 us apart, whether the first has taken every CU by then is a coin toss -- if not, the two split the
     // CUs, run side by side and END together, and so do the next pairs (each pair's ramp and tail in the open, both sparse kernels
