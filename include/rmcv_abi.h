@@ -206,7 +206,7 @@ const char* rmcv_last_error(const rmcv_ctx* ctx);
  * is well (0.186 ms per 1280x1024 chain from a C host), but the copy happens INSIDE the runtime's call and was measured at 160-280 us
  * instead of 35 in some processes (bench.py's C-host child: the chain 0.28-0.40 ms); 1: a kernel on the library's side stream copies
  * the image into pinned host memory chunk by chunk, raising a flag per chunk that the host polls in memory, and the library copies
- * the chunks into `binary_out` as they arrive -- no runtime-internal wait anywhere in the chain: 0.192 ms alone, 0.19-0.22 ms where
+ * the chunks into `binary_out` as they arrive -- no runtime-internal wait anywhere in the chain: 0.190 ms alone, 0.19-0.20 ms where
  * the runtime's copy is slow; 2 (default): 0, and 1 while 0 is slow (three slow frames in a row -> 512 frames on the library's
  * path, then another try; see RMCV_OPT_FRAME_UPLOAD).  Same bytes. */
 #define RMCV_OPT_IMAGE_EXPORT 17

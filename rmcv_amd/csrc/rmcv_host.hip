@@ -568,37 +568,37 @@ namespace rmcv {
 // full-size pipelines beside the chain, by 12 hardware queues, or by how the caller's buffer is backed: tools/chain_ab.sh,
 // chain_beside.sh, chain_queues.sh).  This path has no runtime-internal wait: a kernel on the side stream copies the image into pinned host
 // memory chunk by chunk and raises a flag word per chunk (system-scope release behind the chunk's stores); the host polls the flags
-// in memory -- no HIP call -- and copies each chunk into the caller's buffer while the next ones cross PCIe.  Measured: 0.192 ms per
-// chain alone (the runtime's copy: 0.186), 0.207-0.220 as bench.py's child (the runtime's copy: 0.279-0.396).
-constexpr int IMG_CHUNKS = 16, IMG_GROUPS = 16; // (measured: 16 x 16 0.192 ms per chain; 16 chunks x 32 groups 0.205-0.211; 4 x 64 0.204-0.212; all chunks at once 0.195-0.20)
+// in memory -- no HIP call -- and copies each chunk into the caller's buffer while the next ones cross PCIe.  Measured: 0.190 ms per
+// chain alone (the runtime's copy: 0.186), 0.19-0.20 where the runtime's copy reads 0.28-0.40.
+constexpr int IMG_CHUNKS = 16, IMG_CHUNKS_DEFAULT = 8, IMG_GROUPS = 16; // IMG_CHUNKS: the flags' capacity.  Measured (1280x1024, from C, ms per chain; the runtime's copy: 0.186): 8 chunks x 16 workgroups 0.190, 4 x 8 0.189, 16 x 16 0.193, 8 x 8 0.195, 4 x 16 0.199, 8 x 32 0.200, 2 x 16 0.201, 1 x 16 0.207 (a fence per chunk and workgroup costs microseconds; all chunks at once leave the CPU copy nothing to overlap)
 // All IMG_GROUPS workgroups work on chunk 0 first, then on chunk 1, ...: the chunks reach the host ONE AFTER THE OTHER (the CPU copies
 // chunk g into the caller's buffer while chunk g + 1 crosses PCIe), not all at the end.  A workgroup that has stored its slice of a
 // chunk (system-scope fence behind the stores) counts itself in; the last one raises the chunk's flag in host memory.
 __global__ __launch_bounds__(256) void k_image_export(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, long long bytes,
-                                                      uint32_t* __restrict__ flags, uint32_t seq, uint32_t* __restrict__ arrived)
+                                                      uint32_t* __restrict__ flags, uint32_t seq, uint32_t* __restrict__ arrived, int n_chunks)
 {
     const int wg = blockIdx.x, tid = threadIdx.x;
-    const long long per = ((bytes + IMG_CHUNKS - 1) / IMG_CHUNKS + 15) & ~15ll; // (the host computes the same chunk bounds: image_chunk)
-    for (int g = 0; g < IMG_CHUNKS; g++) {
+    const long long per = ((bytes + n_chunks - 1) / n_chunks + 15) & ~15ll; // (the host computes the same chunk bounds: image_chunk)
+    for (int g = 0; g < n_chunks; g++) {
         const long long lo = (long long)g * per < bytes ? (long long)g * per : bytes, hi = lo + per < bytes ? lo + per : bytes;
         const long long hv = lo + ((hi - lo) & ~15ll);
-        for (long long o = lo + ((long long)wg * 256 + tid) * 16; o < hv; o += (long long)IMG_GROUPS * 256 * 16)
+        for (long long o = lo + ((long long)wg * 256 + tid) * 16; o < hv; o += (long long)gridDim.x * 256 * 16)
             *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src + o);
         if (wg == 0 && hv + tid < hi) dst[hv + tid] = src[hv + tid]; // (the image's last bytes: fewer than 16)
         __threadfence_system();
         __syncthreads();
         if (tid == 0) {
             const uint32_t before = __hip_atomic_fetch_add(&arrived[g], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (before == IMG_GROUPS - 1) {
+            if (before == gridDim.x - 1) {
                 __hip_atomic_store(&arrived[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (for the next frame: launches of one context are ordered)
                 __hip_atomic_store(&flags[g], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
 }
-static inline void image_chunk(long long bytes, int g, long long* lo, long long* hi)
+static inline void image_chunk(long long bytes, int n_chunks, int g, long long* lo, long long* hi)
 {
-    const long long per = ((bytes + IMG_CHUNKS - 1) / IMG_CHUNKS + 15) & ~15ll;
+    const long long per = ((bytes + n_chunks - 1) / n_chunks + 15) & ~15ll;
     *lo = (long long)g * per < bytes ? (long long)g * per : bytes;
     *hi = *lo + per < bytes ? *lo + per : bytes;
 }
@@ -1479,11 +1479,13 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
         const long long bytes = (long long)w * h;
         if (++c->img_seq == 0) c->img_seq = 1;
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0), "image download: fork");
-        HIPCHK(c, launch(k_image_export, dim3(IMG_GROUPS), dim3(256), 0, c->side, b.binary, c->hd_image, bytes, c->hd_iflags, c->img_seq, c->d_iarrived), "k_image_export");
+        static const int env_chunks = getenv("RMCV_IMG_CHUNKS") ? atoi(getenv("RMCV_IMG_CHUNKS")) : 0, env_groups = getenv("RMCV_IMG_GROUPS") ? atoi(getenv("RMCV_IMG_GROUPS")) : 0; // dev knobs
+        const int n_chunks = env_chunks >= 1 && env_chunks <= IMG_CHUNKS ? env_chunks : IMG_CHUNKS_DEFAULT, n_groups = env_groups >= 1 && env_groups <= 256 ? env_groups : IMG_GROUPS;
+        HIPCHK(c, launch(k_image_export, dim3(n_groups), dim3(256), 0, c->side, b.binary, c->hd_image, bytes, c->hd_iflags, c->img_seq, c->d_iarrived, n_chunks), "k_image_export");
         c->last_what = "k_binary, k_image_export";
         const volatile uint32_t* fl = c->h_iflags;
         const double t0w = now_us();
-        for (int gch = 0; gch < IMG_CHUNKS; gch++) {
+        for (int gch = 0; gch < n_chunks; gch++) {
             for (unsigned spins = 0; fl[gch] != c->img_seq; spins++) {
                 __builtin_ia32_pause();
                 if ((spins & 1023u) == 1023u) {
@@ -1495,7 +1497,7 @@ static int extract_color_body(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
             if (gch == 0) c->marks[3] = now_us(); // upload and pixel kernel are through, the first chunk is home
             long long lo, hi;
-            image_chunk(bytes, gch, &lo, &hi);
+            image_chunk(bytes, n_chunks, gch, &lo, &hi);
             if (hi > lo) memcpy(binary_out + lo, c->h_image + lo, (size_t)(hi - lo));
         }
         c->marks[4] = now_us(); // the byte image is in the caller's buffer
