@@ -1217,10 +1217,11 @@ static int upload_one(rmcv_ctx* c, const uint8_t* bgr, int w, int h, int stride,
         HIPCHK(c, hipHostMalloc((void**)&c->h_frame, cap, hipHostMallocDefault), "pinned frame staging");
         c->h_frame_bytes = cap;
     }
-    // two halves: the DMA of the first runs while the CPU copies the second
-    const int h0 = h / 2;
-    for (int part = 0; part < 2; part++) {
-        const int y0 = part ? h0 : 0, y1 = part ? h : h0;
+    // two halves: the DMA of the first runs while the CPU copies the second (eight pieces, measured in round 5: 0.254-0.281 ms per chain
+    // against 0.223 -- every further hipMemcpyAsync costs the host 4-5 us, more than the earlier start of the DMA buys)
+    const int parts = 2;
+    for (int part = 0; part < parts; part++) {
+        const int y0 = (int)((long long)h * part / parts), y1 = (int)((long long)h * (part + 1) / parts);
         if (y1 <= y0) continue;
         if (stride == dstride) memcpy(c->h_frame + (size_t)y0 * dstride, bgr + (size_t)y0 * stride, (size_t)(y1 - y0) * dstride);
         else
