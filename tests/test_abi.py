@@ -130,3 +130,24 @@ def test_bench_refuses_silent_dev_knobs():
         bench.dev_knobs({"RMCV_BENCH_STAGES": "1", "HOME": "/x"}, False)
     assert "RMCV_BENCH_STAGES" in str(e.value)
     assert bench.dev_knobs({"RMCV_SPARSE_WAVES": "8", "RMCV_K1_BPC": ""}, True) == {"RMCV_SPARSE_WAVES": "8"}
+
+
+def test_round5_entry_points_without_a_gpu():
+    """the deadline / diagnosis entry points check their arguments; rmcv_hw_queues_hint sets GPU_MAX_HW_QUEUES only where it is unset
+    (the library itself no longer touches the environment when it is loaded: ADVICE r4)"""
+    import subprocess
+    import sys
+    from rmcv_amd import abi
+    L = abi.lib()
+    us = (C.c_double * 9)()
+    assert L.rmcv_ctx_frame_timing(None, us, 9) == abi.ERR_BAD_ARG
+    assert L.rmcv_pipeline_reset_stats(None) == abi.ERR_BAD_ARG and L.rmcv_pipeline_set_wait_timeout(None, 5) == abi.ERR_BAD_ARG
+    assert abi.ERR_TIMEOUT == -7 and abi.OPT_WAIT_TIMEOUT_MS == 15 and abi.OPT_IMAGE_EXPORT == 17
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); "
+            "from rmcv_amd import abi; L = abi.lib(); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "print(libc.getenv(b'GPU_MAX_HW_QUEUES'), L.rmcv_hw_queues_hint(), libc.getenv(b'GPU_MAX_HW_QUEUES'))" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.split()
+    assert out == ["None", "12", "b'12'"], out                       # loading the library leaves the variable alone; the hint sets it
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="6"), capture_output=True, text=True, timeout=120).stdout.split()
+    assert out == ["b'6'", "6", "b'6'"], out                         # ... and never overrides the host's own value
